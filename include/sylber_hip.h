@@ -1,0 +1,118 @@
+/*
+ * sylber_hip.h — C-ABI of libsylber_hip.so: the MI355X (gfx950) implementation of the SYLBER
+ * Segmenter forward path.
+ *
+ * The reference has no FFI layer; its de-facto operator boundary is three Python call sites inside
+ * Segmenter.__call__ (reference: sylber/model/sylber.py):
+ *   (1) sylber.py:122   hidden = self.speech_model(batch, attention_mask=mask).last_hidden_state
+ *                       (transformers.HubertModel, 9 layers)           -> sylber_forward()
+ *   (2) sylber.py:126   get_segment(states, norm_threshold, merge_threshold)
+ *                       (sylber/utils/segment_utils.py:72-131)         -> sylber_segment()
+ *   (3) sylber.py:133   states[s:e].mean(0) per segment                -> sylber_segment() (fused)
+ * and the weight hand-over at construction, sylber.py:41-54
+ *   (HubertModel(config); load_state_dict(strict=False); eval().to(device)) -> sylber_create().
+ *
+ * Conventions: extern "C", opaque handle, int status (0 = ok, non-zero = error; text via
+ * sylber_last_error()), no exceptions and no torch / HIP types in the signatures.  All *_dev
+ * pointers are device pointers owned by the caller; `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  Calls are stream-ordered and asynchronous.  A handle is bound to one
+ * GPU and is not thread-safe; distinct handles are independent.
+ */
+#ifndef SYLBER_HIP_H
+#define SYLBER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYLBER_MAX_LAYERS 12
+#define SYLBER_HIDDEN 768
+#define SYLBER_CONV_DIM 512
+
+typedef struct sylber_ctx* sylber_t;
+
+/* compute precision of the encoder GEMMs */
+enum { SYLBER_BF16 = 0, SYLBER_FP32 = 1 };
+
+/* HOST pointers to fp32 weights in the layout of HubertModel.state_dict().
+ * Replaces the state_dict hand-over at sylber.py:51-54. */
+typedef struct {
+    const float* q_w; const float* q_b;       /* [768,768],[768] */
+    const float* k_w; const float* k_b;
+    const float* v_w; const float* v_b;
+    const float* o_w; const float* o_b;
+    const float* ln1_w; const float* ln1_b;   /* layer_norm */
+    const float* ff1_w; const float* ff1_b;   /* intermediate_dense [3072,768],[3072] */
+    const float* ff2_w; const float* ff2_b;   /* output_dense [768,3072],[768] */
+    const float* ln2_w; const float* ln2_b;   /* final_layer_norm */
+} SylberLayerWeights;
+
+typedef struct {
+    int32_t num_layers;                        /* encoding_layer, sylber.py:34 (default 9) */
+    const float* conv_w[7];                    /* [512,1,10], 4x[512,512,3], 2x[512,512,2] */
+    const float* gn_w; const float* gn_b;      /* conv_layers.0.layer_norm (GroupNorm affine) [512] */
+    const float* fp_ln_w; const float* fp_ln_b;/* feature_projection.layer_norm [512] */
+    const float* fp_w; const float* fp_b;      /* feature_projection.projection [768,512],[768] */
+    const float* pos_w;                        /* EFFECTIVE pos-conv weight g*v/||v|| [768,48,128] */
+    const float* pos_b;                        /* [768] */
+    const float* enc_ln_w; const float* enc_ln_b;
+    SylberLayerWeights layers[SYLBER_MAX_LAYERS];
+} SylberWeights;
+
+/* number of 50 Hz frames the 7-layer conv stack yields for n_samples (TP:664-677) */
+int32_t sylber_num_frames(int32_t n_samples);
+
+/* copies + packs the weights onto `device` (bf16 MFMA layouts, conv taps interleaved) */
+int sylber_create(const SylberWeights* w, int device, int precision, sylber_t* out);
+void sylber_destroy(sylber_t h);
+const char* sylber_last_error(void);
+
+/* (1) waveform batch -> last_hidden_state.
+ *   wav_dev      [B, Lmax] fp32, rows right-padded with zeros (sylber.py:99-117)
+ *   lengths_host [B] valid samples per row (the attention_mask of sylber.py:104-118, run-length
+ *                coded), or NULL for "all rows full" (identical numerics to an all-ones mask)
+ *   hidden_dev   [B, T, 768] fp32, T = sylber_num_frames(Lmax); padded frames are computed and
+ *                returned exactly like the reference does (sylber.py:125-135)
+ */
+int sylber_forward(sylber_t h, const float* wav_dev, const int32_t* lengths_host, int32_t B, int32_t Lmax,
+                   float* hidden_dev, void* stream);
+
+/* (2)+(3) boundary detection + segment mean-pool, one workgroup per utterance, bit-exact w.r.t. the
+ * reference's numpy float32 evaluation order.
+ *   hidden_dev [B, T, D] fp32 (D = 768 on the product path)
+ *   seg_dev    [B, T, 2] int64  (start, end-exclusive) frame indices, first nseg_dev[b] rows valid
+ *   nseg_dev   [B] int32
+ *   feat_dev   [B, T, D] fp32 mean-pooled features, first nseg_dev[b] rows valid (may be NULL)
+ */
+int sylber_segment(sylber_t h, const float* hidden_dev, int32_t B, int32_t T, int32_t D, float norm_thr,
+                   float merge_thr, int64_t* seg_dev, int32_t* nseg_dev, float* feat_dev, void* stream);
+
+/* ---- introspection used by parity tests and the benchmark ------------------------------------ */
+/* run sylber_forward only up to a stage: 0 = all, 1 = conv stack, 2 = +projection/pos-conv/LN,
+ * 3 + l = through encoder layer l.  The stage output is written to hidden_dev in place of the final
+ * hidden states: stage 1 -> [B,T,512] conv features, otherwise [B,T,768]. */
+int sylber_set_stop_stage(sylber_t h, int32_t stage);
+/* per-kernel device time of the last forward, measured with HIP events on the launch stream.
+ * names/ms arrays of capacity cap; returns the number of entries (<=cap) or <0 on error. */
+int sylber_set_profiling(sylber_t h, int32_t enable);
+int sylber_get_profile(sylber_t h, const char** names, float* ms, int32_t cap);
+/* bytes of device workspace currently held by the handle */
+int64_t sylber_workspace_bytes(sylber_t h);
+
+/* ---- single-op entry points (unit parity tests; same kernels the forward path launches) ------ */
+/* C[M,N] (fp32) = A[M,K] (fp32, cast to bf16) x W[N,K]^T (fp32, cast to bf16) + bias[N] (nullable); act: 0 none, 1 gelu */
+int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, float* c_dev, int32_t M,
+                     int32_t N, int32_t K, int32_t act, int32_t precision, void* stream);
+/* y = LayerNorm(x [+ res]) over the last dim D (512 or 768), eps 1e-5 */
+int sylber_op_layernorm(const float* x_dev, const float* res_dev, const float* g_dev, const float* b_dev,
+                        float* y_dev, int32_t M, int32_t D, void* stream);
+/* softmax(q k^T / 8 + key mask) v ; q,k,v,o: [B,T,768] fp32 (12 heads x 64); valid_dev [B] int32 */
+int sylber_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const int32_t* valid_dev,
+                        float* o_dev, int32_t B, int32_t T, int32_t precision, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYLBER_HIP_H */

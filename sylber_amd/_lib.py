@@ -1,0 +1,73 @@
+"""ctypes binding of libsylber_hip.so (include/sylber_hip.h).  There is no CPU fallback: if the
+HIP library is missing or fails to load, importing the product path raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsylber_hip.so")
+MAX_LAYERS = 12
+
+c_float_p = POINTER(c_float)
+
+
+class SylberLayerWeights(ctypes.Structure):
+    _fields_ = [(n, c_float_p) for n in (
+        "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b", "ln1_w", "ln1_b",
+        "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ln2_w", "ln2_b")]
+
+
+class SylberWeights(ctypes.Structure):
+    _fields_ = [("num_layers", c_int32), ("conv_w", c_float_p * 7), ("gn_w", c_float_p), ("gn_b", c_float_p),
+                ("fp_ln_w", c_float_p), ("fp_ln_b", c_float_p), ("fp_w", c_float_p), ("fp_b", c_float_p),
+                ("pos_w", c_float_p), ("pos_b", c_float_p), ("enc_ln_w", c_float_p), ("enc_ln_b", c_float_p),
+                ("layers", SylberLayerWeights * MAX_LAYERS)]
+
+
+EXPORTS = {
+    "sylber_num_frames": (c_int32, [c_int32]),
+    "sylber_create": (c_int, [POINTER(SylberWeights), c_int, c_int, POINTER(c_void_p)]),
+    "sylber_destroy": (None, [c_void_p]),
+    "sylber_last_error": (c_char_p, []),
+    "sylber_forward": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int32, c_int32, c_void_p, c_void_p]),
+    "sylber_segment": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+    "sylber_set_stop_stage": (c_int, [c_void_p, c_int32]),
+    "sylber_set_profiling": (c_int, [c_void_p, c_int32]),
+    "sylber_get_profile": (c_int, [c_void_p, POINTER(c_char_p), POINTER(c_float), c_int32]),
+    "sylber_workspace_bytes": (c_int64, [c_void_p]),
+    "sylber_op_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                 c_void_p]),
+    "sylber_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "sylber_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                    c_void_p]),
+}
+
+_LIB = None
+
+
+class SylberHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SylberHipError(
+                "libsylber_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python sylber_amd/build.py`; there is no CPU fallback on the product path." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)      # AttributeError if the ABI drifted from include/sylber_hip.h
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise SylberHipError("%s failed: %s" % (what, load().sylber_last_error().decode()))

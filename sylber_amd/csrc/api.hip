@@ -1,0 +1,443 @@
+// C-ABI of libsylber_hip.so (see include/sylber_hip.h): handle, weight packing, workspace, and the
+// launch sequence of the Segmenter forward path
+//   sylber/model/sylber.py:122  speech_model(batch, attention_mask).last_hidden_state
+//   sylber/model/sylber.py:126  get_segment(...)            sylber.py:133  segment mean-pool
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sylber_hip.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+void syl_set_error(const char* what, const char* detail) { snprintf(g_err, sizeof(g_err), "%s: %s", what, detail); }
+extern "C" const char* sylber_last_error(void) { return g_err; }
+
+static const int CK[7] = {10, 3, 3, 3, 3, 2, 2};
+static const int CS[7] = {5, 2, 2, 2, 2, 2, 2};
+
+extern "C" int32_t sylber_num_frames(int32_t n) {
+    for (int i = 0; i < 7; ++i) n = (n - CK[i]) / CS[i] + 1;
+    return n;
+}
+
+struct LayerDev {
+    bf16_t *wqkv, *wo, *w1, *w2;
+    float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
+};
+
+struct ProfEntry { std::string name; hipEvent_t e0, e1; };
+
+struct sylber_ctx {
+    int device = 0, precision = 0, num_layers = 9;
+    // weights
+    char* wbase = nullptr; size_t wbytes = 0;
+    float *conv0_w, *gn_w, *gn_b, *fp_ln_w, *fp_ln_b, *fp_b, *pos_b, *enc_ln_w, *enc_ln_b;
+    bf16_t* conv_w[7];
+    bf16_t *fp_w, *pos_w;
+    LayerDev L[SYLBER_MAX_LAYERS];
+    // workspace
+    char* ws = nullptr; size_t ws_bytes = 0;
+    int ws_B = 0, ws_Lmax = 0;
+    float* seg_scratch = nullptr; size_t seg_scratch_floats = 0;
+    int stop_stage = 0;
+    // profiling
+    int profiling = 0;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::string> prof_names; std::vector<float> prof_ms;
+};
+
+// ------------------------------------------------------------------------------------------------
+struct Packer {
+    std::vector<char> host;
+    size_t add(size_t bytes) { size_t off = (host.size() + 255) & ~(size_t)255; host.resize(off + bytes); return off; }
+    size_t add_f32(const float* src, size_t n) { size_t o = add(n * 4); memcpy(host.data() + o, src, n * 4); return o; }
+    size_t add_bf16(const float* src, size_t n) {
+        size_t o = add(n * 2);
+        bf16_t* d = (bf16_t*)(host.data() + o);
+        for (size_t i = 0; i < n; ++i) d[i] = f2bf(src[i]);
+        return o;
+    }
+};
+
+extern "C" int sylber_create(const SylberWeights* w, int device, int precision, sylber_t* out) {
+    if (!w || !out) { syl_set_error("sylber_create", "null argument"); return 1; }
+    if (w->num_layers < 1 || w->num_layers > SYLBER_MAX_LAYERS) { syl_set_error("sylber_create", "num_layers out of range"); return 1; }
+    if (precision != SYLBER_BF16) { syl_set_error("sylber_create", "only SYLBER_BF16 is implemented in this build"); return 1; }
+    HIP_TRY(hipSetDevice(device));
+    sylber_ctx* c = new sylber_ctx();
+    c->device = device; c->precision = precision; c->num_layers = w->num_layers;
+    Packer P;
+    size_t o_conv0 = P.add_f32(w->conv_w[0], 512 * 10);
+    size_t o_gnw = P.add_f32(w->gn_w, 512), o_gnb = P.add_f32(w->gn_b, 512);
+    size_t o_conv[7] = {0};
+    for (int i = 1; i < 7; ++i) {
+        // [o][c][j] -> [o][j*512 + c]: one output position's receptive field is then ONE contiguous
+        // run of taps*512 channels-last activations (implicit GEMM with ldx = stride*512)
+        const int k = CK[i];
+        std::vector<float> tmp((size_t)512 * k * 512);
+        for (int o = 0; o < 512; ++o)
+            for (int cc = 0; cc < 512; ++cc)
+                for (int j = 0; j < k; ++j) tmp[((size_t)o * k + j) * 512 + cc] = w->conv_w[i][((size_t)o * 512 + cc) * k + j];
+        o_conv[i] = P.add_bf16(tmp.data(), tmp.size());
+    }
+    size_t o_fplw = P.add_f32(w->fp_ln_w, 512), o_fplb = P.add_f32(w->fp_ln_b, 512);
+    size_t o_fpw = P.add_bf16(w->fp_w, 768 * 512), o_fpb = P.add_f32(w->fp_b, 768);
+    size_t o_posw;
+    {
+        // [768 = g*48+n][48 c][128 tap] -> [g][tap][64 n][56 c] (zero padded), 112-byte rows
+        std::vector<float> tmp((size_t)16 * 128 * 64 * 56, 0.f);
+        for (int g = 0; g < 16; ++g)
+            for (int n = 0; n < 48; ++n)
+                for (int cc = 0; cc < 48; ++cc)
+                    for (int t = 0; t < 128; ++t)
+                        tmp[(((size_t)g * 128 + t) * 64 + n) * 56 + cc] = w->pos_w[(((size_t)g * 48 + n) * 48 + cc) * 128 + t];
+        o_posw = P.add_bf16(tmp.data(), tmp.size());
+    }
+    size_t o_posb = P.add_f32(w->pos_b, 768);
+    size_t o_elw = P.add_f32(w->enc_ln_w, 768), o_elb = P.add_f32(w->enc_ln_b, 768);
+    struct LOff { size_t wqkv, bqkv, wo, bo, l1w, l1b, w1, b1, w2, b2, l2w, l2b; } lo[SYLBER_MAX_LAYERS];
+    for (int l = 0; l < w->num_layers; ++l) {
+        const SylberLayerWeights& lw = w->layers[l];
+        std::vector<float> qkv((size_t)2304 * 768), bq(2304);
+        memcpy(qkv.data(), lw.q_w, 768 * 768 * 4);
+        memcpy(qkv.data() + 768 * 768, lw.k_w, 768 * 768 * 4);
+        memcpy(qkv.data() + 2 * 768 * 768, lw.v_w, 768 * 768 * 4);
+        memcpy(bq.data(), lw.q_b, 768 * 4); memcpy(bq.data() + 768, lw.k_b, 768 * 4); memcpy(bq.data() + 1536, lw.v_b, 768 * 4);
+        lo[l].wqkv = P.add_bf16(qkv.data(), qkv.size()); lo[l].bqkv = P.add_f32(bq.data(), 2304);
+        lo[l].wo = P.add_bf16(lw.o_w, 768 * 768); lo[l].bo = P.add_f32(lw.o_b, 768);
+        lo[l].l1w = P.add_f32(lw.ln1_w, 768); lo[l].l1b = P.add_f32(lw.ln1_b, 768);
+        lo[l].w1 = P.add_bf16(lw.ff1_w, (size_t)3072 * 768); lo[l].b1 = P.add_f32(lw.ff1_b, 3072);
+        lo[l].w2 = P.add_bf16(lw.ff2_w, (size_t)768 * 3072); lo[l].b2 = P.add_f32(lw.ff2_b, 768);
+        lo[l].l2w = P.add_f32(lw.ln2_w, 768); lo[l].l2b = P.add_f32(lw.ln2_b, 768);
+    }
+    c->wbytes = P.host.size();
+    if (hipMalloc((void**)&c->wbase, c->wbytes) != hipSuccess) { delete c; syl_set_error("sylber_create", "hipMalloc(weights) failed"); return 1; }
+    if (hipMemcpy(c->wbase, P.host.data(), c->wbytes, hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(c->wbase); delete c; syl_set_error("sylber_create", "weight upload failed"); return 1;
+    }
+    char* b = c->wbase;
+    c->conv0_w = (float*)(b + o_conv0); c->gn_w = (float*)(b + o_gnw); c->gn_b = (float*)(b + o_gnb);
+    c->conv_w[0] = nullptr;
+    for (int i = 1; i < 7; ++i) c->conv_w[i] = (bf16_t*)(b + o_conv[i]);
+    c->fp_ln_w = (float*)(b + o_fplw); c->fp_ln_b = (float*)(b + o_fplb);
+    c->fp_w = (bf16_t*)(b + o_fpw); c->fp_b = (float*)(b + o_fpb);
+    c->pos_w = (bf16_t*)(b + o_posw); c->pos_b = (float*)(b + o_posb);
+    c->enc_ln_w = (float*)(b + o_elw); c->enc_ln_b = (float*)(b + o_elb);
+    for (int l = 0; l < w->num_layers; ++l) {
+        LayerDev& d = c->L[l];
+        d.wqkv = (bf16_t*)(b + lo[l].wqkv); d.bqkv = (float*)(b + lo[l].bqkv);
+        d.wo = (bf16_t*)(b + lo[l].wo); d.bo = (float*)(b + lo[l].bo);
+        d.ln1w = (float*)(b + lo[l].l1w); d.ln1b = (float*)(b + lo[l].l1b);
+        d.w1 = (bf16_t*)(b + lo[l].w1); d.b1 = (float*)(b + lo[l].b1);
+        d.w2 = (bf16_t*)(b + lo[l].w2); d.b2 = (float*)(b + lo[l].b2);
+        d.ln2w = (float*)(b + lo[l].l2w); d.ln2b = (float*)(b + lo[l].l2b);
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void sylber_destroy(sylber_t c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->wbase) hipFree(c->wbase);
+    if (c->ws) hipFree(c->ws);
+    if (c->seg_scratch) hipFree(c->seg_scratch);
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" int sylber_set_stop_stage(sylber_t c, int32_t stage) { if (!c) return 1; c->stop_stage = stage; return 0; }
+// enabling (or re-enabling) profiling resets the accumulated per-kernel times
+extern "C" int sylber_set_profiling(sylber_t c, int32_t enable) {
+    if (!c) return 1;
+    const char* nm[1]; float ms[1];
+    sylber_get_profile(c, nm, ms, 0);   // retire pending events
+    c->prof_names.clear(); c->prof_ms.clear();
+    c->profiling = enable;
+    return 0;
+}
+extern "C" int64_t sylber_workspace_bytes(sylber_t c) { return c ? (int64_t)(c->ws_bytes + c->seg_scratch_floats * 4 + c->wbytes) : 0; }
+
+// ------------------------------------------------------------------------------------------------
+struct Plan {
+    int B, Lmax, L[7], T, Tp, Tpv, R[7];
+    size_t o_bufA, o_bufB, o_ln512, o_xf32, o_xpad, o_pre, o_hf32, o_hbf16, o_q, o_k, o_vt, o_ctx, o_ffn, o_part, o_ss, o_valid,
+        total;
+    int nchunk;
+};
+
+static void make_plan(int B, int Lmax, Plan& p) {
+    p.B = B; p.Lmax = Lmax;
+    int n = Lmax;
+    for (int i = 0; i < 7; ++i) { n = (n - CK[i]) / CS[i] + 1; p.L[i] = n; }
+    p.T = p.L[6];
+    int tp = 0;
+    for (int i = 0; i < 7; ++i) { const int f = 1 << (6 - i); const int need = (p.L[i] + f - 1) / f; tp = need > tp ? need : tp; }
+    p.Tp = (tp + 3) & ~3;
+    p.Tpv = (p.Tp + 63) & ~63;
+    for (int i = 0; i < 7; ++i) p.R[i] = p.Tp << (6 - i);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t M = (size_t)B * p.Tp;
+    p.o_bufA = take(((size_t)B * p.R[0] + 8) * 512 * 2);
+    p.o_bufB = take(((size_t)B * p.R[1] + 8) * 512 * 2);
+    p.o_ln512 = take(M * 512 * 2);
+    p.o_xf32 = take(M * 768 * 4);
+    p.o_xpad = take((size_t)B * (p.Tp + 128) * 768 * 2);
+    p.o_pre = take(M * 768 * 4);
+    p.o_hf32 = take(M * 768 * 4);
+    p.o_hbf16 = take((M + 128) * 768 * 2);
+    p.o_q = take(M * 768 * 2);
+    p.o_k = take(M * 768 * 2);
+    p.o_vt = take((size_t)B * 12 * 64 * p.Tpv * 2);
+    p.o_ctx = take((M + 128) * 768 * 2);
+    p.o_ffn = take((M + 128) * 3072 * 2);
+    p.nchunk = (p.L[0] + 2047) / 2048;
+    p.o_part = take((size_t)B * p.nchunk * 65 * 8);
+    p.o_ss = take((size_t)B * 512 * 2 * 4);
+    p.o_valid = take((size_t)B * 4);
+    p.total = off;
+}
+
+static int ensure_workspace(sylber_ctx* c, const Plan& p, hipStream_t s) {
+    if (p.total > c->ws_bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->ws) HIP_TRY(hipFree(c->ws));
+        c->ws = nullptr; c->ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&c->ws, p.total));
+        c->ws_bytes = p.total;
+        c->ws_B = 0;
+    }
+    if (c->ws_B != p.B || c->ws_Lmax != p.Lmax) {
+        // layout changed: padded regions (pos-conv halo, V^T tail, slack rows) must read as zeros
+        HIP_TRY(hipMemsetAsync(c->ws, 0, p.total, s));
+        c->ws_B = p.B; c->ws_Lmax = p.Lmax;
+    }
+    return 0;
+}
+
+struct ProfScope {
+    sylber_ctx* c; hipStream_t s; bool on;
+    ProfScope(sylber_ctx* c_, hipStream_t s_, const char* name) : c(c_), s(s_), on(c_->profiling != 0) {
+        if (!on) return;
+        ProfEntry e; e.name = name;
+        auto get = [&]() { hipEvent_t ev; if (c->ev_pool.empty()) { hipEventCreate(&ev); } else { ev = c->ev_pool.back(); c->ev_pool.pop_back(); } return ev; };
+        e.e0 = get(); e.e1 = get();
+        hipEventRecord(e.e0, s);
+        c->prof.push_back(e);
+    }
+    ~ProfScope() { if (on) hipEventRecord(c->prof.back().e1, s); }
+};
+
+extern "C" int sylber_get_profile(sylber_t c, const char** names, float* ms, int32_t cap) {
+    if (!c) return -1;
+    if (!c->prof.empty()) {
+        c->prof_names.clear(); c->prof_ms.clear();
+        for (auto& e : c->prof) {
+            hipEventSynchronize(e.e1);
+            float t = 0.f;
+            hipEventElapsedTime(&t, e.e0, e.e1);
+            size_t i = 0;
+            for (; i < c->prof_names.size(); ++i) if (c->prof_names[i] == e.name) break;
+            if (i == c->prof_names.size()) { c->prof_names.push_back(e.name); c->prof_ms.push_back(0.f); }
+            c->prof_ms[i] += t;
+            c->ev_pool.push_back(e.e0); c->ev_pool.push_back(e.e1);
+        }
+        c->prof.clear();
+    }
+    int n = (int)c->prof_names.size();
+    n = n < cap ? n : cap;
+    for (int i = 0; i < n; ++i) { names[i] = c->prof_names[i].c_str(); ms[i] = c->prof_ms[i]; }
+    return n;
+}
+
+#define RUN(name, call)                         \
+    do {                                        \
+        ProfScope _ps(c, s, name);              \
+        if ((call) != 0) return 1;              \
+    } while (0)
+
+extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* lengths_host, int32_t B, int32_t Lmax,
+                              float* hidden_dev, void* stream) {
+    if (!c || !wav_dev || !hidden_dev) { syl_set_error("sylber_forward", "null argument"); return 1; }
+    if (B < 1 || Lmax < 400) { syl_set_error("sylber_forward", "need B >= 1 and at least 400 samples (one frame)"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    Plan p;
+    make_plan(B, Lmax, p);
+    if (ensure_workspace(c, p, s)) return 1;
+    char* w = c->ws;
+    bf16_t* bufA = (bf16_t*)(w + p.o_bufA); bf16_t* bufB = (bf16_t*)(w + p.o_bufB);
+    bf16_t* ln512 = (bf16_t*)(w + p.o_ln512);
+    float* xf32 = (float*)(w + p.o_xf32); bf16_t* xpad = (bf16_t*)(w + p.o_xpad);
+    float* pre = (float*)(w + p.o_pre); float* hf32 = (float*)(w + p.o_hf32); bf16_t* hbf = (bf16_t*)(w + p.o_hbf16);
+    bf16_t* q = (bf16_t*)(w + p.o_q); bf16_t* k = (bf16_t*)(w + p.o_k); bf16_t* vt = (bf16_t*)(w + p.o_vt);
+    bf16_t* ctx = (bf16_t*)(w + p.o_ctx); bf16_t* ffn = (bf16_t*)(w + p.o_ffn);
+    double* part = (double*)(w + p.o_part); float* ss = (float*)(w + p.o_ss); int* valid = (int*)(w + p.o_valid);
+    const int M = B * p.Tp;
+
+    // valid frames per utterance (TP:664-689): conv-length formula of the number of valid samples
+    {
+        std::vector<int> v(B);
+        for (int i = 0; i < B; ++i) {
+            int n = lengths_host ? lengths_host[i] : Lmax;
+            if (n > Lmax || n < 400) { syl_set_error("sylber_forward", "lengths must be in [400, Lmax]"); return 1; }
+            v[i] = sylber_num_frames(n);
+        }
+        HIP_TRY(hipMemcpyAsync(valid, v.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    // ---- conv layer 0 + GroupNorm + GELU
+    RUN("conv0_stats", launch_conv0_stats(wav_dev, B, Lmax, p.L[0], part, p.nchunk, s));
+    RUN("conv0_finalize", launch_conv0_finalize(part, p.nchunk, c->conv0_w, c->gn_w, c->gn_b, B, p.L[0], ss, s));
+    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s));
+    // ---- conv layers 1..6 as implicit GEMM (ping-pong)
+    bf16_t* src = bufA; bf16_t* dst = bufB;
+    for (int i = 1; i < 7; ++i) {
+        GemmArgs a = {};
+        a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w[i];
+        a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = 1;
+        a.out0 = dst; a.ld0 = 512;
+        static const char* nm[7] = {"", "gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_conv6"};
+        RUN(nm[i], launch_gemm_bf16(EPI_BF16, a, s));
+        bf16_t* t = src; src = dst; dst = t;
+    }
+    bf16_t* feats = src;   // [B*Tp][512]
+    if (c->stop_stage == 1) {
+        RUN("copy_out", launch_bf16_to_f32_rows(feats, 512, hidden_dev, B, p.Tp, p.T, 512, s));
+        return 0;
+    }
+    // ---- feature projection: LN(512) -> Linear(512->768), zero padded frames
+    {
+        LnArgs a = {};
+        a.in = feats; a.in_bf16 = 1; a.ld_in = 512; a.gamma = c->fp_ln_w; a.beta = c->fp_ln_b;
+        a.out_bf16 = ln512; a.ld_bf16 = 512; a.M = M; a.D = 512;
+        RUN("ln512", launch_layernorm(a, s));
+        GemmArgs g = {};
+        g.X = ln512; g.ldx = 512; g.W = c->fp_w; g.M = M; g.N = 768; g.K = 512; g.bias = c->fp_b;
+        g.out0 = xf32; g.ld0 = 768; g.out1 = xpad; g.Tp = p.Tp; g.T = p.T; g.valid = valid; g.xpad_rows = p.Tp + 128;
+        RUN("gemm_proj", launch_gemm_bf16(EPI_PROJ, g, s));
+    }
+    // ---- positional conv + residual, encoder LayerNorm
+    RUN("posconv", launch_posconv(xpad, c->pos_w, c->pos_b, xf32, pre, B, p.Tp, 1, s));
+    auto run_ln = [&](const float* gam, const float* bet, bool last) -> int {
+        LnArgs a = {};
+        a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = M; a.D = 768;
+        if (last) { a.out_f32 = hidden_dev; a.ld_f32 = 768; a.Tp = p.Tp; a.T = p.T; }
+        else { a.out_f32 = hf32; a.ld_f32 = 768; a.out_bf16 = hbf; a.ld_bf16 = 768; }
+        return launch_layernorm(a, s);
+    };
+    RUN("layernorm", run_ln(c->enc_ln_w, c->enc_ln_b, c->stop_stage == 2));
+    if (c->stop_stage == 2) return 0;
+    // ---- encoder layers (post-LN)
+    for (int l = 0; l < c->num_layers; ++l) {
+        const LayerDev& d = c->L[l];
+        const bool last = (l == c->num_layers - 1) || (c->stop_stage == 3 + l);
+        GemmArgs g = {};
+        g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 2304; g.K = 768; g.bias = d.bqkv;
+        g.out0 = q; g.out1 = k; g.out2 = vt; g.Tp = p.Tp; g.Tpv = p.Tpv; g.T = p.T;
+        RUN("gemm_qkv", launch_gemm_bf16(EPI_QKV, g, s));
+        RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, s));
+        GemmArgs o = {};
+        o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
+        o.out0 = pre; o.ld0 = 768; o.res = hf32; o.ldres = 768;
+        RUN("gemm_out", launch_gemm_bf16(EPI_F32_RES, o, s));
+        RUN("layernorm", run_ln(d.ln1w, d.ln1b, false));
+        GemmArgs f1 = {};
+        f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = 1;
+        f1.out0 = ffn; f1.ld0 = 3072;
+        RUN("gemm_ffn1", launch_gemm_bf16(EPI_BF16, f1, s));
+        GemmArgs f2 = {};
+        f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
+        f2.out0 = pre; f2.ld0 = 768; f2.res = hf32; f2.ldres = 768;
+        RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RES, f2, s));
+        RUN("layernorm", run_ln(d.ln2w, d.ln2b, last));
+        if (last) break;
+    }
+    return 0;
+}
+
+extern "C" int sylber_segment(sylber_t c, const float* hidden_dev, int32_t B, int32_t T, int32_t D, float norm_thr,
+                              float merge_thr, int64_t* seg_dev, int32_t* nseg_dev, float* feat_dev, void* stream) {
+    if (!c || !hidden_dev || !seg_dev || !nseg_dev) { syl_set_error("sylber_segment", "null argument"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t need = segment_scratch_floats(B, T, D);
+    if (need > c->seg_scratch_floats) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->seg_scratch) HIP_TRY(hipFree(c->seg_scratch));
+        c->seg_scratch = nullptr; c->seg_scratch_floats = 0;
+        HIP_TRY(hipMalloc((void**)&c->seg_scratch, need * 4));
+        c->seg_scratch_floats = need;
+    }
+    ProfScope ps(c, s, "segment");
+    return launch_segment(hidden_dev, B, T, D, norm_thr, merge_thr, seg_dev, nseg_dev, feat_dev, c->seg_scratch, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-op entry points for unit parity tests
+struct TmpBuf {
+    void* p = nullptr;
+    ~TmpBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes) == hipSuccess ? 0 : 1; }
+};
+
+extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, float* c_dev, int32_t M,
+                                int32_t N, int32_t K, int32_t act, int32_t precision, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (precision != SYLBER_BF16) { syl_set_error("sylber_op_linear", "only bf16"); return 1; }
+    TmpBuf ab, wb;
+    if (ab.alloc(((size_t)M + 128) * K * 2) || wb.alloc(((size_t)N + 128) * K * 2)) { syl_set_error("sylber_op_linear", "alloc"); return 1; }
+    if (launch_f32_to_bf16(a_dev, (bf16_t*)ab.p, (size_t)M * K, s)) return 1;
+    if (launch_f32_to_bf16(w_dev, (bf16_t*)wb.p, (size_t)N * K, s)) return 1;
+    GemmArgs g = {};
+    g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev; g.act = act;
+    g.out0 = c_dev; g.ld0 = N;
+    if (launch_gemm_bf16(EPI_F32, g, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int sylber_op_layernorm(const float* x_dev, const float* res_dev, const float* g_dev, const float* b_dev,
+                                   float* y_dev, int32_t M, int32_t D, void* stream) {
+    LnArgs a = {};
+    a.in = x_dev; a.in_bf16 = 0; a.ld_in = D; a.res = res_dev; a.ld_res = D; a.gamma = g_dev; a.beta = b_dev;
+    a.out_f32 = y_dev; a.ld_f32 = D; a.M = M; a.D = D;
+    return launch_layernorm(a, (hipStream_t)stream);
+}
+
+// q,k,v [B,T,768] f32 -> bf16 head-major q (x0.125), k and key-permuted V^T
+__global__ void pack_qkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                bf16_t* __restrict__ qo, bf16_t* __restrict__ ko, bf16_t* __restrict__ vto, int T, int Tp, int Tpv) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    for (int c = threadIdx.x; c < 768; c += 256) {
+        const int head = c >> 6, d = c & 63;
+        const size_t src = ((size_t)b * T + t) * 768 + c;
+        const size_t hm = (((size_t)b * 12 + head) * Tp + t) * 64 + d;
+        qo[hm] = f2bf(q[src] * 0.125f);
+        ko[hm] = f2bf(k[src]);
+        const int pos = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
+        vto[(((size_t)b * 12 + head) * 64 + d) * Tpv + pos] = f2bf(v[src]);
+    }
+}
+
+extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const int32_t* valid_dev,
+                                   float* o_dev, int32_t B, int32_t T, int32_t precision, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (precision != SYLBER_BF16) { syl_set_error("sylber_op_attention", "only bf16"); return 1; }
+    const int Tp = (T + 3) & ~3, Tpv = (Tp + 63) & ~63;
+    TmpBuf qb, kb, vb, cb;
+    const size_t n = (size_t)B * Tp * 768;
+    if (qb.alloc(n * 2) || kb.alloc(n * 2) || vb.alloc((size_t)B * 768 * Tpv * 2) || cb.alloc(n * 2)) { syl_set_error("sylber_op_attention", "alloc"); return 1; }
+    HIP_TRY(hipMemsetAsync(qb.p, 0, n * 2, s)); HIP_TRY(hipMemsetAsync(kb.p, 0, n * 2, s));
+    HIP_TRY(hipMemsetAsync(vb.p, 0, (size_t)B * 768 * Tpv * 2, s)); HIP_TRY(hipMemsetAsync(cb.p, 0, n * 2, s));
+    hipLaunchKernelGGL(pack_qkv_kernel, dim3(T, B), dim3(256), 0, s, q_dev, k_dev, v_dev, (bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, T, Tp, Tpv);
+    if (launch_attention((bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, valid_dev, (bf16_t*)cb.p, B, T, Tp, Tpv, s)) return 1;
+    if (launch_bf16_to_f32_rows((bf16_t*)cb.p, 768, o_dev, B, Tp, T, 768, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}

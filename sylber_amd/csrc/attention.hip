@@ -1,0 +1,184 @@
+// Flash-style multi-head self-attention for gfx950 (12 heads x 64, bidirectional, key-padding mask).
+//
+// Reference semantics (transformers HubertAttention / sdpa, TP:234-344, reached from
+// sylber/model/sylber.py:122): ctx = softmax(q k^T * 64^-0.5 + mask) v where the additive mask is
+// -inf on PADDED KEYS only (padded queries are still computed), and absent when nothing is padded.
+//
+// Everything is kept "query = lane & 31":
+//   S^T[key][q] = K . Q^T      A = K tile (LDS, rows = keys), B = Q (registers, loaded once)
+//   O^T[d][q]   = V^T . P^T    A = V^T tile (LDS, rows = d),  B = P (registers, straight from S^T)
+// With v_mfma_f32_32x32x16_bf16 the C layout of S^T gives lane (q, h = lane>>5) the keys
+// 8g + 4h + e (g < 4, e < 4) of a 32-key tile; those 16 values, rounded to bf16, ARE the B operand of
+// the two 16-key P.V MFMAs if V^T's key axis is stored with bits 2 and 3 swapped (done for free by the
+// QKV GEMM epilogue, see gemm_bf16.hip).  So there is no P transpose, no cross-lane traffic for P, and
+// the online-softmax running max / sum / rescale are lane-local (one shuffle with lane^32 per tile).
+// K and V^T tiles (64 keys) are staged with global_load_lds_dwordx4 into a double buffer, XOR-swizzled
+// through the source address so the ds_read_b128 fragment reads are bank-conflict free.
+#include "kernels.h"
+
+#define AT_QBLK 128      // queries per workgroup (4 waves x 32)
+#define AT_KV 64         // keys per tile
+#define AT_TILE 8192     // bytes of one K or V^T tile
+#define AT_LDS (4 * AT_TILE)
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+__device__ __forceinline__ void glds16a(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((glb_vptr)g, (lds_vptr)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                const bf16_t* __restrict__ Vt, const int* __restrict__ valid,
+                                                                bf16_t* __restrict__ ctx, int T, int Tp, int Tpv) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * AT_QBLK + wave * 32;
+    const int ql = lane & 31, h = lane >> 5;
+    int nvalid = valid ? valid[b] : T;
+    nvalid = nvalid < T ? nvalid : T;
+    const size_t bh = (size_t)b * SYL_HEADS + head;
+    const bf16_t* Qb = Q + bh * Tp * 64;
+    const bf16_t* Kb = K + bh * Tp * 64;
+    const bf16_t* Vb = Vt + bh * 64 * Tpv;
+
+    // Q fragments (B operand): lane (q, h) holds d = 16 ks + 8 h .. +8
+    bf16x8_t qf[4];
+    {
+        int qr = q0 + ql; qr = qr < Tp ? qr : Tp - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(Qb + (size_t)qr * 64 + ks * 16 + h * 8);
+    }
+    // staging: wave w fills rows [16w, 16w+16) of the K tile and of the V^T tile, 8 rows per instruction
+    const int srow = lane >> 3, spos = lane & 7;
+    const bf16_t* gk[2];
+    const bf16_t* gv[2];
+    int krow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 16 + i * 8 + srow;
+        const int c = spos ^ ((r >> 1) & 7);
+        krow[i] = r;
+        gk[i] = Kb + c * 8;                        // + key row * 64 added per tile (clamped)
+        gv[i] = Vb + (size_t)r * Tpv + c * 8;      // + kv0 per tile
+    }
+    const int lds_piece = wave * 16 * 128;
+
+    const int swz = (lane >> 1) & 7;
+    const int frow = ql * 128;
+
+    f32x16_t oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float LOG2E = 1.44269504088896341f;
+
+    const int nt = (nvalid + AT_KV - 1) / AT_KV;
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int kr = krow[i]; kr = kr < Tp ? kr : Tp - 1;
+            glds16a(gk[i] + (size_t)kr * 64, smem + lds_piece + i * 1024);
+            glds16a(gv[i], smem + AT_TILE + lds_piece + i * 1024);
+        }
+    }
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        if (t + 1 < nt) {
+            char* kb = smem + ((t + 1) & 1) * 2 * AT_TILE;
+            const int kv1 = (t + 1) * AT_KV;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int kr = kv1 + krow[i]; kr = kr < Tp ? kr : Tp - 1;
+                glds16a(gk[i] + (size_t)kr * 64, kb + lds_piece + i * 1024);
+                glds16a(gv[i] + kv1, kb + AT_TILE + lds_piece + i * 1024);
+            }
+        }
+        const char* kb = smem + (t & 1) * 2 * AT_TILE;
+        const char* vb = kb + AT_TILE;
+        const int kv0 = t * AT_KV;
+
+        // ---- S^T = K . Q^T  (two 32-key sub-tiles)
+        f32x16_t sacc[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[s][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(kb + s * 32 * 128 + frow + (((2 * ks + h) ^ swz) << 4));
+                sacc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[s], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (lane-local; partner lane^32 holds the other 32 keys of this query)
+        float mx = -INFINITY;
+        const bool tail = kv0 + AT_KV > nvalid;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (tail) {
+                    const int key = kv0 + 32 * s + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= nvalid) sacc[s][r] = -INFINITY;
+                }
+                mx = fmaxf(mx, sacc[s][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);           // finite: key 0 is always valid
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        const float mb = m_new * LOG2E;
+        float psum = 0.f;
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[s][8 * j + e], LOG2E, -mb));
+                    psum += p;
+                    pf[2 * s + j][e] = (__bf16)p;
+                }
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        // ---- O^T += V^T . P^T  (four 16-key groups x two 32-wide d blocks)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                const bf16x8_t vf = *(const bf16x8_t*)(vb + ds * 32 * 128 + frow + (((2 * u + h) ^ swz) << 4));
+                oacc[ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u], oacc[ds], 0, 0, 0);
+            }
+    }
+    // ---- finalize: 1/l, store ctx[b*Tp + q][head*64 + d]
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + ql;
+    if (q < T) {
+        bf16_t* dst = ctx + ((size_t)b * Tp + q) * SYL_HIDDEN + head * 64;
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16x2(oacc[ds][4 * g + 0] * inv, oacc[ds][4 * g + 1] * inv);
+                pk.y = pack_bf16x2(oacc[ds][4 * g + 2] * inv, oacc[ds][4 * g + 3] * inv);
+                *(uint2*)(dst + 32 * ds + 8 * g + 4 * h) = pk;
+            }
+    }
+}
+
+int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T, int Tp,
+                     int Tpv, hipStream_t s) {
+    if (Tpv % 64 != 0 || Tpv < T) { syl_set_error("launch_attention", "Tpv must be a multiple of 64 and >= T"); return 1; }
+    dim3 grid((T + AT_QBLK - 1) / AT_QBLK, SYL_HEADS, B);
+    hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), AT_LDS, s, q, k, vt, valid, ctx, T, Tp, Tpv);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,91 @@
+// Shared device/host helpers for libsylber_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 bits in HBM
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+
+#define SYL_HIDDEN 768
+#define SYL_CONV 512
+#define SYL_HEADS 12
+#define SYL_HDIM 64
+#define SYL_FFN 3072
+#define SYL_POSK 128
+#define SYL_POSG 16
+#define SYL_POSC 48
+
+// ---- bf16 <-> f32 (round to nearest even; NaN kept quiet) ---------------------------------------
+__host__ __device__ __forceinline__ bf16_t f2bf(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__host__ __device__ __forceinline__ float bf2f(bf16_t h) {
+    union { float f; uint32_t u; } v; v.u = ((uint32_t)h) << 16;
+    return v.f;
+}
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// device-side packing: the fptrunc lowers to v_cvt_pk_bf16_f32 (RNE) on gfx950
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    bf16x2_t p;
+    p[0] = (__bf16)lo;
+    p[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, p);
+}
+__device__ __forceinline__ bf16_t f2bf_dev(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+// ---- GELU --------------------------------------------------------------------------------------
+// exact erf form (reference: transformers activations "gelu" = 0.5 x (1 + erf(x / sqrt 2)))
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Abramowitz-Stegun 7.1.26 erf, |abs err| <= 1.5e-7: one v_rcp + one v_exp + 7 fma; used where
+// the result is rounded to bf16 anyway (relative step 3.9e-3).
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896341f);
+    const float erf_abs = fmaf(-p, e, 1.0f);
+    const float erf_x = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_x);
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// bijective XCD-aware remap of a linear workgroup id: consecutive ids land on consecutive XCDs
+// (observed dispatch: block b -> XCD b % 8); give each XCD a contiguous chunk of the tile space so
+// neighbouring tiles (sharing an operand panel) share one L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) { syl_set_error(#expr, hipGetErrorString(_e)); return 1; }      \
+    } while (0)
+
+void syl_set_error(const char* what, const char* detail);

@@ -1,0 +1,267 @@
+// HBM-bound kernels of the conv frontend and the normalisations (gfx950).
+//
+//  * conv layer 0 of HubertFeatureEncoder (TP:160-175, reached from sylber/model/sylber.py:122):
+//    Conv1d(1->512, k=10, s=5, no bias) -> GroupNorm(512 groups: per (b,c) statistics over TIME,
+//    zero padding included) -> GELU.  GroupNorm needs the full-time mean/variance before the first
+//    output can be written.  Because conv0 is linear in the waveform, its per-channel moments follow
+//    from the 10 strided sums S_j = sum_l x[5l+j] and the 10x10 lag products R_jj' = sum_l x[5l+j]x[5l+j']:
+//        mean_c = w_c . S / L,   E[v_c^2] = w_c^T R w_c / L.
+//    So the statistics pass reads only the waveform (0.64 MB per 10 s clip) in fp64, and the
+//    16.4 M-element conv0 output is produced exactly once, already normalised + activated, as
+//    channels-last bf16 rows of 1 KiB (one wave stores one row: fully coalesced).
+//  * LayerNorm(512/768) rows (TP:225-231, 441, 392-397): one wave per row, values held in registers,
+//    two-pass mean/variance, fp32 and/or bf16 outputs (the bf16 copy feeds the next MFMA GEMM).
+#include "kernels.h"
+
+#define NSTAT 65  // 10 sums + 55 upper-triangular lag products
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ wav, int Lmax, int L0, int chunk,
+                                                          double* __restrict__ partials, int nchunk) {
+    const int b = blockIdx.y, ck = blockIdx.x;
+    const float* x = wav + (size_t)b * Lmax;
+    const int l0 = ck * chunk;
+    const int l1 = min(L0, l0 + chunk);
+    double acc[NSTAT];
+#pragma unroll
+    for (int i = 0; i < NSTAT; ++i) acc[i] = 0.0;
+    for (int l = l0 + threadIdx.x; l < l1; l += 256) {
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = x[5 * l + j];
+        int q = 10;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            acc[j] += (double)v[j];
+#pragma unroll
+            for (int k = j; k < 10; ++k) acc[q++] += (double)v[j] * (double)v[k];
+        }
+    }
+    __shared__ double red[4][NSTAT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NSTAT; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NSTAT)
+        partials[((size_t)b * nchunk + ck) * NSTAT + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// one block per utterance, one thread per channel: a_c = gamma/sqrt(var+eps), b_c = beta - mean*a_c
+__global__ __launch_bounds__(512) void conv0_finalize_kernel(const double* __restrict__ partials, int nchunk,
+                                                             const float* __restrict__ w0, const float* __restrict__ gn_w,
+                                                             const float* __restrict__ gn_b, int L0,
+                                                             float* __restrict__ scale_shift) {
+    __shared__ double st[NSTAT];
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c < NSTAT) {
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += partials[((size_t)b * nchunk + k) * NSTAT + c];
+        st[c] = s;
+    }
+    __syncthreads();
+    double w[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w[j] = (double)w0[c * 10 + j];
+    double mean = 0.0, ex2 = 0.0;
+    int q = 10;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        mean += w[j] * st[j];
+#pragma unroll
+        for (int k = j; k < 10; ++k) {
+            const double t = w[j] * w[k] * st[q++];
+            ex2 += (k == j) ? t : 2.0 * t;
+        }
+    }
+    mean /= (double)L0;
+    ex2 /= (double)L0;
+    double var = ex2 - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double a = (double)gn_w[c] / sqrt(var + 1e-5);
+    scale_shift[((size_t)b * SYL_CONV + c) * 2 + 0] = (float)a;
+    scale_shift[((size_t)b * SYL_CONV + c) * 2 + 1] = (float)((double)gn_b[c] - mean * a);
+}
+
+// grid (ceil(R0/64), B); wave w of a block produces rows l = 64*blockIdx.x + 16*w + i; lane owns 8 channels
+template <bool OUT_F32, bool ERF>
+__global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int Lmax, int L0, int R0,
+                                                            const float* __restrict__ w0,
+                                                            const float* __restrict__ scale_shift, void* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c0 = lane * 8;
+    float w[8][10], sa[8], sb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
+        sa[i] = scale_shift[((size_t)b * SYL_CONV + c0 + i) * 2 + 0];
+        sb[i] = scale_shift[((size_t)b * SYL_CONV + c0 + i) * 2 + 1];
+    }
+    const float* x = wav + (size_t)b * Lmax;
+    const int lbase = blockIdx.x * 64 + wave * 16;
+#pragma unroll 2
+    for (int r = 0; r < 16; ++r) {
+        const int l = lbase + r;
+        if (l >= R0) break;
+        float y[8];
+        if (l < L0) {
+            float xv[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) xv[j] = x[5 * l + j];   // wave-uniform address: scalar/broadcast load
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v = fmaf(w[i][j], xv[j], v);
+                v = fmaf(v, sa[i], sb[i]);
+                y[i] = ERF ? gelu_erf(v) : gelu_fast(v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = 0.f;
+        }
+        const size_t o = ((size_t)b * R0 + l) * SYL_CONV + c0;
+        if constexpr (OUT_F32) {
+            float* op = (float*)out + o;
+            *(float4*)op = make_float4(y[0], y[1], y[2], y[3]);
+            *(float4*)(op + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        } else {
+            uint4 pk;
+            pk.x = pack_bf16x2(y[0], y[1]); pk.y = pack_bf16x2(y[2], y[3]);
+            pk.z = pack_bf16x2(y[4], y[5]); pk.w = pack_bf16x2(y[6], y[7]);
+            *(uint4*)((bf16_t*)out + o) = pk;
+        }
+    }
+}
+
+int launch_conv0_stats(const float* wav, int B, int Lmax, int L0, double* partials, int nchunk, hipStream_t s) {
+    const int chunk = (L0 + nchunk - 1) / nchunk;
+    hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, wav, Lmax, L0, chunk, partials, nchunk);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_conv0_finalize(const double* partials, int nchunk, const float* w0, const float* gn_w, const float* gn_b, int B,
+                          int L0, float* scale_shift, hipStream_t s) {
+    hipLaunchKernelGGL(conv0_finalize_kernel, dim3(B), dim3(512), 0, s, partials, nchunk, w0, gn_w, gn_b, L0, scale_shift);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, const float* w0, const float* scale_shift,
+                         void* out, int out_f32, hipStream_t s) {
+    dim3 grid((R0 + 63) / 64, B);
+    if (out_f32)
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<true, true>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
+    else
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, D/64 values per lane in registers.
+template <int D, bool IN_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
+    constexpr int V = D / 256;   // float4 groups per lane (2 for 512, 3 for 768)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= a.M) return;
+    int orow = m;
+    if (a.Tp > 0) {
+        const int b = m / a.Tp, t = m - b * a.Tp;
+        if (t >= a.T) return;
+        orow = b * a.T + t;
+    }
+    float x[V][4];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = i * 256 + lane * 4;
+        if constexpr (IN_BF16) {
+            const uint2 raw = *(const uint2*)((const bf16_t*)a.in + (size_t)m * a.ld_in + c);
+            x[i][0] = bf2f((bf16_t)(raw.x & 0xffff)); x[i][1] = bf2f((bf16_t)(raw.x >> 16));
+            x[i][2] = bf2f((bf16_t)(raw.y & 0xffff)); x[i][3] = bf2f((bf16_t)(raw.y >> 16));
+        } else {
+            const float4 v = *(const float4*)((const float*)a.in + (size_t)m * a.ld_in + c);
+            x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
+        }
+        if (a.res) {
+            const float4 r = *(const float4*)(a.res + (size_t)m * a.ld_res + c);
+            x[i][0] += r.x; x[i][1] += r.y; x[i][2] += r.z; x[i][3] += r.w;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = x[i][j] - mean; q = fmaf(d, d, q); }
+    const float var = wave_sum(q) * (1.0f / D);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = i * 256 + lane * 4;
+        const float4 g = *(const float4*)(a.gamma + c);
+        const float4 be = *(const float4*)(a.beta + c);
+        const float y0 = fmaf((x[i][0] - mean) * rstd, g.x, be.x);
+        const float y1 = fmaf((x[i][1] - mean) * rstd, g.y, be.y);
+        const float y2 = fmaf((x[i][2] - mean) * rstd, g.z, be.z);
+        const float y3 = fmaf((x[i][3] - mean) * rstd, g.w, be.w);
+        if (a.out_f32) *(float4*)(a.out_f32 + (size_t)orow * a.ld_f32 + c) = make_float4(y0, y1, y2, y3);
+        if (a.out_bf16) {
+            uint2 pk; pk.x = pack_bf16x2(y0, y1); pk.y = pack_bf16x2(y2, y3);
+            *(uint2*)(a.out_bf16 + (size_t)m * a.ld_bf16 + c) = pk;
+        }
+    }
+}
+
+int launch_layernorm(const LnArgs& a, hipStream_t s) {
+    dim3 grid((a.M + 3) / 4);
+    if (a.D == 768 && !a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<768, false>), grid, dim3(256), 0, s, a);
+    else if (a.D == 768 && a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<768, true>), grid, dim3(256), 0, s, a);
+    else if (a.D == 512 && !a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<512, false>), grid, dim3(256), 0, s, a);
+    else if (a.D == 512 && a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<512, true>), grid, dim3(256), 0, s, a);
+    else { syl_set_error("launch_layernorm", "D must be 512 or 768"); return 1; }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = *(const float4*)(in + i * 4);
+        uint2 pk; pk.x = pack_bf16x2(v.x, v.y); pk.y = pack_bf16x2(v.z, v.w);
+        *(uint2*)(out + i * 4) = pk;
+    }
+}
+int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
+    if (n % 4) { syl_set_error("launch_f32_to_bf16", "n must be a multiple of 4"); return 1; }
+    const size_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, in, out, n4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// compacting copy bf16 [B][Tp][D] (row stride ld_in) -> f32 [B][T][D]
+__global__ __launch_bounds__(256) void bf16_rows_to_f32_kernel(const bf16_t* __restrict__ in, long ld_in, float* __restrict__ out,
+                                                               int Tp, int T, int D) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    const bf16_t* src = in + ((size_t)b * Tp + t) * ld_in;
+    float* dst = out + ((size_t)b * T + t) * D;
+    for (int c = threadIdx.x; c < D; c += 256) dst[c] = bf2f(src[c]);
+}
+int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_rows_to_f32_kernel, dim3(T, B), dim3(256), 0, s, in, ld_in, out, Tp, T, D);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,100 @@
+// Internal launcher API between the HIP translation units of libsylber_hip.so.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA GEMM  out[m][n] = sum_k X[m][k] * W[n][k]  (+ fused epilogue)
+// X rows may overlap (ldx < K): the strided 1-D convolutions are run as this GEMM on a channels-last
+// activation buffer with ldx = stride*512, K = taps*512 (implicit GEMM, no im2col).
+// ------------------------------------------------------------------------------------------------
+enum GemmEpi {
+    EPI_BF16 = 0,       // out0 bf16 [M][ld0] = act(acc + bias)
+    EPI_F32 = 1,        // out0 f32  [M][ld0] = act(acc + bias)
+    EPI_F32_RES = 2,    // out0 f32  [M][ld0] = acc + bias + res[m][n]
+    EPI_QKV = 3,        // q (x0.125), k -> [B,H,Tp,64] bf16 ; v -> Vt [B,H,64,Tpv] bf16
+    EPI_PROJ = 4,       // feature projection: zero padded frames; out0 f32 [M][768]; out1 bf16 xpad
+};
+
+struct GemmArgs {
+    const bf16_t* X; long ldx;
+    const bf16_t* W;              // [N][K] row-major
+    int M, N, K;
+    const float* bias;            // [N] or nullptr
+    int act;                      // 0 none, 1 gelu(fast), 2 gelu(erf)
+    void* out0; long ld0;
+    void* out1; void* out2;
+    const float* res; long ldres;
+    int Tp, Tpv, T;               // rows per utterance in M, Vt row stride, real frames
+    const int* valid;             // [B] valid frames (EPI_PROJ)
+    int xpad_rows;                // rows per utterance of the zero-padded pos-conv input (EPI_PROJ)
+};
+
+int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
+
+// fp32 parity-mode GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), same epilogues on fp32 tensors
+struct GemmArgsF32 {
+    const float* X; long ldx;
+    const float* W;
+    int M, N, K;
+    const float* bias; int act;
+    float* out0; long ld0;
+    const float* res; long ldres;
+};
+int launch_gemm_f32(const GemmArgsF32& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// conv frontend layer 0: Conv1d(1->512,k10,s5) + GroupNorm(per (b,c) over time) + GELU, channels-last out
+// ------------------------------------------------------------------------------------------------
+int launch_conv0_stats(const float* wav, int B, int Lmax, int L0, double* partials, int nchunk, hipStream_t s);
+int launch_conv0_finalize(const double* partials, int nchunk, const float* w0, const float* gn_w, const float* gn_b,
+                          int B, int L0, float* scale_shift, hipStream_t s);
+// out: [B][R0][512] (bf16 or f32); rows l >= L0 are written as zeros
+int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, const float* w0,
+                         const float* scale_shift, void* out, int out_f32, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (512 or 768), eps 1e-5, one wave per row
+//   in: f32 or bf16 rows (ld_in); optional residual add (f32); outputs: f32 and/or bf16
+//   remap: if Tp>0, input row m=(b,t) with t>=T is skipped and outputs are written compact at b*T+t
+// ------------------------------------------------------------------------------------------------
+struct LnArgs {
+    const void* in; int in_bf16; long ld_in;
+    const float* res; long ld_res;
+    const float* gamma; const float* beta;
+    float* out_f32; long ld_f32;
+    bf16_t* out_bf16; long ld_bf16;
+    int M, D;
+    int Tp, T;        // compaction of the f32 output (final hidden states); 0 = none
+};
+int launch_layernorm(const LnArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// flash attention: softmax(q k^T + key mask) v, 12 heads x 64, q pre-scaled by 1/8
+//   q,k: [B,H,Tp,64] bf16; vt: [B,H,64,Tpv] bf16; ctx out: [B*Tp][768] bf16
+// ------------------------------------------------------------------------------------------------
+int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T,
+                     int Tp, int Tpv, hipStream_t s);
+int launch_attention_f32(const float* q, const float* k, const float* v, const int* valid, float* ctx, int B, int T,
+                         int Tp, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// positional conv embedding: grouped Conv1d(768,768,k=128,pad=64,groups=16)+bias, drop last, GELU, + residual
+//   xpad: [B][Tp+128][768] bf16 with 64 zero rows in front and zeros behind the valid frames
+//   wpk : packed weights [16 groups][128 taps][64 n (48 used)][48 c] bf16
+//   out : f32 [B*Tp][768] = x_f32 + gelu(conv + bias)
+// ------------------------------------------------------------------------------------------------
+int launch_posconv(const bf16_t* xpad, const bf16_t* wpk, const float* bias, const float* x_f32, float* out, int B,
+                   int Tp, int act, hipStream_t s);
+int launch_posconv_f32(const float* xpad, const float* w, const float* bias, const float* x_f32, float* out, int B,
+                       int Tp, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// segmentation (get_segment + mean-pool), one workgroup per utterance, numpy-f32 bit-exact
+// ------------------------------------------------------------------------------------------------
+int launch_segment(const float* hidden, int B, int T, int D, float norm_thr, float merge_thr, int64_t* seg, int* nseg,
+                   float* feat, float* scratch, hipStream_t s);
+size_t segment_scratch_floats(int B, int T, int D);
+
+// misc elementwise
+int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s);

@@ -1,0 +1,259 @@
+// Syllable-boundary detection + segment mean-pool on the GPU, bit-exact w.r.t. the reference's numpy
+// float32 arithmetic.  One workgroup (4 waves) per utterance.
+//
+// Reference: get_segment / cossim, sylber/utils/segment_utils.py:68-131, and the mean-pool at
+// sylber/model/sylber.py:133.  Segment indices come out of discontinuous float comparisons, so the
+// kernel reproduces numpy's evaluation ORDER, not just its maths (spec: SURVEY.md §8(a) row S1):
+//   * ndarray.sum over 768 contiguous f32 = 0 + pairwise sum: 8 leaf blocks of 96, each with 8
+//     stride-8 accumulators (12 sequential adds), combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), leaves
+//     combined by a balanced tree.  That is exactly 64 independent 12-term chains + a 6-level xor
+//     butterfly: one wave64 evaluates one 768-term dot product with lane = 8*leaf + accumulator.
+//   * no FMA contraction anywhere (this file is compiled with -ffp-contract=off), IEEE division and
+//     sqrt (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt), f32 subnormals kept.
+//   * 1-D cossim uses numpy-scalar `** .5` = glibc powf (powf_half.h); 2-D cossim uses sqrtf.
+//   * mean(0) accumulates rows sequentially from +0, then divides by f32(n).
+// Phase 1 (greedy scan) is inherently sequential over frames and runs on wave 0 with frames prefetched
+// four ahead; norms, phase 2 (means, window similarities, sweep) and the pooling use all 256 threads.
+#pragma clang fp contract(off)
+#include "kernels.h"
+#include "powf_half.h"
+
+#define SEG_D 768
+#define SEG_MAXT 4096
+
+// lane l owns elements 96*(l>>3) + (l&7) + 8*i, i = 0..11, of a 768-vector
+__device__ __forceinline__ void load_pw(const float* __restrict__ row, int lane, float (&x)[12]) {
+    const float* p = row + (lane >> 3) * 96 + (lane & 7);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = p[8 * i];
+}
+// numpy (x*y).sum(-1) for 768 contiguous f32; result broadcast to every lane
+__device__ __forceinline__ float pw_dot(const float (&x)[12], const float (&y)[12]) {
+    float r = x[0] * y[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) { const float p = x[i] * y[i]; r = r + p; }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) r = r + __shfl_xor(r, o, 64);
+    return 0.0f + r;
+}
+
+// numpy pairwise sum of n contiguous f32 read by ONE thread (sweep sums; n is the window length)
+__device__ float np_pairwise_leaf(const float* a, int n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+}
+__device__ float np_sum_thread(const float* a, int n) {
+    if (n <= 128) return 0.0f + np_pairwise_leaf(a, n);
+    // explicit post-order walk of the recursion  f(n) = f(n2) + f(n - n2),  n2 = n/2 - (n/2)%8
+    int off[16], len[16], st[16];
+    float val[16];
+    int sp = 0, vp = 0;
+    off[0] = 0; len[0] = n; st[0] = 0; sp = 1;
+    while (sp > 0) {
+        const int o = off[sp - 1], l = len[sp - 1], s = st[sp - 1];
+        if (l <= 128) { val[vp++] = np_pairwise_leaf(a + o, l); --sp; }
+        else if (s == 0) {
+            int n2 = l / 2; n2 -= n2 % 8;
+            st[sp - 1] = 1;
+            off[sp] = o + n2; len[sp] = l - n2; st[sp] = 0; ++sp;   // right (evaluated second-to-top)
+            off[sp] = o; len[sp] = n2; st[sp] = 0; ++sp;            // left first
+        } else { const float rgt = val[--vp]; const float lft = val[--vp]; val[vp++] = lft + rgt; --sp; }
+    }
+    return 0.0f + val[0];
+}
+
+// states[s:e].mean(0) for dims tid, tid+256, tid+512 -> dst (LDS or global)
+__device__ __forceinline__ void mean_rows3(const float* __restrict__ states, int s, int e, int tid, float* dst) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const float* p = states + (size_t)s * SEG_D + tid;
+#pragma unroll 4
+    for (int r = s; r < e; ++r) {
+        a0 = a0 + p[0]; a1 = a1 + p[256]; a2 = a2 + p[512];
+        p += SEG_D;
+    }
+    const float n = (float)(e - s);
+    dst[tid] = a0 / n; dst[tid + 256] = a1 / n; dst[tid + 512] = a2 / n;
+}
+
+__global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ hidden, int T, float norm_thr, float merge_thr,
+                                                      int64_t* __restrict__ seg_out, int* __restrict__ nseg_out,
+                                                      float* __restrict__ feat_out, float* __restrict__ scratch,
+                                                      size_t scratch_per_utt) {
+    __shared__ float ca_s[SEG_D], cb_s[SEG_D];
+    __shared__ float simp_s[SEG_MAXT], simn_s[SEG_MAXT], sweep_s[SEG_MAXT];
+    __shared__ int sh_i[8];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* states = hidden + (size_t)b * T * SEG_D;
+    float* sc = scratch + (size_t)b * scratch_per_utt;
+    float* nsq = sc;                          // sqrt path norms (mask; 2-D cossim)
+    float* npw = sc + T;                      // powf path norms (1-D cossim)
+    int* seg = (int*)(sc + 2 * T);            // [T+1][2]
+    int* mid = seg + 2 * (T + 1);             // [T+1][2]
+    int* merged = mid + 2 * (T + 1);          // [T+1]
+
+    // ---- phase 0: frame norms
+    for (int i = wave; i < T; i += 4) {
+        float x[12];
+        load_pw(states + (size_t)i * SEG_D, lane, x);
+        const float ss = pw_dot(x, x) + 1e-8f;
+        if (lane == 0) { nsq[i] = sqrtf(ss); npw[i] = powf_half_glibc(ss); }
+    }
+    for (int i = tid; i <= T; i += 256) merged[i] = 0;
+    __syncthreads();
+
+    // ---- phase 1: greedy scan (segment_utils.py:78-108), wave 0
+    if (wave == 0) {
+        int s = -1, seg_cnt = 0, nseg = 0, nmid = 0;
+        float c[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) c[i] = 0.f;
+        float xa[12], xb[12], xc[12], xd[12];
+        // frames are processed in groups of 4 with the next group already in flight
+        const int T4 = (T + 3) & ~3;
+        auto ld = [&](int i, float (&x)[12]) { load_pw(states + (size_t)(i < T ? i : T - 1) * SEG_D, lane, x); };
+        ld(0, xa); ld(1, xb); ld(2, xc); ld(3, xd);
+        for (int i0 = 0; i0 < T4; i0 += 4) {
+            float na[12], nb[12], nc[12], nd[12];
+            ld(i0 + 4, na); ld(i0 + 5, nb); ld(i0 + 6, nc); ld(i0 + 7, nd);
+            auto step = [&](int i, const float (&x)[12]) {
+                if (i >= T) return;
+                const bool speech = nsq[i] >= norm_thr;
+                if (!speech) {
+                    if (s > -1) { if (lane == 0) { seg[2 * nseg] = s; seg[2 * nseg + 1] = i; } ++nseg; }
+                    s = -1; seg_cnt = 0;
+                } else if (seg_cnt == 0) {
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) c[k] = x[k];
+                    seg_cnt = 1; s = i;
+                } else {
+                    const float dot = pw_dot(c, x);
+                    const float ncur = powf_half_glibc(pw_dot(c, c) + 1e-8f);
+                    const float sim = dot / ncur / npw[i];
+                    if (sim >= merge_thr) {
+                        const float cf = (float)seg_cnt, c1 = (float)(seg_cnt + 1);
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) c[k] = (c[k] * cf + x[k]) / c1;
+                        seg_cnt += 1;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) c[k] = x[k];
+                        seg_cnt += 1;                      // NOT reset (segment_utils.py:103)
+                        if (lane == 0) { seg[2 * nseg] = s; seg[2 * nseg + 1] = i; mid[2 * nmid] = i; mid[2 * nmid + 1] = nseg; }
+                        ++nseg; ++nmid;
+                        s = i;
+                    }
+                }
+            };
+            step(i0, xa); step(i0 + 1, xb); step(i0 + 2, xc); step(i0 + 3, xd);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) { xa[k] = na[k]; xb[k] = nb[k]; xc[k] = nc[k]; xd[k] = nd[k]; }
+        }
+        if (s > -1) { if (lane == 0) { seg[2 * nseg] = s; seg[2 * nseg + 1] = T; } ++nseg; }
+        if (lane == 0) { sh_i[0] = nseg; sh_i[1] = nmid; }
+    }
+    __syncthreads();
+    const int nseg = sh_i[0], nmid = sh_i[1];
+
+    // ---- phase 2: boundary refinement / re-merge (segment_utils.py:110-128), whole workgroup
+    for (int m = 0; m < nmid; ++m) {
+        const int bd = mid[2 * m], si = mid[2 * m + 1];
+        if (si >= nseg - 1) continue;
+        const int a0 = seg[2 * si], a1 = seg[2 * si + 1];
+        const int b0 = seg[2 * si + 2], b1 = seg[2 * si + 3];
+        mean_rows3(states, a0, a1, tid, ca_s);
+        mean_rows3(states, b0, b1, tid, cb_s);
+        __syncthreads();
+        float ca[12], cb[12];
+        load_pw(ca_s, lane, ca);
+        load_pw(cb_s, lane, cb);
+        const float saa = pw_dot(ca, ca) + 1e-8f, sbb = pw_dot(cb, cb) + 1e-8f;
+        const float sim_ab = pw_dot(ca, cb) / powf_half_glibc(saa) / powf_half_glibc(sbb);   // every wave, identical
+        if (sim_ab >= merge_thr) {
+            __syncthreads();
+            if (tid == 0) { seg[2 * si + 2] = a0; merged[si] = 1; }
+            __syncthreads();
+            continue;
+        }
+        const int la = (a1 - a0) / 2, lb = (b1 - b0) / 2;
+        int ws = bd - (la > 1 ? la : 1); ws = ws < a0 ? a0 : ws;
+        int we = bd + (lb > 1 ? lb : 1); we = we > b1 ? b1 : we;
+        const int w = we - ws;
+        const float nca = sqrtf(saa), ncb = sqrtf(sbb);
+        for (int j = wave; j < w; j += 4) {
+            float x[12];
+            load_pw(states + (size_t)(ws + j) * SEG_D, lane, x);
+            const float nx = nsq[ws + j];
+            const float sp = pw_dot(x, ca) / nx / nca;
+            const float sn = pw_dot(x, cb) / nx / ncb;
+            if (lane == 0) { simp_s[j] = sp; simn_s[j] = sn; }
+        }
+        __syncthreads();
+        for (int i = tid; i < w; i += 256) sweep_s[i] = np_sum_thread(simp_s, i) + np_sum_thread(simn_s + i, w - i);
+        __syncthreads();
+        if (tid == 0) {
+            int best = 0;
+            float bv = sweep_s[0];
+            if (!(bv != bv)) {
+                for (int i = 1; i < w; ++i) {
+                    const float v = sweep_s[i];
+                    if (!(v <= bv)) { bv = v; best = i; if (v != v) break; }
+                }
+            }
+            seg[2 * si + 1] = ws + best;
+            seg[2 * si + 2] = ws + best;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- compaction + mean-pool (sylber.py:133)
+    if (tid == 0) {
+        int n = 0;
+        for (int i = 0; i < nseg; ++i) {
+            if (merged[i]) continue;
+            seg_out[((size_t)b * T + n) * 2 + 0] = seg[2 * i];
+            seg_out[((size_t)b * T + n) * 2 + 1] = seg[2 * i + 1];
+            // reuse mid[] as the compacted list for the pooling loop
+            mid[2 * n] = seg[2 * i]; mid[2 * n + 1] = seg[2 * i + 1];
+            ++n;
+        }
+        nseg_out[b] = n;
+        sh_i[2] = n;
+    }
+    __syncthreads();
+    if (feat_out) {
+        const int n = sh_i[2];
+        for (int k = 0; k < n; ++k)
+            mean_rows3(states, mid[2 * k], mid[2 * k + 1], tid, feat_out + ((size_t)b * T + k) * SEG_D);
+    }
+}
+
+size_t segment_scratch_floats(int B, int T, int D) {
+    (void)D;
+    const size_t per = (size_t)2 * T + 2 * (T + 1) * 2 + (T + 1) + 64;
+    return per * (size_t)B;
+}
+
+int launch_segment(const float* hidden, int B, int T, int D, float norm_thr, float merge_thr, int64_t* seg, int* nseg,
+                   float* feat, float* scratch, hipStream_t s) {
+    if (D != SEG_D) { syl_set_error("launch_segment", "feature dim must be 768"); return 1; }
+    if (T < 1 || T > SEG_MAXT) { syl_set_error("launch_segment", "T must be in [1, 4096]"); return 1; }
+    const size_t per = segment_scratch_floats(1, T, D);
+    hipLaunchKernelGGL(segment_kernel, dim3(B), dim3(256), 0, s, hidden, T, norm_thr, merge_thr, seg, nseg, feat, scratch, per);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

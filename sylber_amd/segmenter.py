@@ -1,0 +1,247 @@
+"""Drop-in ``Segmenter`` for the MI355X: same constructor and ``__call__`` contract as the reference
+(sylber/model/sylber.py:28-138), with the arithmetic on hand-written HIP kernels behind the C-ABI of
+include/sylber_hip.h.  Host code stays Python on PyTorch-ROCm (device memory, streams)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import wave as _wave
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import (NUM_LAYERS, expected_shapes, fold_pos_conv_weight, normalize_keys, synthetic_state_dict)
+
+FRAME_RATE = 50  # sylber.py:132
+
+
+def _ptr(t: torch.Tensor):
+    return ctypes.cast(t.data_ptr(), _lib.c_float_p)
+
+
+def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def load_wav_file(path: str) -> torch.Tensor:
+    """16 kHz PCM ``.wav`` -> float32 [C, N] in [-1, 1] (what torchaudio.load returns at
+    sylber.py:83).  Resampling (sylber.py:84-85) is not on the hot path of this build."""
+    with _wave.open(str(path), "rb") as w:
+        sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if sr != 16000:
+        raise NotImplementedError("only 16 kHz input is supported by this build (got %d Hz); resample first" % sr)
+    if width == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 4:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif width == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError("unsupported sample width %d" % width)
+    return torch.from_numpy(x.reshape(-1, nch).T.copy())
+
+
+class HubertEncoderHIP:
+    """The (1) boundary of include/sylber_hip.h: weights -> handle, waveform batch -> hidden states."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_layers: int = NUM_LAYERS, device: str = "cuda",
+                 precision: str = "bf16"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.SylberHipError("no MI355X visible to PyTorch-ROCm; the HIP path has no CPU fallback")
+        self.device = torch.device(device if device != "cuda" else "cuda:%d" % torch.cuda.current_device())
+        self.num_layers = num_layers
+        sd = normalize_keys(state_dict)
+        shapes = expected_shapes(num_layers)
+        keep = {}
+
+        def get(name):
+            if name not in sd:
+                raise KeyError("checkpoint is missing %s" % name)
+            t = sd[name].detach().to("cpu", torch.float32).contiguous()
+            if name in shapes and tuple(t.shape) != shapes[name]:
+                raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), shapes[name]))
+            keep[name] = t
+            return _ptr(t)
+
+        w = _lib.SylberWeights()
+        w.num_layers = num_layers
+        for i in range(7):
+            w.conv_w[i] = get(f"feature_extractor.conv_layers.{i}.conv.weight")
+        w.gn_w = get("feature_extractor.conv_layers.0.layer_norm.weight")
+        w.gn_b = get("feature_extractor.conv_layers.0.layer_norm.bias")
+        w.fp_ln_w = get("feature_projection.layer_norm.weight")
+        w.fp_ln_b = get("feature_projection.layer_norm.bias")
+        w.fp_w = get("feature_projection.projection.weight")
+        w.fp_b = get("feature_projection.projection.bias")
+        pos = fold_pos_conv_weight(sd)
+        keep["pos"] = pos
+        w.pos_w = _ptr(pos)
+        w.pos_b = get("encoder.pos_conv_embed.conv.bias")
+        w.enc_ln_w = get("encoder.layer_norm.weight")
+        w.enc_ln_b = get("encoder.layer_norm.bias")
+        for l in range(num_layers):
+            p = f"encoder.layers.{l}."
+            L = w.layers[l]
+            L.q_w, L.q_b = get(p + "attention.q_proj.weight"), get(p + "attention.q_proj.bias")
+            L.k_w, L.k_b = get(p + "attention.k_proj.weight"), get(p + "attention.k_proj.bias")
+            L.v_w, L.v_b = get(p + "attention.v_proj.weight"), get(p + "attention.v_proj.bias")
+            L.o_w, L.o_b = get(p + "attention.out_proj.weight"), get(p + "attention.out_proj.bias")
+            L.ln1_w, L.ln1_b = get(p + "layer_norm.weight"), get(p + "layer_norm.bias")
+            L.ff1_w, L.ff1_b = (get(p + "feed_forward.intermediate_dense.weight"),
+                                get(p + "feed_forward.intermediate_dense.bias"))
+            L.ff2_w, L.ff2_b = get(p + "feed_forward.output_dense.weight"), get(p + "feed_forward.output_dense.bias")
+            L.ln2_w, L.ln2_b = get(p + "final_layer_norm.weight"), get(p + "final_layer_norm.bias")
+        h = ctypes.c_void_p()
+        prec = {"bf16": 0, "fp32": 1}[precision]
+        _lib.check(self.lib.sylber_create(ctypes.byref(w), self.device.index or 0, prec, ctypes.byref(h)),
+                   "sylber_create")
+        self.handle = h
+        del keep
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.lib.sylber_destroy(h)
+            self.handle = None
+
+    def num_frames(self, n_samples: int) -> int:
+        return int(self.lib.sylber_num_frames(int(n_samples)))
+
+    def forward(self, wav: torch.Tensor, lengths: Optional[Sequence[int]] = None, stop_stage: int = 0) -> torch.Tensor:
+        """wav: [B, Lmax] float32 on this device, zero padded.  Returns [B, T, 768] float32 (device)."""
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
+        B, Lmax = wav.shape
+        T = self.num_frames(Lmax)
+        width = 512 if stop_stage == 1 else 768
+        out = torch.empty(B, T, width, dtype=torch.float32, device=wav.device)
+        larr = None
+        if lengths is not None:
+            larr = (ctypes.c_int32 * B)(*[int(x) for x in lengths])
+        self.lib.sylber_set_stop_stage(self.handle, int(stop_stage))
+        with torch.cuda.device(wav.device):
+            st = self.lib.sylber_forward(self.handle, ctypes.c_void_p(wav.data_ptr()), larr, B, Lmax,
+                                         ctypes.c_void_p(out.data_ptr()), _stream_ptr(wav.device))
+        self.lib.sylber_set_stop_stage(self.handle, 0)
+        _lib.check(st, "sylber_forward")
+        return out
+
+    def segment(self, hidden: torch.Tensor, norm_threshold: float, merge_threshold: float, with_features: bool = True):
+        """hidden: [B, T, 768] float32 device.  Returns (segments [B,T,2] int64, nseg [B] int32, feats [B,T,768])."""
+        assert hidden.is_cuda and hidden.dtype == torch.float32 and hidden.is_contiguous()
+        B, T, D = hidden.shape
+        seg = torch.empty(B, T, 2, dtype=torch.int64, device=hidden.device)
+        nseg = torch.empty(B, dtype=torch.int32, device=hidden.device)
+        feats = torch.empty(B, T, D, dtype=torch.float32, device=hidden.device) if with_features else None
+        with torch.cuda.device(hidden.device):
+            st = self.lib.sylber_segment(self.handle, ctypes.c_void_p(hidden.data_ptr()), B, T, D,
+                                         ctypes.c_float(float(np.float32(norm_threshold))),
+                                         ctypes.c_float(float(np.float32(merge_threshold))),
+                                         ctypes.c_void_p(seg.data_ptr()), ctypes.c_void_p(nseg.data_ptr()),
+                                         ctypes.c_void_p(feats.data_ptr()) if feats is not None else None,
+                                         _stream_ptr(hidden.device))
+        _lib.check(st, "sylber_segment")
+        return seg, nseg, feats
+
+    def set_profiling(self, on: bool) -> None:
+        self.lib.sylber_set_profiling(self.handle, 1 if on else 0)
+
+    def get_profile(self) -> Dict[str, float]:
+        cap = 64
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = self.lib.sylber_get_profile(self.handle, names, ms, cap)
+        return {names[i].decode(): float(ms[i]) for i in range(max(n, 0))}
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.sylber_workspace_bytes(self.handle))
+
+
+class Segmenter:
+    """Same signature as the reference's ``Segmenter`` (sylber/model/sylber.py:30-39, 63)."""
+
+    def __init__(self, model_ckpt="sylber", speech_upstream="facebook/hubert-base-ls960", ema_decay=0.999,
+                 encoding_layer=9, merge_threshold=0.8, norm_threshold=2.6, device="cuda", **kwargs):
+        self.encoding_layer = encoding_layer
+        self.enc_dim = 768
+        state_dict = self._load_state_dict(model_ckpt, encoding_layer)
+        if "cuda" not in str(device):
+            raise _lib.SylberHipError("sylber_amd.Segmenter runs on the MI355X only (device=%r)" % (device,))
+        self.speech_model = HubertEncoderHIP(state_dict, num_layers=encoding_layer, device=device,
+                                             precision=kwargs.get("precision", "bf16"))
+        self.device = str(self.speech_model.device)
+        self.norm_threshold = norm_threshold
+        self.merge_threshold = merge_threshold
+
+    @staticmethod
+    def _load_state_dict(model_ckpt, encoding_layer):
+        if model_ckpt is None:
+            # the reference keeps HubertModel's random init here (sylber.py:41,46); use the seeded one
+            return synthetic_state_dict(0, num_layers=encoding_layer)
+        if isinstance(model_ckpt, dict):
+            return model_ckpt
+        if model_ckpt == "sylber":
+            model_ckpt = "sylber.ckpt"
+        if not Path(model_ckpt).exists():
+            from huggingface_hub import hf_hub_download  # sylber.py:49-50
+            model_ckpt = hf_hub_download(repo_id="cheoljun95/sylber", filename=model_ckpt)
+        sd = torch.load(model_ckpt, map_location="cpu")
+        print("Pre-trained checkpoint loaded")
+        return sd
+
+    # -- batching exactly like sylber.py:76-118 ---------------------------------------------------
+    def _collect(self, wav_file, wav):
+        batch_wavs: List[torch.Tensor] = []
+        if wav_file is not None:
+            is_batch = isinstance(wav_file, list)
+            for f in (wav_file if is_batch else [wav_file]):
+                x = load_wav_file(f)
+                x = (x - x.mean()) / x.std()          # sylber.py:86 (unbiased std over all elements)
+                batch_wavs.append(x)
+        else:
+            assert wav is not None
+            is_batch = isinstance(wav, list)
+            batch_wavs = wav if is_batch else [wav]
+        return batch_wavs, is_batch
+
+    def encode_batch(self, batch_wavs: Sequence[torch.Tensor]):
+        """Pads to the batch max (sylber.py:93-118) and runs the HIP forward.  Returns the device
+        hidden states [B,T,768] (full padded T, like the reference) and the per-row lengths."""
+        rows, lengths = [], []
+        for w in batch_wavs:
+            if w.dim() != 2:
+                raise ValueError("each wav must be a [channels, N] tensor (sylber.py:96 reads wav.shape[1])")
+            for ch in range(w.shape[0]):              # torch.cat(dim=0) makes every channel a batch row
+                rows.append(w[ch])
+                lengths.append(int(w.shape[1]))
+        lmax = max(lengths)
+        dev = self.speech_model.device
+        batch = torch.zeros(len(rows), lmax, dtype=torch.float32, device=dev)
+        for i, r in enumerate(rows):
+            batch[i, : lengths[i]] = r.to(dev, torch.float32, non_blocking=True)
+        hidden = self.speech_model.forward(batch, lengths)
+        return hidden, lengths
+
+    def __call__(self, wav_file=None, wav=None, in_second=True):
+        batch_wavs, is_batch = self._collect(wav_file, wav)
+        hidden, _ = self.encode_batch(batch_wavs)
+        seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold)
+        nseg_h = nseg.cpu().numpy()
+        nmax = int(nseg_h.max()) if len(nseg_h) else 0
+        hidden_h = hidden.cpu().numpy()
+        seg_h = seg[:, :max(nmax, 1)].cpu().numpy()
+        feats_h = feats[:, :max(nmax, 1)].cpu().numpy()
+        outputs = []
+        for i in range(hidden_h.shape[0]):
+            n = int(nseg_h[i])
+            segments = seg_h[i, :n].copy() if n > 0 else np.array([])
+            outputs.append({
+                "segments": segments * 1.0 / FRAME_RATE if in_second else segments,
+                "segment_features": feats_h[i, :n].copy() if n > 0 else np.array([]),
+                "hidden_states": hidden_h[i],
+            })
+        return outputs if is_batch else outputs[0]

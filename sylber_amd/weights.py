@@ -124,3 +124,15 @@ def normalize_keys(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
             k = POS_V_KEYS[0]
         out[k] = v
     return out
+
+
+def fold_pos_conv_weight(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """Effective positional-conv weight ``g * v / ||v||`` (weight_norm with dim=2: the norm runs over
+    dims (0, 1) for every tap; TP:63-80).  Folded once at load time; also accepts a plain
+    ``conv.weight`` entry."""
+    sd = normalize_keys(sd)
+    if POS_G_KEYS[0] in sd:
+        g = sd[POS_G_KEYS[0]].float()
+        v = sd[POS_V_KEYS[0]].float()
+        return (g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).contiguous()
+    return sd["encoder.pos_conv_embed.conv.weight"].float().contiguous()

@@ -1,0 +1,55 @@
+"""CPU tier: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/sylber_hip.h declares (no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sylber_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "sylber_hip.h")).read()
+    declared = set(re.findall(r"\b(sylber_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("sylber_ctx")
+    assert {"sylber_create", "sylber_forward", "sylber_segment", "sylber_destroy", "sylber_last_error"} <= declared
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    from sylber_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+
+
+def test_num_frames_matches_conv_formula(lib):
+    assert lib.sylber_num_frames(160000) == 499
+    assert lib.sylber_num_frames(46080) == 143
+    assert lib.sylber_num_frames(960000) == 2999
+    assert lib.sylber_num_frames(400) == 1
+
+
+def test_product_path_refuses_cpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sylber_amd import Segmenter, _lib
+    with pytest.raises(_lib.SylberHipError):
+        Segmenter(model_ckpt=None)
+    with pytest.raises(_lib.SylberHipError):
+        Segmenter(model_ckpt=None, device="cpu")
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under sylber_amd/ may import it."""
+    pkg = os.path.join(ROOT, "sylber_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "segment_ref" not in src and "hubert_ref" not in src, f

@@ -1,0 +1,83 @@
+"""GPU tier: single-kernel parity through the C-ABI op entry points against plain torch fp32 on
+the same (bf16-rounded) inputs."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sylber_amd import _lib
+    assert torch.cuda.is_available(), "gpu tier needs the MI355X"
+    return _lib.load()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(128, 128, 64, 0), (500, 768, 768, 0), (1000, 3072, 768, 1),
+                                      (333, 768, 3072, 0), (257, 512, 1536, 1), (64, 2304, 768, 0)])
+def test_linear(lib, M, N, K, act):
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+    c = torch.full((M, N), float("nan"), device="cuda")
+    _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, act, 0, None), "op_linear")
+    ref = _bf(a) @ _bf(w).T + b
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    err = (c.cpu() - ref).abs().max().item()
+    assert err < 2e-3, err     # same bf16 products, fp32 accumulation order differs; A-S gelu 1.5e-7
+
+
+@pytest.mark.parametrize("D", [512, 768])
+def test_layernorm(lib, D):
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(777, D, generator=g) * 3 + 0.5
+    r = torch.randn(777, D, generator=g)
+    gam = torch.randn(D, generator=g)
+    bet = torch.randn(D, generator=g)
+    y = torch.empty(777, D, device="cuda")
+    _lib.check(lib.sylber_op_layernorm(_p(x.cuda()), _p(r.cuda()), _p(gam.cuda()), _p(bet.cuda()), _p(y), 777, D, None),
+               "op_layernorm")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x + r, (D,), gam, bet, 1e-5)
+    assert (y.cpu() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,T,valid", [(2, 64, None), (3, 143, [143, 100, 1]), (2, 499, [499, 300]), (1, 700, None)])
+def test_attention(lib, B, T, valid):
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    q = torch.randn(B, T, 768, generator=g)
+    k = torch.randn(B, T, 768, generator=g)
+    v = torch.randn(B, T, 768, generator=g)
+    # a query/key spike so that the running max really jumps between tiles (online-softmax rescale path)
+    k[0, T // 2, :64] = 4.0 * q[0, 3, :64] / 8
+    vd = torch.tensor(valid, dtype=torch.int32).cuda() if valid else None
+    o = torch.full((B, T, 768), float("nan"), device="cuda")
+    _lib.check(lib.sylber_op_attention(_p(q.cuda()), _p(k.cuda()), _p(v.cuda()), _p(vd), _p(o), B, T, 0, None), "op_attention")
+    qh = _bf(q * 0.125).view(B, T, 12, 64).transpose(1, 2)
+    kh = _bf(k).view(B, T, 12, 64).transpose(1, 2)
+    vh = _bf(v).view(B, T, 12, 64).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    if valid:
+        mask = torch.arange(T)[None, :] >= torch.tensor(valid)[:, None]
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, T, 768)
+    err = (o.cpu() - ref).abs().max().item()
+    assert err < 3e-2, err     # P and the output are rounded to bf16 (rel 3.9e-3) around O(1) values
+    assert (o.cpu() - ref).pow(2).mean().sqrt().item() < 4e-3
