@@ -51,8 +51,8 @@ def test_layernorm(lib, D):
     gam = torch.randn(D, generator=g)
     bet = torch.randn(D, generator=g)
     y = torch.empty(777, D, device="cuda")
-    _lib.check(lib.sylber_op_layernorm(_p(x.cuda()), _p(r.cuda()), _p(gam.cuda()), _p(bet.cuda()), _p(y), 777, D, None),
-               "op_layernorm")
+    xd, rd, gd, bd = x.cuda(), r.cuda(), gam.cuda(), bet.cuda()
+    _lib.check(lib.sylber_op_layernorm(_p(xd), _p(rd), _p(gd), _p(bd), _p(y), 777, D, None), "op_layernorm")
     torch.cuda.synchronize()
     ref = torch.nn.functional.layer_norm(x + r, (D,), gam, bet, 1e-5)
     assert (y.cpu() - ref).abs().max().item() < 2e-5
@@ -69,7 +69,8 @@ def test_attention(lib, B, T, valid):
     k[0, T // 2, :64] = 4.0 * q[0, 3, :64] / 8
     vd = torch.tensor(valid, dtype=torch.int32).cuda() if valid else None
     o = torch.full((B, T, 768), float("nan"), device="cuda")
-    _lib.check(lib.sylber_op_attention(_p(q.cuda()), _p(k.cuda()), _p(v.cuda()), _p(vd), _p(o), B, T, 0, None), "op_attention")
+    qd, kd, vdev = q.cuda(), k.cuda(), v.cuda()
+    _lib.check(lib.sylber_op_attention(_p(qd), _p(kd), _p(vdev), _p(vd), _p(o), B, T, 0, None), "op_attention")
     qh = _bf(q * 0.125).view(B, T, 12, 64).transpose(1, 2)
     kh = _bf(k).view(B, T, 12, 64).transpose(1, 2)
     vh = _bf(v).view(B, T, 12, 64).transpose(1, 2)
