@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Throughput benchmark of the Segmenter hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one batch of synthetic input: waveform batch resident in HBM
+-> 7-layer conv frontend -> 9-layer HuBERT encoder -> boundary detection + segment mean-pool, outputs
+(hidden_states, segments, segment_features) left in HBM.  Workload = BASELINE.json configs[1]:
+32 x 10 s x 16 kHz random waveforms per GPU, synthetic seeded weights of the sylber_base geometry
+(no network for the real checkpoint), bf16 MFMA compute with fp32 accumulation/residual stream.
+Weak scaling: every rank processes its own 32-clip shard (cfg3 = 256 clips on 8 GPUs); for N > 1 the
+step also includes the root scatter of waveforms and the gather of all outputs over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CLIP_SAMPLES = 160000
+CLIP_SECONDS = 10.0
+BATCH_PER_GPU = 32
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def gemm_flops_per_forward(B: int) -> dict:
+    """Algorithmic FLOPs (2*MAC) of the launches of the bf16 MFMA GEMM kernel family
+    in one forward over B 10 s clips, keyed by the launch names api.hip uses."""
+    L = [31999, 15999, 7999, 3999, 1999, 999, 499]
+    K = [10, 3, 3, 3, 3, 2, 2]
+    T = 499
+    f = {}
+    for i in range(1, 7):
+        f[f"gemm_conv{i}"] = 2.0 * L[i] * 512 * 512 * K[i] * B
+    f["gemm_proj"] = 2.0 * T * 512 * 768 * B
+    f["gemm_qkv"] = 9 * 3 * 2.0 * T * 768 * 768 * B
+    f["gemm_out"] = 9 * 2.0 * T * 768 * 768 * B
+    f["gemm_ffn1"] = 9 * 2.0 * T * 768 * 3072 * B
+    f["gemm_ffn2"] = 9 * 2.0 * T * 768 * 3072 * B
+    return f
+
+
+def cpu_baseline(sd, seconds_budget=25.0):
+    """The CPU restatement of the same path (oracle/: torch fp32 ops in the reference's order +
+    C get_segment), timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle.segmenter_ref import SegmenterRef
+    from sylber_amd.synth import noise_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ref = SegmenterRef(sd)
+    B = 4
+    wavs = [w[None, :] for w in noise_batch(B, CLIP_SAMPLES, seed=0)]
+    t0 = time.perf_counter()
+    ref(wavs, in_second=False)               # warm-up (also bounds the loop below)
+    warm = time.perf_counter() - t0
+    iters = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ref(wavs, in_second=False)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(B * CLIP_SECONDS / dt, 2), "unit": "audio-sec/s", "cores": cores, "kind": "port",
+            "sample": "%d iterations of batch %d x 10 s (same generator as the GPU workload), fp32, "
+                      "torch CPU ops + C get_segment" % (iters, B)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the RCCL scatter/gather in the step")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.dist import ShardedSegmenter
+    from sylber_amd.synth import noise_batch
+    from sylber_amd.weights import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    enc = HubertEncoderHIP(sd, device=str(dev))
+    sharded = ShardedSegmenter(enc)
+    B = args.batch
+    exchange = world > 1 and not args.no_exchange
+    # inputs resident in HBM before the timed region: rank r holds clips [r*B, (r+1)*B) of the seeded job;
+    # with the exchange enabled the root additionally holds the whole job and scatters it every step
+    my_batch = noise_batch(B, CLIP_SAMPLES, seed=1000 + rank).to(dev)
+    root_batch = None
+    if exchange and rank == 0:
+        root_batch = torch.cat([noise_batch(B, CLIP_SAMPLES, seed=1000 + r) for r in range(world)], 0).to(dev)
+
+    def step():
+        if exchange:
+            return sharded.step(root_batch, None)
+        hidden = enc.forward(my_batch, None)
+        return (hidden,) + tuple(enc.segment(hidden, 2.6, 0.8))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_audio = world * B * CLIP_SECONDS * args.steps
+    value = total_audio / elapsed
+
+    # ---- per-kernel device time with HIP events on the launch stream (separate pass: event records
+    # perturb the launch stream slightly, so they are kept out of the throughput timing above)
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        enc.set_profiling(True)
+        nprof = max(3, min(args.steps, 10))
+        for _ in range(nprof):
+            h = enc.forward(my_batch, None)
+            enc.segment(h, 2.6, 0.8)
+        torch.cuda.synchronize(dev)
+        prof = enc.get_profile()
+        enc.set_profiling(False)
+        kernels = {k: round(v / nprof, 4) for k, v in prof.items()}      # ms per forward
+        fl = gemm_flops_per_forward(B)
+        gemm_ms = sum(kernels.get(k, 0.0) for k in fl)
+        gemm_fl = sum(fl.values())
+        n_launch = 6 + 1 + 9 * 4
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all %d launches per forward: 6 implicit-GEMM convs, "
+                    "projection, 9 x {qkv, out, ffn1, ffn2})" % n_launch,
+                    "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(gemm_ms / n_launch, 4), "flops_per_forward": gemm_fl,
+                    "per_launch_tflops": {k: round(fl[k] / (kernels[k] * 1e-3) / 1e12, 1) for k in fl if kernels.get(k)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sd)
+
+    if rank == 0:
+        line = {
+            "metric": "audio-sec/s encoded (sylber_base, 16 kHz, batched 10 s clips)",
+            "value": round(value, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Segmenter forward (conv frontend + HuBERT-9L encoder + boundary detection + "
+                                   "segment mean-pool), batch %d x 10 s 16 kHz random waveforms per GPU, random-init "
+                                   "sylber_base weights (BASELINE.json configs[1]%s)" % (B, "; configs[2] sharding" if world > 1 else ""),
+                       "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": 499,
+                       "parallelism": "utterance-sharded x%d%s" % (world, " + RCCL scatter/gather" if exchange else ""),
+                       "gflop_per_clip": 124.65},
+            "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_forward": kernels,
+            "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

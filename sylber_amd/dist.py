@@ -1,0 +1,119 @@
+"""Utterance-sharded Segmenter over one node: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference has no inference-time multi-device code (the only parallelism is
+Lightning DDP for training, train.py:93).  Utterances are independent units on this path
+(GroupNorm is per (b,c), attention per b, get_segment per utterance, sylber.py:126); the only
+batch-global quantity is the padded length Lmax (sylber.py:93-97), so every shard is padded to the
+GLOBAL max length and then reproduces the single-process result row for row.
+
+Exchange: root scatters contiguous row blocks of the padded waveform batch (+ lengths), every rank
+runs forward + segmentation on its block, root gathers hidden states, segment tables and pooled
+features.  No collective sits inside the compute path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+FRAME_RATE = 50
+
+
+class ShardedSegmenter:
+    """``engine`` is a per-rank object with ``device``, ``num_frames(n)``, ``forward(wav, lengths)`` and
+    ``segment(hidden, norm_thr, merge_thr)`` (sylber_amd.HubertEncoderHIP on the GPU)."""
+
+    def __init__(self, engine, norm_threshold: float = 2.6, merge_threshold: float = 0.8, group=None):
+        self.engine = engine
+        self.norm_threshold = norm_threshold
+        self.merge_threshold = merge_threshold
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.device = engine.device
+
+    # ---- device-level step (what bench.py times) -------------------------------------------------
+    def scatter(self, batch_root: Optional[torch.Tensor], lengths_root: Optional[Sequence[int]]):
+        """batch_root: [Btot, Lmax] on root (None elsewhere).  Returns this rank's block [Bper, Lmax],
+        its lengths, and (Btot, Bper)."""
+        W = self.world
+        meta = torch.zeros(2, dtype=torch.int64, device=self.device)
+        if self.rank == 0:
+            meta[0], meta[1] = batch_root.shape[0], batch_root.shape[1]
+        if W > 1:
+            dist.broadcast(meta, src=0, group=self.group)
+        btot, lmax = int(meta[0]), int(meta[1])
+        bper = (btot + W - 1) // W
+        lens = torch.full((bper * W,), lmax, dtype=torch.int32, device=self.device)
+        if self.rank == 0 and lengths_root is not None:
+            lens[:btot] = torch.as_tensor(list(lengths_root), dtype=torch.int32)
+        if W == 1:
+            my_wav, my_lens = batch_root, lens
+        else:
+            my_lens = torch.empty(bper, dtype=torch.int32, device=self.device)
+            my_wav = torch.empty(bper, lmax, dtype=torch.float32, device=self.device)
+            if self.rank == 0:
+                pad = bper * W - btot
+                full = batch_root if pad == 0 else torch.cat(
+                    [batch_root, torch.zeros(pad, lmax, dtype=torch.float32, device=self.device)], 0)
+                wav_chunks = list(full.contiguous().view(W, bper, lmax).unbind(0))
+                len_chunks = list(lens.view(W, bper).unbind(0))
+            else:
+                wav_chunks = len_chunks = None
+            dist.scatter(my_lens, len_chunks, src=0, group=self.group)
+            dist.scatter(my_wav, wav_chunks, src=0, group=self.group)
+        return my_wav, my_lens, btot, bper
+
+    def compute(self, my_wav: torch.Tensor, my_lens):
+        lens = [int(x) for x in (my_lens.tolist() if torch.is_tensor(my_lens) else my_lens)]
+        hidden = self.engine.forward(my_wav, lens)
+        seg, nseg, feats = self.engine.segment(hidden, self.norm_threshold, self.merge_threshold)
+        return hidden, seg, nseg, feats
+
+    def gather(self, hidden, seg, nseg, feats, btot: int):
+        """Root receives [Btot, ...] tensors; other ranks receive None."""
+        W = self.world
+        if W == 1:
+            return hidden[:btot], seg[:btot], nseg[:btot], feats[:btot]
+
+        def g(t):
+            outs = [torch.empty_like(t) for _ in range(W)] if self.rank == 0 else None
+            dist.gather(t.contiguous(), outs, dst=0, group=self.group)
+            return torch.cat(outs, 0)[:btot] if self.rank == 0 else None
+
+        # features are mostly empty rows: trim to the global max segment count first (tiny all-reduce)
+        nmax = nseg.max().to(torch.int64).clone()
+        dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.group)
+        k = max(int(nmax), 1)
+        return g(hidden), g(seg[:, :k]), g(nseg), g(feats[:, :k])
+
+    def step(self, batch_root, lengths_root=None):
+        my_wav, my_lens, btot, _ = self.scatter(batch_root, lengths_root)
+        hidden, seg, nseg, feats = self.compute(my_wav, my_lens)
+        return self.gather(hidden, seg, nseg, feats, btot)
+
+    # ---- reference-shaped API on root ------------------------------------------------------------
+    def __call__(self, wav: Optional[List[torch.Tensor]] = None, in_second: bool = True):
+        """``wav``: list of [1, N] tensors on root (ignored elsewhere).  Root returns the same list of
+        dicts the single-process Segmenter returns (sylber.py:128-138); other ranks return None."""
+        batch = lengths = None
+        if self.rank == 0:
+            lengths = [int(w.shape[1]) for w in wav]
+            batch = torch.zeros(len(wav), max(lengths), dtype=torch.float32, device=self.device)
+            for i, w in enumerate(wav):
+                batch[i, : lengths[i]] = w[0].to(self.device)
+        out = self.step(batch, lengths)
+        if self.rank != 0:
+            return None
+        hidden, seg, nseg, feats = (t.cpu().numpy() for t in out)
+        res = []
+        for i in range(hidden.shape[0]):
+            n = int(nseg[i])
+            segments = seg[i, :n].copy() if n > 0 else np.array([])
+            res.append({"segments": segments * 1.0 / FRAME_RATE if in_second else segments,
+                        "segment_features": feats[i, :n].copy() if n > 0 else np.array([]),
+                        "hidden_states": hidden[i]})
+        return res

@@ -1,0 +1,99 @@
+"""CPU tier, world_size 2 over gloo: the utterance-sharding logic of sylber_amd/dist.py (scatter
+to the global max length, per-rank compute, gather) reproduces the single-process result row for
+row.  The per-rank engine here is the CPU oracle (tests may use it); on the GPU the engine is
+HubertEncoderHIP and the backend is nccl (RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import hubert_ref, segment_oracle
+from oracle.segmenter_ref import SegmenterRef
+from sylber_amd.synth import syllable_wave
+from sylber_amd.weights import synthetic_state_dict
+
+
+class OracleEngine:
+    device = torch.device("cpu")
+
+    def __init__(self, sd):
+        self.sd = sd
+
+    def num_frames(self, n):
+        return hubert_ref.num_frames(n)
+
+    def forward(self, wav, lengths):
+        with torch.no_grad():
+            return hubert_ref.forward(self.sd, wav, lengths, num_layers=2)["hidden"].contiguous()
+
+    def segment(self, hidden, nt, mt):
+        B, T, D = hidden.shape
+        seg = torch.zeros(B, T, 2, dtype=torch.int64)
+        nseg = torch.zeros(B, dtype=torch.int32)
+        feats = torch.zeros(B, T, D)
+        for b in range(B):
+            s = segment_oracle.get_segment(hidden[b].numpy(), nt, mt).reshape(-1, 2)
+            nseg[b] = len(s)
+            if len(s):
+                seg[b, : len(s)] = torch.from_numpy(s)
+                feats[b, : len(s)] = torch.from_numpy(segment_oracle.mean_pool(hidden[b].numpy(), s))
+        return seg, nseg, feats
+
+
+LENS = [12000, 9000, 16000, 7000, 11000]   # odd count: exercises the padded tail block
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from sylber_amd.dist import ShardedSegmenter
+    sd = synthetic_state_dict(0, num_layers=2)
+    S = ShardedSegmenter(OracleEngine(sd), norm_threshold=2.6, merge_threshold=0.8)
+    wavs = [syllable_wave(n, 60 + i) for i, n in enumerate(LENS)] if rank == 0 else None
+    out = S(wavs, in_second=False)
+    if rank == 0:
+        q.put([(o["segments"], o["segment_features"], o["hidden_states"]) for o in out])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sd = synthetic_state_dict(0, num_layers=2)
+    ref = SegmenterRef(sd, encoding_layer=2)([syllable_wave(n, 60 + i) for i, n in enumerate(LENS)], in_second=False)
+    assert len(got) == len(ref) == len(LENS)
+    for (seg, feats, hid), r in zip(got, ref):
+        assert hid.shape == r["hidden_states"].shape
+        assert np.abs(hid - r["hidden_states"]).max() < 2e-5      # same fp32 CPU ops; batch split changes BLAS blocking
+        assert seg.shape == r["segments"].shape and np.array_equal(seg, r["segments"])
+        if len(seg):
+            assert np.abs(feats - r["segment_features"]).max() < 2e-5
+
+
+def test_single_process_degenerate_path():
+    from sylber_amd.dist import ShardedSegmenter
+    sd = synthetic_state_dict(0, num_layers=2)
+    S = ShardedSegmenter(OracleEngine(sd))
+    wavs = [syllable_wave(n, 60 + i) for i, n in enumerate(LENS[:2])]
+    out = S(wavs, in_second=True)
+    ref = SegmenterRef(sd, encoding_layer=2)(wavs, in_second=True)
+    for o, r in zip(out, ref):
+        assert np.array_equal(o["segments"], r["segments"])
+        assert np.abs(o["hidden_states"] - r["hidden_states"]).max() < 2e-5
