@@ -41,7 +41,8 @@ def gemm_flops_per_forward(B: int) -> dict:
     for i in range(1, 7):
         f[f"gemm_conv{i}"] = 2.0 * L[i] * 512 * 512 * K[i] * B
     f["gemm_proj"] = 2.0 * T * 512 * 768 * B
-    f["gemm_qkv"] = 9 * 3 * 2.0 * T * 768 * 768 * B
+    f["gemm_qk"] = 9 * 2 * 2.0 * T * 768 * 768 * B
+    f["gemm_v"] = 9 * 2.0 * T * 768 * 768 * B
     f["gemm_out"] = 9 * 2.0 * T * 768 * 768 * B
     f["gemm_ffn1"] = 9 * 2.0 * T * 768 * 3072 * B
     f["gemm_ffn2"] = 9 * 2.0 * T * 768 * 3072 * B
@@ -167,10 +168,10 @@ def main():
         fl = gemm_flops_per_forward(B)
         gemm_ms = sum(kernels.get(k, 0.0) for k in fl)
         gemm_fl = sum(fl.values())
-        n_launch = 6 + 1 + 9 * 4
+        n_launch = 6 + 1 + 9 * 5
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all %d launches per forward: 6 implicit-GEMM convs, "
-                    "projection, 9 x {qkv, out, ffn1, ffn2})" % n_launch,
+                    "projection, 9 x {qk, v, out, ffn1, ffn2})" % n_launch,
                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                     "avg_launch_ms": round(gemm_ms / n_launch, 4), "flops_per_forward": gemm_fl,

@@ -112,6 +112,11 @@ int sylber_op_layernorm(const float* x_dev, const float* res_dev, const float* g
 int sylber_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const int32_t* valid_dev,
                         float* o_dev, int32_t B, int32_t T, int32_t precision, void* stream);
 
+/* development aid: average ms of one launch of the bf16 GEMM kernel (M x N x K, activation row stride
+ * ldx) on pseudo-random operands; epi/act as in csrc/kernels.h, cfg -1 = automatic tile shape */
+int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
+                            int32_t iters, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

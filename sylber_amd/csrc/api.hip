@@ -338,9 +338,11 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         const LayerDev& d = c->L[l];
         const bool last = (l == c->num_layers - 1) || (c->stop_stage == 3 + l);
         GemmArgs g = {};
-        g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 2304; g.K = 768; g.bias = d.bqkv;
+        g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 1536; g.K = 768; g.bias = d.bqkv;
         g.out0 = q; g.out1 = k; g.out2 = vt; g.Tp = p.Tp; g.Tpv = p.Tpv; g.T = p.T;
-        RUN("gemm_qkv", launch_gemm_bf16(EPI_QKV, g, s));
+        RUN("gemm_qk", launch_gemm_bf16(EPI_QK, g, s));
+        g.W = d.wqkv + (size_t)1536 * 768; g.bias = d.bqkv + 1536; g.N = 768;
+        RUN("gemm_v", launch_gemm_bf16(EPI_V, g, s));
         RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, s));
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
@@ -440,4 +442,45 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
     if (launch_bf16_to_f32_rows((bf16_t*)cb.p, 768, o_dev, B, Tp, T, 768, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// GEMM micro-benchmark (development aid): times `iters` launches of the bf16 GEMM on pseudo-random
+// operands with HIP events.  cfg: -1 auto, 0 = 256x128, 1 = 128x192, 2 = 128x128 tiles.
+__global__ void fill_random_bf16(bf16_t* p, size_t n, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+        p[i] = f2bf(((float)(x & 0xffff) / 32768.0f - 1.0f) * 0.5f);
+    }
+}
+extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
+                                       int32_t iters, float* ms_out) {
+    TmpBuf xb, wb, ob, rb, bb;
+    const size_t xn = (size_t)(M + 8) * ldx + K, wn = (size_t)N * K;
+    if (xb.alloc(xn * 2) || wb.alloc(wn * 2) || ob.alloc((size_t)M * N * 4) || rb.alloc((size_t)M * N * 4) || bb.alloc((size_t)N * 4)) {
+        syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1;
+    }
+    hipLaunchKernelGGL(fill_random_bf16, dim3(2048), dim3(256), 0, 0, (bf16_t*)xb.p, xn, 1u);
+    hipLaunchKernelGGL(fill_random_bf16, dim3(2048), dim3(256), 0, 0, (bf16_t*)wb.p, wn, 2u);
+    HIP_TRY(hipMemset(rb.p, 0, (size_t)M * N * 4)); HIP_TRY(hipMemset(bb.p, 0, (size_t)N * 4));
+    GemmArgs g = {};
+    g.X = (bf16_t*)xb.p; g.ldx = ldx; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = (float*)bb.p; g.act = act;
+    g.out0 = ob.p; g.ld0 = N; g.res = (float*)rb.p; g.ldres = N;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    gemm_force_cfg(cfg);
+    int rc = 0;
+    for (int i = 0; i < 3 && !rc; ++i) rc = launch_gemm_bf16(epi, g, 0);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_gemm_bf16(epi, g, 0);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    gemm_force_cfg(-1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
 }

@@ -5,22 +5,20 @@
 // (TP:112-124, as implicit GEMM on channels-last activations: ldx = stride*512, K = taps*512), the
 // feature projection (TP:225-231), q/k/v/out projections (TP:318-342) and the FFN (TP:361-368).
 //
-// Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
-// 2x2 v_mfma_f32_32x32x16_bf16 fragments, 64 fp32 accumulators/lane), K step 64.  Both operands are
-// staged HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip) into a double buffer; the LDS
-// image is lane-linear per wave instruction (8 rows x 128 B), so the bank-conflict swizzle
-// (16-B chunk ^= (row>>1)&7, conflict-free for ds_read_b128's 16-lane groups on 128-B rows) is
-// applied to the per-lane SOURCE address and again on the fragment read.  One barrier per K tile:
-// the loads of tile t+1 are issued before the MFMAs of tile t and land under them.
-// Workgroup ids are remapped so that each XCD owns a contiguous run of tiles (shared X panel in L2).
+// Structure: one 256-thread workgroup (4 waves as 2x2, ONE wave per SIMD) per output tile of
+// (64*FM) x (64*FN); a wave owns FM x FN v_mfma_f32_32x32x16_bf16 fragments (256x128: 128 fp32
+// accumulators/lane, 8 MFMAs per 6 ds_read_b128).  K step 64.  Both operands are staged HBM -> LDS
+// with global_load_lds_dwordx4 (no VGPR round trip) into a 3-slot ring: the loads of tile t+2 are
+// issued before the MFMAs of tile t and stay in flight ACROSS the per-tile barrier (raw s_barrier +
+// counted s_waitcnt vmcnt(N), never vmcnt(0) in the steady state).  The LDS image is lane-linear
+// per wave instruction (8 rows x 128 B), so the bank-conflict swizzle (16-B chunk ^= (row>>1)&7,
+// conflict-free for ds_read_b128's 16-lane groups on 128-B rows) is applied to the per-lane SOURCE
+// address and again on the fragment read.  Fragments of k-substep kk+1 are read while the MFMAs of
+// kk issue.  Tile shape is picked per launch to minimise the last partial round over 256 CUs
+// (e.g. 128x192 for M=16000,N=768: 500 tiles = 1.95 rounds).  Workgroup ids are remapped so that
+// each XCD owns a contiguous run of tiles (shared X panel in L2).
 #include "kernels.h"
 
-#define BM 128
-#define BN 128
-#define BK 64
-#define TILE_BYTES (128 * BK * 2)          // 16 KiB per operand tile
-#define STAGE_BYTES (2 * TILE_BYTES)       // X tile + W tile
-#define GEMM_LDS (2 * STAGE_BYTES)         // double buffered: 64 KiB
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* glb_vptr;
@@ -63,7 +61,7 @@ __device__ __forceinline__ void epilogue_swapped(const GemmArgs& a, const f32x16
         } else if constexpr (EPI == EPI_F32_RES) {
             const float4 rr = *(const float4*)(a.res + (size_t)m * a.ldres + n);
             *(float4*)((float*)a.out0 + (size_t)m * a.ld0 + n) = make_float4(v0 + rr.x, v1 + rr.y, v2 + rr.z, v3 + rr.w);
-        } else if constexpr (EPI == EPI_QKV) {
+        } else if constexpr (EPI == EPI_QK) {
             // n < 1536 here (q and k thirds); head-major [B,H,Tp,64]
             const int which = n >= SYL_HIDDEN;            // 0 = q, 1 = k
             const int nn = n - which * SYL_HIDDEN;
@@ -84,14 +82,14 @@ __device__ __forceinline__ void epilogue_swapped(const GemmArgs& a, const f32x16
     }
 }
 
-// V third of the fused QKV projection, NATURAL orientation: lane owns feature n (column l&31) and 16
+// V projection (its own launch, EPI_V), NATURAL orientation: lane owns feature n (column l&31) and 16
 // tokens m = mb + (r&3) + 8*(r>>2) + 4*(l>>5): four runs of 4 consecutive tokens -> 8-byte stores
 // into the key-contiguous Vt[b][head][d][t] image the attention kernel reads as MFMA A-operand.
 __device__ __forceinline__ void epilogue_v_natural(const GemmArgs& a, const f32x16_t& acc, int mb, int n, int lane) {
     if (n >= a.N) return;
     const int h = lane >> 5;
     const float bias = a.bias ? a.bias[n] : 0.f;
-    const int nn = n - 2 * SYL_HIDDEN;
+    const int nn = n;                            // the V launch has its own weight/bias slice: N = 768
     const int head = nn >> 6, d = nn & 63;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -108,11 +106,24 @@ __device__ __forceinline__ void epilogue_v_natural(const GemmArgs& a, const f32x
     }
 }
 
-template <int EPI, int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT>
+__global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) {
+    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int RB = BK * 2;               // bytes per LDS row (128 or 64)
+    constexpr int CPR = RB / 16;             // 16-B chunks per row
+    constexpr int RPP = 1024 / RB;           // rows per 1-KiB staging piece (one wave instruction)
+    constexpr int KK = BK / 16;              // MFMA k-substeps per stage
+    constexpr int XT = BM * RB, WT = BN * RB, STAGE = XT + WT;
+    constexpr int NP = (BM + BN) / RPP;      // 1-KiB pieces per stage
+    constexpr int NPW = NP / 4;              // pieces per wave
+    static_assert(NP % 4 == 0, "tile must split evenly over 4 waves");
+    constexpr bool NATURAL = (EPI == EPI_V); // A = activations: lane owns a feature column, runs of 4 tokens
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = (a.N + BN - 1) / BN;
@@ -121,123 +132,169 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs a) {
     const int m0 = (wg / tiles_n) * BM;
     const int n0 = (wg % tiles_n) * BN;
 
-    // ---- staging addresses: wave w fills rows [32w, 32w+32) of both tiles, 8 rows per instruction
-    const int srow = lane >> 3;                 // row within the 8-row piece
-    const int spos = lane & 7;                  // 16-B position within the 128-B LDS row
-    const bf16_t* gx[4];
-    const bf16_t* gw[4];
+    // ---- staging: wave w owns pieces w, w+4, ...; piece p < BM/8 is X rows 8p.., else W rows
+    const int srow = lane / CPR, spos = lane % CPR;
+    const bf16_t* gp[NPW];
+    int lds_off[NPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 32 + i * 8 + srow;
-        const int c = spos ^ ((r >> 1) & 7);    // source chunk that must land at LDS position spos
-        int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1;
-        int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1;
-        gx[i] = a.X + (size_t)xm * a.ldx + c * 8;
-        gw[i] = a.W + (size_t)wr * a.K + c * 8;
+    for (int i = 0; i < NPW; ++i) {
+        const int p = wave + 4 * i;
+        const bool isx = p < BM / RPP;
+        const int r = (isx ? p : p - BM / RPP) * RPP + srow;   // tile-local row
+        // source chunk landing at LDS position spos (bank swizzle through the source address)
+        const int c = spos ^ (BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3));
+        if (isx) { int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1; gp[i] = a.X + (size_t)xm * a.ldx + c * 8; }
+        else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; gp[i] = a.W + (size_t)wr * a.K + c * 8; }
+        lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / RPP) * 1024;
     }
-    const int lds_piece = (wave * 32) * 128;    // byte offset of this wave's first piece in a tile
+    auto stage = [&](int kt, int slot) {
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) glds16(gp[i] + kt * BK, base + lds_off[i]);
+    };
 
-    // ---- fragment read addresses (bytes within a tile)
+    // ---- fragment read addresses (bytes within a stage)
     const int frow = lane & 31;
-    const int swz = (lane >> 1) & 7;            // == ((row >> 1) & 7) for row = 32*j + (lane & 31)
+    const int swz = BK == 64 ? ((lane >> 1) & 7) : ((lane >> 2) & 3);   // swizzle key of row 32*j + (lane & 31)
     const int fhalf = lane >> 5;
-    int koff[4];
+    int koff[KK];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) koff[kk] = (((2 * kk + fhalf) ^ swz) << 4);
-    const int xrow_off = (wm * 64 + frow) * 128;
-    const int wrow_off = (wn * 64 + frow) * 128;
+    for (int kk = 0; kk < KK; ++kk) koff[kk] = (((2 * kk + fhalf) ^ swz) << 4);
+    const int xrow_off = (wm * 32 * FM + frow) * RB;
+    const int wrow_off = XT + (wn * 32 * FN + frow) * RB;
 
-    // V third of the QKV GEMM runs in natural orientation (block-uniform)
-    const bool natural = (EPI == EPI_QKV) && (n0 >= 2 * SYL_HIDDEN);
-
-    f32x16_t acc[2][2];
+    f32x16_t acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    bf16x8_t xf[2][FM], wf[2][FN];
+    auto read_frags = [&](const char* sb, int kk, int buf) {
+#pragma unroll
+        for (int f = 0; f < FM; ++f) xf[buf][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff[kk]);
+#pragma unroll
+        for (int f = 0; f < FN; ++f) wf[buf][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff[kk]);
+    };
+    auto mfmas = [&](int buf) {
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+                if constexpr (NATURAL)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[buf][fm], wf[buf][fn], acc[fm][fn], 0, 0, 0);
+                else
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][fn], xf[buf][fm], acc[fm][fn], 0, 0, 0);
+            }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- NSTAGE-slot ring: tiles t+1 .. t+NSTAGE-1 in flight while tile t is consumed
     const int nt = a.K / BK;
-    // prologue: stage tile 0 into buffer 0
-    {
-        char* xb = smem;
-        char* wb = smem + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(gx[i], xb + lds_piece + i * 1024);
-            glds16(gw[i], wb + lds_piece + i * 1024);
-        }
-    }
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    if constexpr (NSTAGE > 2) { if (nt > 2) stage(2, 2); }
+    if constexpr (NSTAGE > 3) { if (nt > 3) stage(3, 3); }
+    if (NSTAGE > 3 && nt > 3) wait_vmcnt<3 * NPW>();
+    else if (NSTAGE > 2 && nt > 2) wait_vmcnt<2 * NPW>();
+    else if (nt > 1) wait_vmcnt<NPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(smem, 0, 0);
+    int slot = 0;
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();   // tile t landed (vmcnt(0) precedes the barrier); everyone is done with the other buffer
+        const char* sb = smem + slot * STAGE;
+        const int nslot = slot == NSTAGE - 1 ? 0 : slot + 1;
+#pragma unroll
+        for (int kk = 0; kk < KK - 1; ++kk) {
+            SCHED_FENCE();
+            read_frags(sb, kk + 1, (kk + 1) & 1);
+            SCHED_FENCE();
+            mfmas(kk & 1);
+        }
+        SCHED_FENCE();
         if (t + 1 < nt) {
-            char* xb = smem + ((t + 1) & 1) * STAGE_BYTES;
-            char* wb = xb + TILE_BYTES;
-            const int ko = (t + 1) * BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                glds16(gx[i] + ko, xb + lds_piece + i * 1024);
-                glds16(gw[i] + ko, wb + lds_piece + i * 1024);
-            }
+            // every ds_read of tile t has been issued; once they have landed (lgkmcnt(0)) and my pieces of
+            // tile t+1 have landed (counted vmcnt: tile t+2 stays in flight), meet the other waves.  After
+            // the barrier tile t+1 is visible and slot(t) is dead -> refill it with tile t+3, and fetch the
+            // first fragments of tile t+1 so that they land under the last 8 MFMAs of tile t.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // outstanding tiles: t+1 .. min(t+NSTAGE-1, nt-1); everything after t+1 may stay in flight
+            if (NSTAGE > 3 && t + 3 < nt) wait_vmcnt<2 * NPW>();
+            else if (NSTAGE > 2 && t + 2 < nt) wait_vmcnt<NPW>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            SCHED_FENCE();
+            read_frags(smem + nslot * STAGE, 0, 0);
+            if (t + NSTAGE < nt) stage(t + NSTAGE, slot);
+            SCHED_FENCE();
         }
-        const char* xb = smem + (t & 1) * STAGE_BYTES;
-        const char* wb = xb + TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8_t xf[2], wf[2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                xf[f] = *(const bf16x8_t*)(xb + xrow_off + f * 32 * 128 + koff[kk]);
-                wf[f] = *(const bf16x8_t*)(wb + wrow_off + f * 32 * 128 + koff[kk]);
-            }
-            if (natural) {
-#pragma unroll
-                for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-                    for (int fn = 0; fn < 2; ++fn)
-                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fm], wf[fn], acc[fm][fn], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-                    for (int fn = 0; fn < 2; ++fn)
-                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fn], xf[fm], acc[fm][fn], 0, 0, 0);
-            }
-        }
+        mfmas((KK - 1) & 1);
+        slot = nslot;
     }
 
     // ---- epilogue
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm)
+    for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-        for (int fn = 0; fn < 2; ++fn) {
-            const int mb = m0 + wm * 64 + fm * 32;
-            const int nb = n0 + wn * 64 + fn * 32;
-            if (natural) {
-                if constexpr (EPI == EPI_QKV) epilogue_v_natural(a, acc[fm][fn], mb, nb + frow, lane);
-            } else {
-                epilogue_swapped<EPI, ACT>(a, acc[fm][fn], mb + frow, nb, lane);
-            }
+        for (int fn = 0; fn < FN; ++fn) {
+            const int mb = m0 + wm * 32 * FM + fm * 32;
+            const int nb = n0 + wn * 32 * FN + fn * 32;
+            if constexpr (NATURAL) epilogue_v_natural(a, acc[fm][fn], mb, nb + frow, lane);
+            else epilogue_swapped<EPI, ACT>(a, acc[fm][fn], mb + frow, nb, lane);
         }
 }
 
-template <int EPI, int ACT>
-static int launch_t(const GemmArgs& a, hipStream_t s) {
+template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT>
+static int launch_cfg(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int LDS = NSTAGE * (BM + BN) * BK * 2;
+    if (a.K % BK != 0) { syl_set_error("launch_gemm_bf16", "K must be a multiple of the K step"); return 1; }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static bool attr_set = false;
-    auto kern = gemm_bf16_kernel<EPI, ACT>;
+    auto kern = gemm_bf16_kernel<FM, FN, BK, NSTAGE, MINB, PRIO, EPI, ACT>;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), GEMM_LDS, s, a);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+// Tile-shape choice.  Measured on MI355X (tools/gemm_bench.py, random operands): two co-resident
+// workgroups per CU (2-slot ring, <= 80 KiB LDS each) beat one workgroup with a 3-slot ring on every
+// hot-path shape, because one workgroup's epilogue / barrier / load-issue time is covered by the other's
+// MFMAs.  Between 128x128 and 128x192 the choice minimises the last partial round over 256 CUs x 2.
+static int g_force_cfg = -1;
+void gemm_force_cfg(int cfg) { g_force_cfg = cfg; }
+
+template <int EPI, int ACT>
+static int launch_t(const GemmArgs& a, hipStream_t s) {
+    struct Cfg { int bm, bn; double eff; };
+    const Cfg cfgs[2] = {{128, 128, 0.90}, {128, 192, 1.00}};
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < 2; ++i) {
+        const long tm = (a.M + cfgs[i].bm - 1) / cfgs[i].bm, tn = (a.N + cfgs[i].bn - 1) / cfgs[i].bn;
+        const long rounds = (tm * tn + 511) / 512;
+        const double cost = (double)rounds * cfgs[i].bm * cfgs[i].bn / cfgs[i].eff;
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    int cfg = best == 0 ? 3 : 4;
+    if (g_force_cfg >= 0) cfg = g_force_cfg;
+    switch (cfg) {
+        case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
+        case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT>(a, s);   // 128x128, 2 WG/CU
+        default: return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT>(a, s);  // 128x192, 2 WG/CU
+    }
+}
+
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s) {
-    if (a.K % BK != 0 || a.K <= 0 || a.M <= 0 || a.N <= 0) { syl_set_error("launch_gemm_bf16", "K must be a positive multiple of 64"); return 1; }
+    if (a.K % 64 != 0 || a.K <= 0 || a.M <= 0 || a.N <= 0) { syl_set_error("launch_gemm_bf16", "K must be a positive multiple of 64"); return 1; }
     if (a.N % 4 != 0) { syl_set_error("launch_gemm_bf16", "N must be a multiple of 4"); return 1; }
     switch (epi) {
         case EPI_BF16:
@@ -249,7 +306,8 @@ int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s) {
             if (a.act == 2) return launch_t<EPI_F32, 2>(a, s);
             return launch_t<EPI_F32, 0>(a, s);
         case EPI_F32_RES: return launch_t<EPI_F32_RES, 0>(a, s);
-        case EPI_QKV: return launch_t<EPI_QKV, 0>(a, s);
+        case EPI_QK: return launch_t<EPI_QK, 0>(a, s);
+        case EPI_V: return launch_t<EPI_V, 0>(a, s);
         case EPI_PROJ: return launch_t<EPI_PROJ, 0>(a, s);
     }
     syl_set_error("launch_gemm_bf16", "unknown epilogue");

@@ -11,8 +11,9 @@ enum GemmEpi {
     EPI_BF16 = 0,       // out0 bf16 [M][ld0] = act(acc + bias)
     EPI_F32 = 1,        // out0 f32  [M][ld0] = act(acc + bias)
     EPI_F32_RES = 2,    // out0 f32  [M][ld0] = acc + bias + res[m][n]
-    EPI_QKV = 3,        // q (x0.125), k -> [B,H,Tp,64] bf16 ; v -> Vt [B,H,64,Tpv] bf16
+    EPI_QK = 3,         // N = 1536: q (x0.125) -> out0, k -> out1, both [B,H,Tp,64] bf16
     EPI_PROJ = 4,       // feature projection: zero padded frames; out0 f32 [M][768]; out1 bf16 xpad
+    EPI_V = 5,          // N = 768: v -> out2 = Vt [B,H,64,Tpv] bf16 (key axis bit-swapped), natural orientation
 };
 
 struct GemmArgs {
@@ -30,6 +31,7 @@ struct GemmArgs {
 };
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
+void gemm_force_cfg(int cfg);   // -1 = automatic tile-shape choice
 
 // fp32 parity-mode GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), same epilogues on fp32 tensors
 struct GemmArgsF32 {
