@@ -114,6 +114,8 @@ int sylber_op_attention(const float* q_dev, const float* k_dev, const float* v_d
 
 /* development aid: average ms of one launch of the bf16 GEMM kernel (M x N x K, activation row stride
  * ldx) on pseudo-random operands; epi/act as in csrc/kernels.h, cfg -1 = automatic tile shape */
+/* development aid: force a GEMM tile configuration for every following launch (-1 = automatic) */
+void sylber_debug_force_gemm_cfg(int32_t cfg);
 int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
                             int32_t iters, float* ms_out);
 

@@ -446,6 +446,8 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
 
 
 // ------------------------------------------------------------------------------------------------
+extern "C" void sylber_debug_force_gemm_cfg(int32_t cfg) { gemm_force_cfg(cfg); }
+
 // GEMM micro-benchmark (development aid): times `iters` launches of the bf16 GEMM on pseudo-random
 // operands with HIP events.  cfg: -1 auto, 0 = 256x128, 1 = 128x192, 2 = 128x128 tiles.
 __global__ void fill_random_bf16(bf16_t* p, size_t n, unsigned seed) {
@@ -468,6 +470,15 @@ extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t 
     GemmArgs g = {};
     g.X = (bf16_t*)xb.p; g.ldx = ldx; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = (float*)bb.p; g.act = act;
     g.out0 = ob.p; g.ld0 = N; g.res = (float*)rb.p; g.ldres = N;
+    g.xpad_rows = cfg >= 1000 ? (cfg / 1000) : 0;     // ablation flags ride on cfg = flags*1000 + cfg
+    cfg = cfg % 1000;
+    TmpBuf dbg;
+    const size_t ndbg = (size_t)((M + 127) / 128) * ((N + 127) / 128) * 4 * 5;
+    if (g.xpad_rows & 16) {
+        if (dbg.alloc(ndbg * 8)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }
+        HIP_TRY(hipMemset(dbg.p, 0, ndbg * 8));
+        g.out1 = dbg.p;
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     gemm_force_cfg(cfg);
@@ -482,5 +493,16 @@ extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t 
     hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (g.xpad_rows & 16) {
+        std::vector<unsigned long long> h(ndbg);
+        hipMemcpy(h.data(), dbg.p, ndbg * 8, hipMemcpyDeviceToHost);
+        double tot[5] = {0, 0, 0, 0, 0};
+        size_t nw = 0;
+        for (size_t w = 0; w + 5 <= ndbg; w += 5) { if (!h[w]) continue; for (int i = 0; i < 5; ++i) tot[i] += (double)h[w + i]; ++nw; }
+        const double steps = (double)(K / (cfg >= 10 ? 32 : 64)) * (nw ? nw : 1);
+        printf("timing (ticks per step, mean over %zu waves; cfg<10: kk0..2 | waits | barrier | frag0+DMA | last mfma; cfg>=10: "
+               "reads+DMA issue | waits | barrier | mfma | barrier): %.0f | %.0f | %.0f | %.0f | %.0f\n", nw, tot[0] / steps, tot[1] / steps, tot[2] / steps, tot[3] / steps, tot[4] / steps);
+        fflush(stdout);
+    }
     return rc;
 }

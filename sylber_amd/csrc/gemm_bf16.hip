@@ -205,9 +205,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
     __builtin_amdgcn_s_barrier();
     read_frags(smem, 0, 0);
     int slot = 0;
+    const bool timing = (EPI != EPI_PROJ) && (a.xpad_rows & 16);
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return timing ? __builtin_readcyclecounter() : 0ull; };
     for (int t = 0; t < nt; ++t) {
         const char* sb = smem + slot * STAGE;
         const int nslot = slot == NSTAGE - 1 ? 0 : slot + 1;
+        const unsigned long long t0 = now();
 #pragma unroll
         for (int kk = 0; kk < KK - 1; ++kk) {
             SCHED_FENCE();
@@ -216,6 +220,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
             mfmas(kk & 1);
         }
         SCHED_FENCE();
+        const unsigned long long t1 = now();
+        unsigned long long t2 = t1, t3 = t1, t4 = t1;
         if (t + 1 < nt) {
             // every ds_read of tile t has been issued; once they have landed (lgkmcnt(0)) and my pieces of
             // tile t+1 have landed (counted vmcnt: tile t+2 stays in flight), meet the other waves.  After
@@ -226,17 +232,40 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
             if (NSTAGE > 3 && t + 3 < nt) wait_vmcnt<2 * NPW>();
             else if (NSTAGE > 2 && t + 2 < nt) wait_vmcnt<NPW>();
             else wait_vmcnt<0>();
+            t2 = now();
             __builtin_amdgcn_s_barrier();
+            t3 = now();
             SCHED_FENCE();
             read_frags(smem + nslot * STAGE, 0, 0);
             if (t + NSTAGE < nt) stage(t + NSTAGE, slot);
             SCHED_FENCE();
+            t4 = now();
         }
         mfmas((KK - 1) & 1);
         slot = nslot;
+        if (timing) {
+            const unsigned long long t5 = now();
+            tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += t5 - t4;
+        }
+    }
+    if (timing && lane == 0 && a.out1) {
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 5;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
     }
 
     // ---- epilogue
+    if (EPI != EPI_PROJ && (a.xpad_rows & 8)) {      // development ablation: no stores
+        float sum = 0.f;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[fm][fn][r];
+        if (sum == 123.456f) ((float*)a.out0)[0] = sum;
+        return;
+    }
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
@@ -265,30 +294,213 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-// Tile-shape choice.  Measured on MI355X (tools/gemm_bench.py, random operands): two co-resident
-// workgroups per CU (2-slot ring, <= 80 KiB LDS each) beat one workgroup with a 3-slot ring on every
-// hot-path shape, because one workgroup's epilogue / barrier / load-issue time is covered by the other's
-// MFMAs.  Between 128x128 and 128x192 the choice minimises the last partial round over 256 CUs x 2.
+// ---------------------------------------------------------------------------------------------------
+// 8-wave variant (512 threads, two waves per SIMD, ONE workgroup per CU) for the big tiles 256x256 and
+// 256x192.  Per-CU L1/TA traffic per FLOP falls with the tile area, which is what caps the 4-wave kernel
+// above (128x192 needs ~53 B/clk/CU of the 64 B/clk texture path at full MFMA rate).  The two waves
+// of a SIMD belong to two groups staggered by ONE barrier: each step is
+//     A: ds_read this step's fragments + issue a share of the next stage's LDS-DMA              | barrier
+//     B: 2*FM*FN MFMAs from registers                                                       | barrier
+// so while group 0 is in B (matrix pipe), group 1 is in A (LDS / VMEM issue) and vice versa.
+// Hazards: a step's DMA is retired (vmcnt) two program barriers before its first ds_read (one more than
+// usual because the groups are staggered); fragment reads complete (lgkmcnt(0)) before the barrier that
+// lets the other group refill that slot.
+template <int FM, int FN, int WM, int WN, int EPI, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
+    // K step 32 (64-byte LDS rows), 4-slot ring: the DMA of step s+3 is issued in step s and retired with
+    // counted vmcnt, never 0 in the steady state.  (A 2-slot ring of 64-wide stages measured 5-12 % slower.)
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
+    constexpr int RB = 64;
+    constexpr int XT = BM * RB, WT = BN * RB, STAGE = XT + WT;
+    constexpr int NP = (BM + BN) / 16;               // 1-KiB pieces (16 rows x 64 B) per step
+    constexpr int NPW_HI = (NP + 7) / 8, NPW_LO = NP / 8;
+    constexpr bool NATURAL = (EPI == EPI_V);
+    static_assert(WM * WN == 8, "8 waves");
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int group = wave >> 2;                     // waves w and w+4 share a SIMD
+    const int wm = wave / WN, wn = wave % WN;
+    const bool hi = wave < (NP % 8 == 0 ? 8 : NP % 8);   // this wave issues NPW_HI pieces per step
+
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (wg / tiles_n) * BM;
+    const int n0 = (wg % tiles_n) * BN;
+
+    const int srow = lane >> 2, spos = lane & 3;
+    const bf16_t* gp[NPW_HI];
+    int lds_off[NPW_HI];
+#pragma unroll
+    for (int i = 0; i < NPW_HI; ++i) {
+        int p = wave + 8 * i;
+        p = p < NP ? p : NP - 1;                     // (unused slot of a "lo" wave; never issued)
+        const bool isx = p < BM / 16;
+        const int r = (isx ? p : p - BM / 16) * 16 + srow;
+        const int c = spos ^ ((r >> 2) & 3);
+        if (isx) { int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1; gp[i] = a.X + (size_t)xm * a.ldx + c * 8; }
+        else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; gp[i] = a.W + (size_t)wr * a.K + c * 8; }
+        lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / 16) * 1024;
+    }
+    auto stage = [&](int ks, int slot) {
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < NPW_HI; ++i)
+            if (i < NPW_LO || hi) glds16(gp[i] + ks * 32, base + lds_off[i]);
+    };
+    auto wait_steps = [&](int nsteps_in_flight) {    // leave that many of MY steps' pieces outstanding
+        if (hi) {
+            if (nsteps_in_flight >= 2) wait_vmcnt<2 * NPW_HI>(); else if (nsteps_in_flight == 1) wait_vmcnt<NPW_HI>(); else wait_vmcnt<0>();
+        } else {
+            if (nsteps_in_flight >= 2) wait_vmcnt<2 * NPW_LO>(); else if (nsteps_in_flight == 1) wait_vmcnt<NPW_LO>(); else wait_vmcnt<0>();
+        }
+    };
+
+    const int frow = lane & 31;
+    const int swz = (lane >> 2) & 3;
+    const int fhalf = lane >> 5;
+    const int koff0 = (((0 + fhalf) ^ swz) << 4), koff1 = (((2 + fhalf) ^ swz) << 4);
+    const int xrow_off = (wm * 32 * FM + frow) * RB;
+    const int wrow_off = XT + (wn * 32 * FN + frow) * RB;
+
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = a.K / 32;
+    const int abl = (EPI == EPI_PROJ) ? 0 : a.xpad_rows;     // development ablations (micro-benchmark only)
+    const bool timing = abl & 16;
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return timing ? __builtin_readcyclecounter() : 0ull; };
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    if (nt > 2) stage(2, 2);
+    wait_steps(nt > 2 ? 2 : nt - 1);                 // step 0 landed (mine)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    if (group == 1) __builtin_amdgcn_s_barrier();    // stagger: group 1 runs one barrier behind
+    int slot = 0;
+    for (int s = 0; s < nt; ++s) {
+        const char* sb = smem + slot * STAGE;
+        bf16x8_t xf[2][FM], wf[2][FN];
+        // ---- A: fragments of step s, DMA of step s+3, retire step s+1
+        const unsigned long long t0 = now();
+        SCHED_FENCE();
+        if (!(abl & 2) || s == 0) {
+#pragma unroll
+            for (int f = 0; f < FM; ++f) {
+                xf[0][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff0);
+                xf[1][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff1);
+            }
+#pragma unroll
+            for (int f = 0; f < FN; ++f) {
+                wf[0][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff0);
+                wf[1][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff1);
+            }
+        }
+        if (s + 3 < nt && !(abl & 1)) stage(s + 3, (slot + 3) & 3);
+        const unsigned long long t1 = now();
+        {
+            const int after = nt - 2 - s;            // steps issued after step s+1
+            wait_steps(after >= 2 ? 2 : (after > 0 ? after : 0));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SCHED_FENCE();
+        const unsigned long long t2 = now();
+        __builtin_amdgcn_s_barrier();
+        const unsigned long long t3 = now();
+        SCHED_FENCE();
+        // ---- B: MFMAs of step s
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) {
+                    if constexpr (NATURAL)
+                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[kk][fm], wf[kk][fn], acc[fm][fn], 0, 0, 0);
+                    else
+                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][fn], xf[kk][fm], acc[fm][fn], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+        SCHED_FENCE();
+        const unsigned long long t4 = now();
+        __builtin_amdgcn_s_barrier();
+        if (timing) {
+            const unsigned long long t5 = now();
+            tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += t5 - t4;
+        }
+        slot = (slot + 1) & 3;
+    }
+    if (group == 0) __builtin_amdgcn_s_barrier();    // pairs with group 1's extra barrier
+    if (timing && lane == 0 && a.out1 && wave < 4) {
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 5;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
+    }
+
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int mb = m0 + wm * 32 * FM + fm * 32;
+            const int nb = n0 + wn * 32 * FN + fn * 32;
+            if constexpr (NATURAL) epilogue_v_natural(a, acc[fm][fn], mb, nb + frow, lane);
+            else epilogue_swapped<EPI, ACT>(a, acc[fm][fn], mb + frow, nb, lane);
+        }
+}
+
+template <int FM, int FN, int WM, int WN, int EPI, int ACT>
+static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
+    constexpr int LDS = 4 * (BM + BN) * 64;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    static bool attr_set = false;
+    auto kern = gemm8_bf16_kernel<FM, FN, WM, WN, EPI, ACT>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Tile-shape choice, measured on MI355X with tools/gemm_bench.py (random operands):
+//   cfg 3  128x128, 4 waves, 2 workgroups/CU   best when the tile count just fills one round (conv6)
+//   cfg 4  128x192, 4 waves, 2 workgroups/CU   best for N = 768 / 1536 (500 / 1000 tiles = 1 / 2 rounds)
+//   cfg 10 256x256, 8 waves staggered, 1 WG/CU best for the big GEMMs (conv1-5, FFN1): +20-25 %
+// Two co-resident workgroups (cfg 3/4) cover each other's epilogue / barrier / DMA-issue time; the big
+// tile (cfg 10) instead halves the per-FLOP L1/TA traffic.  Cost = rounds x (tile area per CU) / eff.
 static int g_force_cfg = -1;
 void gemm_force_cfg(int cfg) { g_force_cfg = cfg; }
 
 template <int EPI, int ACT>
 static int launch_t(const GemmArgs& a, hipStream_t s) {
-    struct Cfg { int bm, bn; double eff; };
-    const Cfg cfgs[2] = {{128, 128, 0.90}, {128, 192, 1.00}};
+    struct Cfg { int id, bm, bn, per_cu; double eff; };
+    const Cfg cfgs[3] = {{3, 128, 128, 2, 0.93}, {4, 128, 192, 2, 1.00}, {10, 256, 256, 1, 1.20}};
     int best = 0;
     double best_cost = 1e300;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         const long tm = (a.M + cfgs[i].bm - 1) / cfgs[i].bm, tn = (a.N + cfgs[i].bn - 1) / cfgs[i].bn;
-        const long rounds = (tm * tn + 511) / 512;
-        const double cost = (double)rounds * cfgs[i].bm * cfgs[i].bn / cfgs[i].eff;
+        const long slots = 256L * cfgs[i].per_cu;
+        const long rounds = (tm * tn + slots - 1) / slots;
+        const double cost = (double)rounds * cfgs[i].per_cu * cfgs[i].bm * cfgs[i].bn / cfgs[i].eff;
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
-    int cfg = best == 0 ? 3 : 4;
+    int cfg = cfgs[best].id;
     if (g_force_cfg >= 0) cfg = g_force_cfg;
     switch (cfg) {
         case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
         case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT>(a, s);   // 128x128, 2 WG/CU
+        case 10: return launch_cfg8<4, 2, 2, 4, EPI, ACT>(a, s);            // 256x256, 8 waves staggered
+        case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT>(a, s);            // 256x192, 8 waves staggered
         default: return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT>(a, s);  // 128x192, 2 WG/CU
     }
 }

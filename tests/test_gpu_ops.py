@@ -82,3 +82,24 @@ def test_attention(lib, B, T, valid):
     err = (o.cpu() - ref).abs().max().item()
     assert err < 3e-2, err     # P and the output are rounded to bf16 (rel 3.9e-3) around O(1) values
     assert (o.cpu() - ref).pow(2).mean().sqrt().item() < 4e-3
+
+
+@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11])
+def test_linear_every_tile_config(lib, cfg):
+    """every GEMM tile configuration (4-wave 2/3-slot rings, 8-wave staggered big tiles) gives the same
+    result, including ragged M / N tails and a strided (overlapping-row) activation operand"""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(7)
+    for (M, N, K) in [(700, 768, 768), (1000, 512, 1536), (333, 3072, 768), (257, 768, 3072)]:
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+        c = torch.full((M, N), float("nan"), device="cuda")
+        lib.sylber_debug_force_gemm_cfg(cfg)
+        try:
+            _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 1, 0, None), "op_linear")
+        finally:
+            lib.sylber_debug_force_gemm_cfg(-1)
+        ref = torch.nn.functional.gelu(_bf(a) @ _bf(w).T + b)
+        assert (c.cpu() - ref).abs().max().item() < 2e-3, (cfg, M, N, K)

@@ -18,7 +18,7 @@ SHAPES = [  # name, M, N, K, ldx, epi, act
     ("ffn2", M, 768, 3072, 3072, 2, 0),
     ("sq4096", 4096, 4096, 4096, 4096, 0, 0),
 ]
-cfgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1, 0, 3, 4]
+cfgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1, 3, 4, 10, 11]
 for name, m, n, k, ldx, epi, act in SHAPES:
     row = []
     for cfg in cfgs:
