@@ -106,6 +106,96 @@ __device__ __forceinline__ void epilogue_v_natural(const GemmArgs& a, const f32x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Coalesced epilogue through LDS (swapped orientation).  Straight from the MFMA layout a lane owns ONE
+// output row and runs of 4 columns, so a store instruction would touch 32 rows with 16-32 bytes each
+// (measured: 20-48 % of the kernel on the hot-path shapes).  Instead every wave transposes one 32-row block
+// of its tile through a private LDS region (row stride padded by 16 B: 2-way worst case on ds_write_b64)
+// and reads it back as 16-byte chunks with consecutive lanes on consecutive chunks of a row, so global
+// loads (fp32 residual) and stores run over whole 128-byte lines.  Bias / activation / q-scaling / padded
+// frame zeroing are applied on the way in; the residual add on the way out.
+template <int FN, int EPI>
+struct StagedEpi {
+    static constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_RES || EPI == EPI_PROJ);
+    static constexpr int ES = F32OUT ? 4 : 2;
+    static constexpr int ROWB = 32 * FN * ES;       // payload bytes per row
+    static constexpr int RS = ROWB + 16;            // padded row stride
+    static constexpr int CH = ROWB / 16;            // 16-byte chunks per row
+    static constexpr int BYTES = 32 * RS;           // private LDS bytes per wave
+};
+
+template <int FN, int EPI, int ACT>
+__device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_t (&acc)[FN], int mrow0, int ncol0, char* lds,
+                                                int lane) {
+    using S = StagedEpi<FN, EPI>;
+    const int ml = lane & 31, h = lane >> 5;
+    const int m = mrow0 + ml;
+    // ---- in: MFMA layout -> row-major LDS
+    bool zero_row = false;
+    if constexpr (EPI == EPI_PROJ) {
+        const int mm = m < a.M ? m : a.M - 1;
+        const int b = mm / a.Tp, t = mm - b * a.Tp;
+        const int nv = a.valid[b] < a.T ? a.valid[b] : a.T;
+        zero_row = t >= nv;                              // TP:428-431 zero padded frames (and rows beyond T)
+    }
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = 32 * fn + 8 * g + 4 * h;
+            const int n = ncol0 + nl;
+            float v0 = acc[fn][4 * g + 0], v1 = acc[fn][4 * g + 1], v2 = acc[fn][4 * g + 2], v3 = acc[fn][4 * g + 3];
+            if (a.bias && n < a.N) {
+                const float4 bb = *(const float4*)(a.bias + n);
+                v0 += bb.x; v1 += bb.y; v2 += bb.z; v3 += bb.w;
+            }
+            if constexpr (EPI == EPI_BF16 || EPI == EPI_F32) {
+                v0 = apply_act<ACT>(v0); v1 = apply_act<ACT>(v1); v2 = apply_act<ACT>(v2); v3 = apply_act<ACT>(v3);
+            }
+            if constexpr (EPI == EPI_QK) {
+                if (n < SYL_HIDDEN) { v0 *= 0.125f; v1 *= 0.125f; v2 *= 0.125f; v3 *= 0.125f; }
+            }
+            if constexpr (EPI == EPI_PROJ) { if (zero_row) { v0 = v1 = v2 = v3 = 0.f; } }
+            if constexpr (S::F32OUT) {
+                *(float4*)(lds + ml * S::RS + nl * 4) = make_float4(v0, v1, v2, v3);
+            } else {
+                uint2 pk; pk.x = pack_bf16x2(v0, v1); pk.y = pack_bf16x2(v2, v3);
+                *(uint2*)(lds + ml * S::RS + nl * 2) = pk;
+            }
+        }
+    // ---- out: 16-byte chunks, consecutive lanes on consecutive chunks of a row
+#pragma unroll
+    for (int it = 0; it < S::CH / 2; ++it) {
+        const int idx = it * 64 + lane;
+        const int r = idx / S::CH, c = idx - r * S::CH;
+        const int mo = mrow0 + r;
+        const int n = ncol0 + c * (16 / S::ES);
+        if (mo >= a.M || n >= a.N) continue;
+        const uint4 raw = *(const uint4*)(lds + r * S::RS + c * 16);
+        if constexpr (EPI == EPI_BF16) {
+            *(uint4*)((bf16_t*)a.out0 + (size_t)mo * a.ld0 + n) = raw;
+        } else if constexpr (EPI == EPI_F32) {
+            *(uint4*)((float*)a.out0 + (size_t)mo * a.ld0 + n) = raw;
+        } else if constexpr (EPI == EPI_F32_RES) {
+            const float4 rr = *(const float4*)(a.res + (size_t)mo * a.ldres + n);
+            const float4 v = __builtin_bit_cast(float4, raw);
+            *(float4*)((float*)a.out0 + (size_t)mo * a.ld0 + n) = make_float4(v.x + rr.x, v.y + rr.y, v.z + rr.z, v.w + rr.w);
+        } else if constexpr (EPI == EPI_QK) {
+            const int which = n >= SYL_HIDDEN;
+            const int nn = n - which * SYL_HIDDEN;
+            const int head = nn >> 6, d = nn & 63;
+            const int b = mo / a.Tp, t = mo - b * a.Tp;
+            *(uint4*)((bf16_t*)(which ? a.out1 : a.out0) + (((size_t)b * SYL_HEADS + head) * a.Tp + t) * 64 + d) = raw;
+        } else if constexpr (EPI == EPI_PROJ) {
+            const float4 v = __builtin_bit_cast(float4, raw);
+            *(float4*)((float*)a.out0 + (size_t)mo * a.ld0 + n) = v;
+            const int b = mo / a.Tp, t = mo - b * a.Tp;
+            uint2 pk; pk.x = pack_bf16x2(v.x, v.y); pk.y = pack_bf16x2(v.z, v.w);
+            *(uint2*)((bf16_t*)a.out1 + ((size_t)b * a.xpad_rows + 64 + t) * SYL_HIDDEN + n) = pk;
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -266,15 +356,28 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
         if (sum == 123.456f) ((float*)a.out0)[0] = sum;
         return;
     }
+    if constexpr (NATURAL) {
 #pragma unroll
-    for (int fm = 0; fm < FM; ++fm)
+        for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-        for (int fn = 0; fn < FN; ++fn) {
-            const int mb = m0 + wm * 32 * FM + fm * 32;
-            const int nb = n0 + wn * 32 * FN + fn * 32;
-            if constexpr (NATURAL) epilogue_v_natural(a, acc[fm][fn], mb, nb + frow, lane);
-            else epilogue_swapped<EPI, ACT>(a, acc[fm][fn], mb + frow, nb, lane);
-        }
+            for (int fn = 0; fn < FN; ++fn)
+                epilogue_v_natural(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN + fn * 32 + frow, lane);
+    } else if constexpr (EPI == EPI_QK || EPI == EPI_PROJ) {
+        // measured A/B (MI355X): the LDS-staged, line-coalesced epilogue wins for the scattered head-major /
+        // dual-output epilogues (+7 % qk, +40 % proj) and is neutral-to-slightly-negative for the others
+        static_assert(4 * StagedEpi<FN, EPI>::BYTES <= NSTAGE * STAGE, "epilogue staging must fit the ring");
+        __builtin_amdgcn_s_barrier();                 // every wave is done reading operand tiles
+        char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+            epilogue_rows32<FN, EPI, ACT>(a, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
+    } else {
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                epilogue_swapped<EPI, ACT>(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+    }
 }
 
 template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT>
@@ -445,15 +548,28 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
         for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
     }
 
+    if constexpr (NATURAL) {
 #pragma unroll
-    for (int fm = 0; fm < FM; ++fm)
+        for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-        for (int fn = 0; fn < FN; ++fn) {
-            const int mb = m0 + wm * 32 * FM + fm * 32;
-            const int nb = n0 + wn * 32 * FN + fn * 32;
-            if constexpr (NATURAL) epilogue_v_natural(a, acc[fm][fn], mb, nb + frow, lane);
-            else epilogue_swapped<EPI, ACT>(a, acc[fm][fn], mb + frow, nb, lane);
-        }
+            for (int fn = 0; fn < FN; ++fn)
+                epilogue_v_natural(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN + fn * 32 + frow, lane);
+    } else if constexpr (EPI == EPI_QK || EPI == EPI_PROJ) {
+        // measured A/B (MI355X): the LDS-staged, line-coalesced epilogue wins for the scattered head-major /
+        // dual-output epilogues (+7 % qk, +40 % proj) and is neutral-to-slightly-negative for the others
+        static_assert(8 * StagedEpi<FN, EPI>::BYTES <= 4 * STAGE, "epilogue staging must fit the ring");
+        __builtin_amdgcn_s_barrier();                 // every wave is done reading operand tiles
+        char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+            epilogue_rows32<FN, EPI, ACT>(a, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
+    } else {
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                epilogue_swapped<EPI, ACT>(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+    }
 }
 
 template <int FM, int FN, int WM, int WN, int EPI, int ACT>

@@ -19,7 +19,6 @@
 #include "powf_half.h"
 
 #define SEG_D 768
-#define SEG_MAXT 4096
 
 // lane l owns elements 96*(l>>3) + (l&7) + 8*i, i = 0..11, of a 768-vector
 __device__ __forceinline__ void load_pw(const float* __restrict__ row, int lane, float (&x)[12]) {
@@ -27,14 +26,31 @@ __device__ __forceinline__ void load_pw(const float* __restrict__ row, int lane,
 #pragma unroll
     for (int i = 0; i < 12; ++i) x[i] = p[8 * i];
 }
-// numpy (x*y).sum(-1) for 768 contiguous f32; result broadcast to every lane
+// cross-lane partner values through DPP (VALU, a few cycles) instead of ds_bpermute (LDS round trip,
+// ~50 cycles): these sit on the sequential critical path of the greedy scan, six per dot product.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// numpy (x*y).sum(-1) for 768 contiguous f32; result broadcast to every lane.
+// lane = 8*leaf + accumulator.  Tree: ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) per leaf, then leaves pairwise.
+// Every add is commutative, so a partner permutation that pairs the right GROUPS is enough once the
+// values inside a group are already equal: xor1, xor2 = quad_perm; "xor4" = row_half_mirror (lane i <-> 7-i:
+// the other quad of the same leaf); "xor8" = row_mirror (i <-> 15-i: the other leaf of the pair).  The four
+// 16-lane row sums R0..R3 (= leaf pairs) are then read as scalars and combined as (R0+R1)+(R2+R3).
 __device__ __forceinline__ float pw_dot(const float (&x)[12], const float (&y)[12]) {
     float r = x[0] * y[0];
 #pragma unroll
     for (int i = 1; i < 12; ++i) { const float p = x[i] * y[i]; r = r + p; }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) r = r + __shfl_xor(r, o, 64);
-    return 0.0f + r;
+    r = r + dpp_f32<0xB1>(r);     // quad_perm [1,0,3,2]
+    r = r + dpp_f32<0x4E>(r);     // quad_perm [2,3,0,1]
+    r = r + dpp_f32<0x141>(r);    // row_half_mirror
+    r = r + dpp_f32<0x140>(r);    // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 48));
+    return 0.0f + ((r0 + r1) + (r2 + r3));
 }
 
 // numpy pairwise sum of n contiguous f32 read by ONE thread (sweep sums; n is the window length)
@@ -91,19 +107,23 @@ __device__ __forceinline__ void mean_rows3(const float* __restrict__ states, int
 
 __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ hidden, int T, float norm_thr, float merge_thr,
                                                       int64_t* __restrict__ seg_out, int* __restrict__ nseg_out,
-                                                      float* __restrict__ feat_out, float* __restrict__ scratch,
-                                                      size_t scratch_per_utt) {
-    __shared__ float ca_s[SEG_D], cb_s[SEG_D];
-    __shared__ float simp_s[SEG_MAXT], simn_s[SEG_MAXT], sweep_s[SEG_MAXT];
-    __shared__ int sh_i[8];
+                                                      float* __restrict__ feat_out) {
+    // all bookkeeping lives in LDS (dynamic, sized by T): the refinement loop is a chain of dependent
+    // reads of the segment table, which from global memory cost an L2 round trip per step
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    float* ca_s = lds_f;                       // [768]
+    float* cb_s = ca_s + SEG_D;                // [768]
+    float* simp_s = cb_s + SEG_D;              // [T]
+    float* simn_s = simp_s + T;                // [T]
+    float* sweep_s = simn_s + T;               // [T]
+    float* nsq = sweep_s + T;                  // [T] sqrt path norms (mask; 2-D cossim)
+    float* npw = nsq + T;                      // [T] powf path norms (1-D cossim)
+    int* seg = (int*)(npw + T);                // [T+1][2]
+    int* mid = seg + 2 * (T + 1);              // [T+1][2]
+    int* merged = mid + 2 * (T + 1);           // [T+1]
+    int* sh_i = merged + (T + 1);              // [8]
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* states = hidden + (size_t)b * T * SEG_D;
-    float* sc = scratch + (size_t)b * scratch_per_utt;
-    float* nsq = sc;                          // sqrt path norms (mask; 2-D cossim)
-    float* npw = sc + T;                      // powf path norms (1-D cossim)
-    int* seg = (int*)(sc + 2 * T);            // [T+1][2]
-    int* mid = seg + 2 * (T + 1);             // [T+1][2]
-    int* merged = mid + 2 * (T + 1);          // [T+1]
 
     // ---- phase 0: frame norms
     for (int i = wave; i < T; i += 4) {
@@ -140,10 +160,19 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
                     for (int k = 0; k < 12; ++k) c[k] = x[k];
                     seg_cnt = 1; s = i;
                 } else {
+                    // The decision needs the reference's exact float32 value only near the threshold.  An
+                    // estimate with relative error < 1e-5 (v_rsq / v_rcp, 1 ulp each, against <= 2 ulp of the
+                    // exact chain) settles every frame outside a +-1e-4 guard band; inside the band the exact
+                    // chain (glibc powf + two IEEE divisions, ~600 dependent cycles) is evaluated.  Same
+                    // decisions as the reference, bit for bit; the slow path just stops being per-frame.
                     const float dot = pw_dot(c, x);
-                    const float ncur = powf_half_glibc(pw_dot(c, c) + 1e-8f);
-                    const float sim = dot / ncur / npw[i];
-                    if (sim >= merge_thr) {
+                    const float cc = pw_dot(c, c) + 1e-8f;
+                    const float est = dot * __builtin_amdgcn_rsqf(cc) * __builtin_amdgcn_rcpf(npw[i]);
+                    bool merge;
+                    if (est > merge_thr + 1e-4f) merge = true;
+                    else if (est < merge_thr - 1e-4f) merge = false;
+                    else merge = (dot / powf_half_glibc(cc) / npw[i]) >= merge_thr;   // also taken for NaN
+                    if (merge) {
                         const float cf = (float)seg_cnt, c1 = (float)(seg_cnt + 1);
 #pragma unroll
                         for (int k = 0; k < 12; ++k) c[k] = (c[k] * cf + x[k]) / c1;
@@ -242,18 +271,22 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
     }
 }
 
-size_t segment_scratch_floats(int B, int T, int D) {
-    (void)D;
-    const size_t per = (size_t)2 * T + 2 * (T + 1) * 2 + (T + 1) + 64;
-    return per * (size_t)B;
-}
+static size_t segment_lds_bytes(int T) { return ((size_t)2 * SEG_D + 5 * (size_t)T + 5 * ((size_t)T + 1) + 8) * 4; }
+
+size_t segment_scratch_floats(int B, int T, int D) { (void)B; (void)T; (void)D; return 0; }   // everything lives in LDS
 
 int launch_segment(const float* hidden, int B, int T, int D, float norm_thr, float merge_thr, int64_t* seg, int* nseg,
                    float* feat, float* scratch, hipStream_t s) {
+    (void)scratch;
     if (D != SEG_D) { syl_set_error("launch_segment", "feature dim must be 768"); return 1; }
-    if (T < 1 || T > SEG_MAXT) { syl_set_error("launch_segment", "T must be in [1, 4096]"); return 1; }
-    const size_t per = segment_scratch_floats(1, T, D);
-    hipLaunchKernelGGL(segment_kernel, dim3(B), dim3(256), 0, s, hidden, T, norm_thr, merge_thr, seg, nseg, feat, scratch, per);
+    const size_t lds = segment_lds_bytes(T);
+    if (T < 1 || lds > 160 * 1024) { syl_set_error("launch_segment", "T must be in [1, 3940] (160 KiB of LDS per utterance)"); return 1; }
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        HIP_TRY(hipFuncSetAttribute((const void*)segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(segment_kernel, dim3(B), dim3(256), lds, s, hidden, T, norm_thr, merge_thr, seg, nseg, feat);
     HIP_TRY(hipGetLastError());
     return 0;
 }
