@@ -170,10 +170,18 @@ def main():
         gemm_fl = sum(fl.values())
         n_launch = 6 + 1 + 9 * 5
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and B == BATCH_PER_GPU:
+            # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
+            # (FETCH_SIZE x2 + WRITE_SIZE, separate passes; tools/pmc_traffic.py) -- PMC cannot be read live
+            traffic = round(json.load(open(tpath))["gemm_family_bytes_per_launch"])
         roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all %d launches per forward: 6 implicit-GEMM convs, "
                     "projection, 9 x {qk, v, out, ffn1, ffn2})" % n_launch,
                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch, rocprofv3 PMC (profiles/r01_hbm_traffic.md); algorithmic minimum "
+                                    "~160 MB per launch (8.3 GB of operands/outputs over 52 launches)",
                     "avg_launch_ms": round(gemm_ms / n_launch, 4), "flops_per_forward": gemm_fl,
                     "per_launch_tflops": {k: round(fl[k] / (kernels[k] * 1e-3) / 1e12, 1) for k in fl if kernels.get(k)}}
 
@@ -181,6 +189,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd)
 
+    seg_stats = None
+    if rank == 0:
+        h = enc.forward(my_batch, None)
+        _, nseg_t, _ = enc.segment(h, 2.6, 0.8)
+        nn_ = nseg_t.float()
+        seg_stats = {"mean": round(float(nn_.mean()), 1), "min": int(nn_.min()), "max": int(nn_.max())}
     if rank == 0:
         line = {
             "metric": "audio-sec/s encoded (sylber_base, 16 kHz, batched 10 s clips)",
@@ -194,7 +208,7 @@ def main():
                        "parallelism": "utterance-sharded x%d%s" % (world, " + RCCL scatter/gather" if exchange else ""),
                        "gflop_per_clip": 124.65},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_forward": kernels,
-            "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2),
+            "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2), "segments_per_clip": seg_stats,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

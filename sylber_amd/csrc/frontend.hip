@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 #define NSTAT 65  // 10 sums + 55 upper-triangular lag products
+#define C0_ROWS 256  // conv0 output rows per workgroup
 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ wav, int Lmax, int L0, int chunk,
@@ -88,15 +89,24 @@ __global__ __launch_bounds__(512) void conv0_finalize_kernel(const double* __res
     scale_shift[((size_t)b * SYL_CONV + c) * 2 + 1] = (float)((double)gn_b[c] - mean * a);
 }
 
-// grid (ceil(R0/64), B); wave w of a block produces rows l = 64*blockIdx.x + 16*w + i; lane owns 8 channels
+// grid (ceil(R0/256), B); wave w of a block produces rows l = 256*blockIdx.x + 64*w + i; lane owns 8 channels
+// (80 tap weights + scale/shift stay in registers across 64 rows).  The 1285 waveform samples a block needs are staged in LDS once (coalesced), then every row reads its 10
+// taps as LDS broadcasts instead of 10 wave-uniform global loads.
 template <bool OUT_F32, bool ERF>
 __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int Lmax, int L0, int R0,
                                                             const float* __restrict__ w0,
                                                             const float* __restrict__ scale_shift, void* __restrict__ out) {
+    __shared__ float xs[C0_ROWS * 5 + 16];
     const int b = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int c0 = lane * 8;
+    const float* x = wav + (size_t)b * Lmax;
+    const int l_blk = blockIdx.x * C0_ROWS;
+    for (int i = threadIdx.x; i < C0_ROWS * 5 + 5; i += 256) {
+        const int idx = 5 * l_blk + i;
+        xs[i] = idx < Lmax ? x[idx] : 0.f;
+    }
     float w[8][10], sa[8], sb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -105,17 +115,18 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
         sa[i] = scale_shift[((size_t)b * SYL_CONV + c0 + i) * 2 + 0];
         sb[i] = scale_shift[((size_t)b * SYL_CONV + c0 + i) * 2 + 1];
     }
-    const float* x = wav + (size_t)b * Lmax;
-    const int lbase = blockIdx.x * 64 + wave * 16;
+    __syncthreads();
+    const int lbase = l_blk + wave * (C0_ROWS / 4);
 #pragma unroll 2
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < C0_ROWS / 4; ++r) {
         const int l = lbase + r;
         if (l >= R0) break;
         float y[8];
         if (l < L0) {
             float xv[10];
+            const float* xr = xs + 5 * (wave * (C0_ROWS / 4) + r);
 #pragma unroll
-            for (int j = 0; j < 10; ++j) xv[j] = x[5 * l + j];   // wave-uniform address: scalar/broadcast load
+            for (int j = 0; j < 10; ++j) xv[j] = xr[j];          // LDS broadcast
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float v = 0.f;
@@ -156,7 +167,7 @@ int launch_conv0_finalize(const double* partials, int nchunk, const float* w0, c
 }
 int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, const float* w0, const float* scale_shift,
                          void* out, int out_f32, hipStream_t s) {
-    dim3 grid((R0 + 63) / 64, B);
+    dim3 grid((R0 + C0_ROWS - 1) / C0_ROWS, B);
     if (out_f32)
         hipLaunchKernelGGL((conv0_gn_gelu_kernel<true, true>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
     else

@@ -96,3 +96,19 @@ def test_full_size_config_vs_oracle_sample(enc, sd):
     ref = hubert_ref.forward(sd, x[[0, 31]], None)["hidden"].numpy()
     assert rel_rms(out[0], ref[0]) < STAGE_TOL["hidden"]
     assert rel_rms(out[31], ref[1]) < STAGE_TOL["hidden"]
+
+
+def test_long_form_config(enc, sd):
+    """BASELINE configs[3] shape class (60 s clips, T = 2999: O(T^2) attention, 192k-step GroupNorm):
+    runs, finite, and one (shortened to keep the CPU oracle quick) long clip matches the oracle."""
+    x = noise_batch(2, 960000, seed=9)
+    out = enc.forward(x.cuda())
+    assert out.shape == (2, 2999, 768) and bool(torch.isfinite(out).all())
+    seg, nseg, feats = enc.segment(out, 2.6, 0.8)
+    torch.cuda.synchronize()
+    assert int(nseg.min()) >= 0
+    y = syllable_wave(400000, 91)                      # 25 s, T = 1249
+    ref = hubert_ref.forward(sd, y, None)["hidden"].numpy()
+    got = enc.forward(y.cuda().contiguous()).cpu().numpy()
+    assert got.shape == ref.shape
+    assert rel_rms(got, ref) < STAGE_TOL["hidden"]
