@@ -39,6 +39,9 @@ struct sylber_ctx {
     bf16_t* conv_w[7];
     bf16_t *fp_w, *pos_w;
     LayerDev L[SYLBER_MAX_LAYERS];
+    // fp32 parity mode: the same tensors kept in fp32
+    float* conv_w32[7]; float *fp_w32, *pos_w32;
+    struct { float *wqkv, *wo, *w1, *w2; } L32[SYLBER_MAX_LAYERS];
     // workspace
     char* ws = nullptr; size_t ws_bytes = 0;
     int ws_B = 0, ws_Lmax = 0;
@@ -67,7 +70,8 @@ struct Packer {
 extern "C" int sylber_create(const SylberWeights* w, int device, int precision, sylber_t* out) {
     if (!w || !out) { syl_set_error("sylber_create", "null argument"); return 1; }
     if (w->num_layers < 1 || w->num_layers > SYLBER_MAX_LAYERS) { syl_set_error("sylber_create", "num_layers out of range"); return 1; }
-    if (precision != SYLBER_BF16) { syl_set_error("sylber_create", "only SYLBER_BF16 is implemented in this build"); return 1; }
+    if (precision != SYLBER_BF16 && precision != SYLBER_FP32) { syl_set_error("sylber_create", "unknown precision"); return 1; }
+    const bool f32 = precision == SYLBER_FP32;
     HIP_TRY(hipSetDevice(device));
     sylber_ctx* c = new sylber_ctx();
     c->device = device; c->precision = precision; c->num_layers = w->num_layers;
@@ -83,10 +87,10 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
         for (int o = 0; o < 512; ++o)
             for (int cc = 0; cc < 512; ++cc)
                 for (int j = 0; j < k; ++j) tmp[((size_t)o * k + j) * 512 + cc] = w->conv_w[i][((size_t)o * 512 + cc) * k + j];
-        o_conv[i] = P.add_bf16(tmp.data(), tmp.size());
+        o_conv[i] = f32 ? P.add_f32(tmp.data(), tmp.size()) : P.add_bf16(tmp.data(), tmp.size());
     }
     size_t o_fplw = P.add_f32(w->fp_ln_w, 512), o_fplb = P.add_f32(w->fp_ln_b, 512);
-    size_t o_fpw = P.add_bf16(w->fp_w, 768 * 512), o_fpb = P.add_f32(w->fp_b, 768);
+    size_t o_fpw = f32 ? P.add_f32(w->fp_w, 768 * 512) : P.add_bf16(w->fp_w, 768 * 512), o_fpb = P.add_f32(w->fp_b, 768);
     size_t o_posw;
     {
         // [768 = g*48+n][48 c][128 tap] -> [g][tap][64 n][56 c] (zero padded), 112-byte rows
@@ -96,7 +100,17 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
                 for (int cc = 0; cc < 48; ++cc)
                     for (int t = 0; t < 128; ++t)
                         tmp[(((size_t)g * 128 + t) * 64 + n) * 56 + cc] = w->pos_w[(((size_t)g * 48 + n) * 48 + cc) * 128 + t];
-        o_posw = P.add_bf16(tmp.data(), tmp.size());
+        if (!f32) o_posw = P.add_bf16(tmp.data(), tmp.size());
+        else {
+            // fp32 parity kernel wants [g][tap][c][n] (n contiguous)
+            std::vector<float> t32((size_t)16 * 128 * 48 * 48);
+            for (int g = 0; g < 16; ++g)
+                for (int n = 0; n < 48; ++n)
+                    for (int cc = 0; cc < 48; ++cc)
+                        for (int t = 0; t < 128; ++t)
+                            t32[(((size_t)g * 128 + t) * 48 + cc) * 48 + n] = w->pos_w[(((size_t)g * 48 + n) * 48 + cc) * 128 + t];
+            o_posw = P.add_f32(t32.data(), t32.size());
+        }
     }
     size_t o_posb = P.add_f32(w->pos_b, 768);
     size_t o_elw = P.add_f32(w->enc_ln_w, 768), o_elb = P.add_f32(w->enc_ln_b, 768);
@@ -108,11 +122,11 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
         memcpy(qkv.data() + 768 * 768, lw.k_w, 768 * 768 * 4);
         memcpy(qkv.data() + 2 * 768 * 768, lw.v_w, 768 * 768 * 4);
         memcpy(bq.data(), lw.q_b, 768 * 4); memcpy(bq.data() + 768, lw.k_b, 768 * 4); memcpy(bq.data() + 1536, lw.v_b, 768 * 4);
-        lo[l].wqkv = P.add_bf16(qkv.data(), qkv.size()); lo[l].bqkv = P.add_f32(bq.data(), 2304);
-        lo[l].wo = P.add_bf16(lw.o_w, 768 * 768); lo[l].bo = P.add_f32(lw.o_b, 768);
+        lo[l].wqkv = f32 ? P.add_f32(qkv.data(), qkv.size()) : P.add_bf16(qkv.data(), qkv.size()); lo[l].bqkv = P.add_f32(bq.data(), 2304);
+        lo[l].wo = f32 ? P.add_f32(lw.o_w, 768 * 768) : P.add_bf16(lw.o_w, 768 * 768); lo[l].bo = P.add_f32(lw.o_b, 768);
         lo[l].l1w = P.add_f32(lw.ln1_w, 768); lo[l].l1b = P.add_f32(lw.ln1_b, 768);
-        lo[l].w1 = P.add_bf16(lw.ff1_w, (size_t)3072 * 768); lo[l].b1 = P.add_f32(lw.ff1_b, 3072);
-        lo[l].w2 = P.add_bf16(lw.ff2_w, (size_t)768 * 3072); lo[l].b2 = P.add_f32(lw.ff2_b, 768);
+        lo[l].w1 = f32 ? P.add_f32(lw.ff1_w, (size_t)3072 * 768) : P.add_bf16(lw.ff1_w, (size_t)3072 * 768); lo[l].b1 = P.add_f32(lw.ff1_b, 3072);
+        lo[l].w2 = f32 ? P.add_f32(lw.ff2_w, (size_t)768 * 3072) : P.add_bf16(lw.ff2_w, (size_t)768 * 3072); lo[l].b2 = P.add_f32(lw.ff2_b, 768);
         lo[l].l2w = P.add_f32(lw.ln2_w, 768); lo[l].l2b = P.add_f32(lw.ln2_b, 768);
     }
     c->wbytes = P.host.size();
@@ -123,7 +137,8 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
     char* b = c->wbase;
     c->conv0_w = (float*)(b + o_conv0); c->gn_w = (float*)(b + o_gnw); c->gn_b = (float*)(b + o_gnb);
     c->conv_w[0] = nullptr;
-    for (int i = 1; i < 7; ++i) c->conv_w[i] = (bf16_t*)(b + o_conv[i]);
+    for (int i = 1; i < 7; ++i) { c->conv_w[i] = (bf16_t*)(b + o_conv[i]); c->conv_w32[i] = (float*)(b + o_conv[i]); }
+    c->fp_w32 = (float*)(b + o_fpw); c->pos_w32 = (float*)(b + o_posw);
     c->fp_ln_w = (float*)(b + o_fplw); c->fp_ln_b = (float*)(b + o_fplb);
     c->fp_w = (bf16_t*)(b + o_fpw); c->fp_b = (float*)(b + o_fpb);
     c->pos_w = (bf16_t*)(b + o_posw); c->pos_b = (float*)(b + o_posb);
@@ -136,6 +151,8 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
         d.w1 = (bf16_t*)(b + lo[l].w1); d.b1 = (float*)(b + lo[l].b1);
         d.w2 = (bf16_t*)(b + lo[l].w2); d.b2 = (float*)(b + lo[l].b2);
         d.ln2w = (float*)(b + lo[l].l2w); d.ln2b = (float*)(b + lo[l].l2b);
+        c->L32[l].wqkv = (float*)(b + lo[l].wqkv); c->L32[l].wo = (float*)(b + lo[l].wo);
+        c->L32[l].w1 = (float*)(b + lo[l].w1); c->L32[l].w2 = (float*)(b + lo[l].w2);
     }
     *out = c;
     return 0;
@@ -262,9 +279,13 @@ extern "C" int sylber_get_profile(sylber_t c, const char** names, float* ms, int
         if ((call) != 0) return 1;              \
     } while (0)
 
+static int forward_f32(sylber_ctx* c, const float* wav_dev, const int32_t* lengths_host, int B, int Lmax, float* hidden_dev,
+                       hipStream_t s);
+
 extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* lengths_host, int32_t B, int32_t Lmax,
                               float* hidden_dev, void* stream) {
     if (!c || !wav_dev || !hidden_dev) { syl_set_error("sylber_forward", "null argument"); return 1; }
+    if (c->precision == SYLBER_FP32) return forward_f32(c, wav_dev, lengths_host, B, Lmax, hidden_dev, (hipStream_t)stream);
     if (B < 1 || Lmax < 400) { syl_set_error("sylber_forward", "need B >= 1 and at least 400 samples (one frame)"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
@@ -357,6 +378,102 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
         f2.out0 = pre; f2.ld0 = 768; f2.res = hf32; f2.ldres = 768;
         RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RES, f2, s));
+        RUN("layernorm", run_ln(d.ln2w, d.ln2b, last));
+        if (last) break;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 parity mode: same sequence, every tensor fp32, own workspace plan
+static int forward_f32(sylber_ctx* c, const float* wav_dev, const int32_t* lengths_host, int B, int Lmax, float* hidden_dev,
+                       hipStream_t s) {
+    if (B < 1 || Lmax < 400) { syl_set_error("sylber_forward", "need B >= 1 and at least 400 samples (one frame)"); return 1; }
+    HIP_TRY(hipSetDevice(c->device));
+    Plan p;
+    make_plan(B, Lmax, p);
+    const size_t M = (size_t)B * p.Tp;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_a = take(((size_t)B * p.R[0] + 8) * 512 * 4), o_b = take(((size_t)B * p.R[1] + 8) * 512 * 4);
+    const size_t o_ln = take(M * 512 * 4), o_x = take(M * 768 * 4), o_xpad = take((size_t)B * (p.Tp + 128) * 768 * 4);
+    const size_t o_pre = take(M * 768 * 4), o_h = take(M * 768 * 4), o_qkv = take(M * 2304 * 4), o_ctx = take(M * 768 * 4);
+    const size_t o_ffn = take(M * 3072 * 4), o_part = take((size_t)B * p.nchunk * 65 * 8), o_ss = take((size_t)B * 512 * 2 * 4);
+    const size_t o_valid = take((size_t)B * 4);
+    Plan q = p; q.total = off;
+    if (ensure_workspace(c, q, s)) return 1;
+    char* w = c->ws;
+    float* bufA = (float*)(w + o_a); float* bufB = (float*)(w + o_b); float* ln512 = (float*)(w + o_ln);
+    float* xf = (float*)(w + o_x); float* xpad = (float*)(w + o_xpad); float* pre = (float*)(w + o_pre); float* h = (float*)(w + o_h);
+    float* qkv = (float*)(w + o_qkv); float* ctx = (float*)(w + o_ctx); float* ffn = (float*)(w + o_ffn);
+    double* part = (double*)(w + o_part); float* ss = (float*)(w + o_ss); int* valid = (int*)(w + o_valid);
+    {
+        std::vector<int> v(B);
+        for (int i = 0; i < B; ++i) {
+            int n = lengths_host ? lengths_host[i] : Lmax;
+            if (n > Lmax || n < 400) { syl_set_error("sylber_forward", "lengths must be in [400, Lmax]"); return 1; }
+            v[i] = sylber_num_frames(n);
+        }
+        HIP_TRY(hipMemcpyAsync(valid, v.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    RUN("conv0_stats", launch_conv0_stats(wav_dev, B, Lmax, p.L[0], part, p.nchunk, s));
+    RUN("conv0_finalize", launch_conv0_finalize(part, p.nchunk, c->conv0_w, c->gn_w, c->gn_b, B, p.L[0], ss, s));
+    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 1, s));
+    float* src = bufA; float* dst = bufB;
+    for (int i = 1; i < 7; ++i) {
+        GemmArgsF32 a = {};
+        a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w32[i]; a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.act = 1;
+        a.out0 = dst; a.ld0 = 512;
+        RUN("gemm_f32", launch_gemm_f32(a, s));
+        float* t = src; src = dst; dst = t;
+    }
+    float* feats = src;
+    if (c->stop_stage == 1) {
+        for (int b = 0; b < B; ++b)
+            HIP_TRY(hipMemcpyAsync(hidden_dev + (size_t)b * p.T * 512, feats + (size_t)b * p.Tp * 512, (size_t)p.T * 512 * 4,
+                                   hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    {
+        LnArgs a = {};
+        a.in = feats; a.in_bf16 = 0; a.ld_in = 512; a.gamma = c->fp_ln_w; a.beta = c->fp_ln_b; a.out_f32 = ln512; a.ld_f32 = 512;
+        a.M = (int)M; a.D = 512;
+        RUN("ln512", launch_layernorm(a, s));
+        GemmArgsF32 g = {};
+        g.X = ln512; g.ldx = 512; g.W = c->fp_w32; g.M = (int)M; g.N = 768; g.K = 512; g.bias = c->fp_b; g.out0 = xf; g.ld0 = 768;
+        g.Tp = p.Tp; g.T = p.T; g.valid = valid; g.xpad = xpad; g.xpad_rows = p.Tp + 128;
+        RUN("gemm_f32", launch_gemm_f32(g, s));
+    }
+    RUN("posconv_f32", launch_posconv_f32(xpad, c->pos_w32, c->pos_b, xf, pre, B, p.Tp, s));
+    auto run_ln = [&](const float* gam, const float* bet, bool last) -> int {
+        LnArgs a = {};
+        a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = (int)M; a.D = 768;
+        if (last) { a.out_f32 = hidden_dev; a.ld_f32 = 768; a.Tp = p.Tp; a.T = p.T; }
+        else { a.out_f32 = h; a.ld_f32 = 768; }
+        return launch_layernorm(a, s);
+    };
+    RUN("layernorm", run_ln(c->enc_ln_w, c->enc_ln_b, c->stop_stage == 2));
+    if (c->stop_stage == 2) return 0;
+    for (int l = 0; l < c->num_layers; ++l) {
+        const LayerDev& d = c->L[l];
+        const bool last = (l == c->num_layers - 1) || (c->stop_stage == 3 + l);
+        GemmArgsF32 g = {};
+        g.X = h; g.ldx = 768; g.W = c->L32[l].wqkv; g.M = (int)M; g.N = 2304; g.K = 768; g.bias = d.bqkv; g.out0 = qkv; g.ld0 = 2304;
+        RUN("gemm_f32", launch_gemm_f32(g, s));
+        RUN("attention_f32", launch_attention_f32(qkv, qkv + 768, qkv + 1536, valid, ctx, B, p.T, p.Tp, s));
+        GemmArgsF32 o = {};
+        o.X = ctx; o.ldx = 768; o.W = c->L32[l].wo; o.M = (int)M; o.N = 768; o.K = 768; o.bias = d.bo; o.out0 = pre; o.ld0 = 768;
+        o.res = h; o.ldres = 768;
+        RUN("gemm_f32", launch_gemm_f32(o, s));
+        RUN("layernorm", run_ln(d.ln1w, d.ln1b, false));
+        GemmArgsF32 f1 = {};
+        f1.X = h; f1.ldx = 768; f1.W = c->L32[l].w1; f1.M = (int)M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = 1;
+        f1.out0 = ffn; f1.ld0 = 3072;
+        RUN("gemm_f32", launch_gemm_f32(f1, s));
+        GemmArgsF32 f2 = {};
+        f2.X = ffn; f2.ldx = 3072; f2.W = c->L32[l].w2; f2.M = (int)M; f2.N = 768; f2.K = 3072; f2.bias = d.b2; f2.out0 = pre; f2.ld0 = 768;
+        f2.res = h; f2.ldres = 768;
+        RUN("gemm_f32", launch_gemm_f32(f2, s));
         RUN("layernorm", run_ln(d.ln2w, d.ln2b, last));
         if (last) break;
     }

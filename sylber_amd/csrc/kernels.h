@@ -38,9 +38,11 @@ struct GemmArgsF32 {
     const float* X; long ldx;
     const float* W;
     int M, N, K;
-    const float* bias; int act;
+    const float* bias; int act;       // act: 0 none, 1 erf-GELU
     float* out0; long ld0;
     const float* res; long ldres;
+    int Tp, T; const int* valid;      // feature projection: zero frames t >= min(valid[b], T) (Tp > 0 enables row -> (b,t))
+    float* xpad; int xpad_rows;       // optional second copy into the zero-padded pos-conv input
 };
 int launch_gemm_f32(const GemmArgsF32& a, hipStream_t s);
 
