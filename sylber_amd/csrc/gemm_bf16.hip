@@ -506,11 +506,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
                 wf[1][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff1);
             }
         }
-        if (s + 3 < nt && !(abl & 1)) stage(s + 3, (slot + 3) & 3);
         const unsigned long long t1 = now();
         {
-            const int after = nt - 2 - s;            // steps issued after step s+1
-            wait_steps(after >= 2 ? 2 : (after > 0 ? after : 0));
+            // step s+3's DMA is issued in phase B below (between the MFMAs), so at this point the steps
+            // issued after step s+1 are at most {s+2}
+            const int after = nt - 2 - s;
+            wait_steps(after >= 1 ? 1 : 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SCHED_FENCE();
@@ -519,18 +520,30 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
         const unsigned long long t3 = now();
         SCHED_FENCE();
         // ---- B: MFMAs of step s
+        // The LDS-DMA of step s+3 is spread between the MFMAs (one 1-KiB piece per quarter of the MFMAs):
+        // a DMA instruction costs ~70-100 issue cycles because the CU's texture path moves 64 B/clk, and
+        // issued in a burst in phase A it made A the longer phase (measured 623 vs 517 cycles).  Here it
+        // issues under MFMAs that are already executing.  Target slot = slot of step s-1: every wave has
+        // left A(s-1) at least two program barriers ago.
+        const bool dma = (s + 3 < nt) && !(abl & 1);
+        char* dbase = smem + ((slot + 3) & 3) * STAGE;
+        constexpr int NMF = 2 * FM * FN;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < FN; ++fn) {
-                    if constexpr (NATURAL)
-                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[kk][fm], wf[kk][fn], acc[fm][fn], 0, 0, 0);
-                    else
-                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][fn], xf[kk][fm], acc[fm][fn], 0, 0, 0);
-                }
+        for (int i = 0; i < NMF; ++i) {
+            const int kk = i / (FM * FN), fm = (i / FN) % FM, fn = i % FN;
+            if constexpr (NATURAL)
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[kk][fm], wf[kk][fn], acc[fm][fn], 0, 0, 0);
+            else
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][fn], xf[kk][fm], acc[fm][fn], 0, 0, 0);
+            // after MFMA number (q+1)*NMF/NPW_HI - 1 issue piece q
+            if ((i + 1) % (NMF / NPW_HI) == 0) {
+                const int q = (i + 1) / (NMF / NPW_HI) - 1;
+                SCHED_FENCE();
+                if (dma && q < NPW_HI && (q < NPW_LO || hi)) glds16(gp[q] + (s + 3) * 32, dbase + lds_off[q]);
+                SCHED_FENCE();
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         SCHED_FENCE();
         const unsigned long long t4 = now();
