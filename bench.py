@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the RCCL scatter/gather in the step")
+    ap.add_argument("--no-overlap", action="store_true", help="run the segmenter on the forward stream (no pipelining)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,16 +126,44 @@ def main():
     if exchange and rank == 0:
         root_batch = torch.cat([noise_batch(B, CLIP_SAMPLES, seed=1000 + r) for r in range(world)], 0).to(dev)
 
+    # Pipelining across steps: boundary detection of batch i (one workgroup per utterance, 32 of 256 CUs)
+    # runs on a side stream while the conv frontend of batch i+1 already occupies the chip.  Outputs are
+    # double-buffered; every step's work is complete before the closing synchronize of the timed region.
+    T_frames = enc.num_frames(CLIP_SAMPLES)
+    side = torch.cuda.Stream(device=dev)
+    bufs = [(torch.empty(B, T_frames, 768, device=dev),
+             (torch.empty(B, T_frames, 2, dtype=torch.int64, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+              torch.empty(B, T_frames, 768, device=dev))) for _ in range(2)]
+    seg_done = [None, None]
+    state = {"i": 0}
+
     def step():
         if exchange:
             return sharded.step(root_batch, None)
-        hidden = enc.forward(my_batch, None)
-        return (hidden,) + tuple(enc.segment(hidden, 2.6, 0.8))
+        if args.no_overlap:
+            hidden = enc.forward(my_batch, None)
+            return (hidden,) + tuple(enc.segment(hidden, 2.6, 0.8))
+        k = state["i"] & 1
+        state["i"] += 1
+        hidden, seg_out = bufs[k]
+        main = torch.cuda.current_stream(dev)
+        if seg_done[k] is not None:
+            main.wait_event(seg_done[k])          # the segmenter that last read this buffer pair has finished
+        enc.forward(my_batch, None, out=hidden)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            enc.segment(hidden, 2.6, 0.8, out=seg_out)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        seg_done[k] = ev
+        return (hidden,) + seg_out
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)               # device-wide: main and side stream
 
     for _ in range(args.warmup):
         step()
@@ -206,6 +235,7 @@ def main():
                                    "sylber_base weights (BASELINE.json configs[1]%s)" % (B, "; configs[2] sharding" if world > 1 else ""),
                        "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": 499,
                        "parallelism": "utterance-sharded x%d%s" % (world, " + RCCL scatter/gather" if exchange else ""),
+                       "pipelining": "none" if (exchange or args.no_overlap) else "segmenter of batch i on a side stream under the forward of batch i+1",
                        "gflop_per_clip": 124.65},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_forward": kernels,
             "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2), "segments_per_clip": seg_stats,

@@ -145,10 +145,12 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             *(float4*)op = make_float4(y[0], y[1], y[2], y[3]);
             *(float4*)(op + 4) = make_float4(y[4], y[5], y[6], y[7]);
         } else {
-            uint4 pk;
-            pk.x = pack_bf16x2(y[0], y[1]); pk.y = pack_bf16x2(y[2], y[3]);
-            pk.z = pack_bf16x2(y[4], y[5]); pk.w = pack_bf16x2(y[6], y[7]);
-            *(uint4*)((bf16_t*)out + o) = pk;
+            // 1 GiB per 32 clips, consumed exactly once by conv1: stream it past the caches
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t pk;
+            pk[0] = pack_bf16x2(y[0], y[1]); pk[1] = pack_bf16x2(y[2], y[3]);
+            pk[2] = pack_bf16x2(y[4], y[5]); pk[3] = pack_bf16x2(y[6], y[7]);
+            __builtin_nontemporal_store(pk, (u32x4_t*)((bf16_t*)out + o));
         }
     }
 }

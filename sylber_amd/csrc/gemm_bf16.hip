@@ -281,6 +281,33 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
             }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
+    // MFMAs of one k-substep with LDS-DMA pieces [p0, p1) of k-tile `kt` (into ring slot `dslot`) issued
+    // between them.  A DMA instruction costs ~70-100 issue cycles (the CU's texture path moves 64 B/clk and
+    // is shared by every resident wave); issued in one burst after the barrier they were 43 % of the K step.
+    auto mfmas_dma = [&](int buf, int kt, int dslot, int p0, int p1, bool on) {
+        constexpr int NM = FM * FN;
+        char* base = smem + dslot * STAGE;
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int fm = i / FN, fn = i % FN;
+            if constexpr (NATURAL)
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[buf][fm], wf[buf][fn], acc[fm][fn], 0, 0, 0);
+            else
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][fn], xf[buf][fm], acc[fm][fn], 0, 0, 0);
+            // pieces are spread evenly: piece p0 + j goes after MFMA number ceil((j+1)*NM/np) - 1
+#pragma unroll
+            for (int p = 0; p < NPW; ++p) {
+                const int np = p1 - p0;
+                if (p >= p0 && p < p1 && ((p - p0 + 1) * NM + np - 1) / np - 1 == i) {
+                    SCHED_FENCE();
+                    if (on) glds16(gp[p] + kt * BK, base + lds_off[p]);
+                    SCHED_FENCE();
+                }
+            }
+        }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
 
     // ---- NSTAGE-slot ring: tiles t+1 .. t+NSTAGE-1 in flight while tile t is consumed
     const int nt = a.K / BK;
@@ -302,12 +329,18 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
         const char* sb = smem + slot * STAGE;
         const int nslot = slot == NSTAGE - 1 ? 0 : slot + 1;
         const unsigned long long t0 = now();
+        // 2-slot ring: the DMA of tile t+1 (into the slot tile t-1 left at the previous barrier) was started
+        // under the last MFMA group of tile t-1 (pieces [0, D0)) and continues under groups 0 and 1 here
+        constexpr int D0 = (NPW * 2 + 4) / 5, D1 = D0 + (NPW - D0 + 1) / 2;   // e.g. NPW = 10 -> 4 | 3 | 3
+        const bool cont = (NSTAGE == 2) && (t >= 1) && (t + 1 < nt);
 #pragma unroll
         for (int kk = 0; kk < KK - 1; ++kk) {
             SCHED_FENCE();
             read_frags(sb, kk + 1, (kk + 1) & 1);
             SCHED_FENCE();
-            mfmas(kk & 1);
+            if (NSTAGE == 2 && kk == 0) mfmas_dma(0, t + 1, nslot, D0, D1, cont);
+            else if (NSTAGE == 2 && kk == 1) mfmas_dma(1, t + 1, nslot, D1, NPW, cont);
+            else mfmas(kk & 1);
         }
         SCHED_FENCE();
         const unsigned long long t1 = now();
@@ -327,11 +360,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
             t3 = now();
             SCHED_FENCE();
             read_frags(smem + nslot * STAGE, 0, 0);
-            if (t + NSTAGE < nt) stage(t + NSTAGE, slot);
+            if constexpr (NSTAGE != 2) { if (t + NSTAGE < nt) stage(t + NSTAGE, slot); }
             SCHED_FENCE();
             t4 = now();
         }
-        mfmas((KK - 1) & 1);
+        if constexpr (NSTAGE == 2) mfmas_dma((KK - 1) & 1, t + 2, slot, 0, D0, (t + 1 < nt) && (t + 2 < nt));
+        else mfmas((KK - 1) & 1);
         slot = nslot;
         if (timing) {
             const unsigned long long t5 = now();

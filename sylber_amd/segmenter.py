@@ -112,13 +112,15 @@ class HubertEncoderHIP:
     def num_frames(self, n_samples: int) -> int:
         return int(self.lib.sylber_num_frames(int(n_samples)))
 
-    def forward(self, wav: torch.Tensor, lengths: Optional[Sequence[int]] = None, stop_stage: int = 0) -> torch.Tensor:
+    def forward(self, wav: torch.Tensor, lengths: Optional[Sequence[int]] = None, stop_stage: int = 0,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """wav: [B, Lmax] float32 on this device, zero padded.  Returns [B, T, 768] float32 (device)."""
         assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
         B, Lmax = wav.shape
         T = self.num_frames(Lmax)
         width = 512 if stop_stage == 1 else 768
-        out = torch.empty(B, T, width, dtype=torch.float32, device=wav.device)
+        if out is None:
+            out = torch.empty(B, T, width, dtype=torch.float32, device=wav.device)
         larr = None
         if lengths is not None:
             larr = (ctypes.c_int32 * B)(*[int(x) for x in lengths])
@@ -130,13 +132,19 @@ class HubertEncoderHIP:
         _lib.check(st, "sylber_forward")
         return out
 
-    def segment(self, hidden: torch.Tensor, norm_threshold: float, merge_threshold: float, with_features: bool = True):
-        """hidden: [B, T, 768] float32 device.  Returns (segments [B,T,2] int64, nseg [B] int32, feats [B,T,768])."""
+    def segment(self, hidden: torch.Tensor, norm_threshold: float, merge_threshold: float, with_features: bool = True,
+                out=None):
+        """hidden: [B, T, 768] float32 device.  Returns (segments [B,T,2] int64, nseg [B] int32, feats [B,T,768]).
+        Runs on the CURRENT torch stream; it touches no encoder workspace, so a caller may run it on a side
+        stream concurrently with the next batch's forward (32 workgroups vs a 256-CU chip)."""
         assert hidden.is_cuda and hidden.dtype == torch.float32 and hidden.is_contiguous()
         B, T, D = hidden.shape
-        seg = torch.empty(B, T, 2, dtype=torch.int64, device=hidden.device)
-        nseg = torch.empty(B, dtype=torch.int32, device=hidden.device)
-        feats = torch.empty(B, T, D, dtype=torch.float32, device=hidden.device) if with_features else None
+        if out is not None:
+            seg, nseg, feats = out
+        else:
+            seg = torch.empty(B, T, 2, dtype=torch.int64, device=hidden.device)
+            nseg = torch.empty(B, dtype=torch.int32, device=hidden.device)
+            feats = torch.empty(B, T, D, dtype=torch.float32, device=hidden.device) if with_features else None
         with torch.cuda.device(hidden.device):
             st = self.lib.sylber_segment(self.handle, ctypes.c_void_p(hidden.data_ptr()), B, T, D,
                                          ctypes.c_float(float(np.float32(norm_threshold))),
