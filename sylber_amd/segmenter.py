@@ -221,7 +221,7 @@ class Segmenter:
         hidden states [B,T,768] (full padded T, like the reference) and the per-row lengths."""
         rows, lengths = [], []
         for w in batch_wavs:
-            if w.dim() != 2:
+            if not torch.is_tensor(w) or w.dim() != 2:
                 raise ValueError("each wav must be a [channels, N] tensor (sylber.py:96 reads wav.shape[1])")
             for ch in range(w.shape[0]):              # torch.cat(dim=0) makes every channel a batch row
                 rows.append(w[ch])

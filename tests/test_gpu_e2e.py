@@ -104,3 +104,38 @@ def test_silence_only_gives_empty_arrays(sd):
     out = S2(wav=syllable_wave(16000, 1))
     assert out["segments"].shape == (0,) and out["segment_features"].shape == (0,)
     assert out["hidden_states"].shape == (49, 768)
+
+
+def test_edge_shapes_and_errors(S, sd):
+    """shortest possible clip (one frame), odd lengths, batch of one, and the error behaviour of the ABI"""
+    from sylber_amd import _lib
+    ref = SegmenterRef(sd)
+    for n in (400, 401, 719, 720, 1000, 16001):
+        x = syllable_wave(max(n, 800), 300 + n)[:, :n].contiguous()
+        a = S(wav=x, in_second=False)
+        b = ref(x, in_second=False)
+        assert a["hidden_states"].shape == b["hidden_states"].shape, n
+        assert rel_rms(a["hidden_states"], b["hidden_states"]) < 3e-2, n
+        _segments_consistent(a, S)
+    # ragged list with a one-frame utterance next to a long one
+    wl = [syllable_wave(800, 1)[:, :400].contiguous(), syllable_wave(24000, 2)]
+    outs = S(wav=wl, in_second=True)
+    assert outs[0]["hidden_states"].shape == outs[1]["hidden_states"].shape
+    for o in outs:
+        _check_contract(o, True)
+    # too short for a single frame: the reference would fail inside the conv stack; we raise
+    with pytest.raises(_lib.SylberHipError):
+        S(wav=torch.zeros(1, 399))
+    with pytest.raises(ValueError):
+        S(wav=torch.zeros(16000))          # sylber.py:96 reads wav.shape[1]
+
+
+def test_stereo_file_rows(S, tmp_path):
+    """torch.cat(dim=0) at sylber.py:117 turns every channel of a multi-channel file into a batch row"""
+    import wave
+    pcm = (np.sin(np.arange(32000) * 0.05) * 8000).astype(np.int16).reshape(-1, 2)
+    p = str(tmp_path / "st.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    outs = S([p], in_second=False)
+    assert isinstance(outs, list) and len(outs) == 2
