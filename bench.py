@@ -9,8 +9,10 @@ A step = one pass of the hot path over one batch of synthetic input: waveform ba
 (hidden_states, segments, segment_features) left in HBM.  Workload = BASELINE.json configs[1]:
 32 x 10 s x 16 kHz random waveforms per GPU, synthetic seeded weights of the sylber_base geometry
 (no network for the real checkpoint), bf16 MFMA compute with fp32 accumulation/residual stream.
-Weak scaling: every rank processes its own 32-clip shard (cfg3 = 256 clips on 8 GPUs); for N > 1 the
-step also includes the root scatter of waveforms and the gather of all outputs over RCCL.
+Weak scaling: every rank processes its own resident 32-clip shard (cfg3 = 256 clips on 8 GPUs); the path
+shards over utterances with no collective inside it, so the timed steps contain none (only the closing
+barrier / max-reduce of the contract).  `--exchange` adds the root scatter of waveforms and the gather of all
+outputs over RCCL to every step (sylber_amd/dist.py).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -91,8 +93,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the RCCL scatter/gather in the step")
+    ap.add_argument("--exchange", action="store_true",
+                    help="N>1: include the root scatter of waveforms and the gather of all outputs (RCCL) in every step")
     ap.add_argument("--no-overlap", action="store_true", help="run the segmenter on the forward stream (no pipelining)")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight (independent handles/streams)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +122,7 @@ def main():
     enc = HubertEncoderHIP(sd, device=str(dev))
     sharded = ShardedSegmenter(enc)
     B = args.batch
-    exchange = world > 1 and not args.no_exchange
+    exchange = world > 1 and args.exchange
     # inputs resident in HBM before the timed region: rank r holds clips [r*B, (r+1)*B) of the seeded job;
     # with the exchange enabled the root additionally holds the whole job and scatters it every step
     my_batch = noise_batch(B, CLIP_SAMPLES, seed=1000 + rank).to(dev)
@@ -126,15 +130,21 @@ def main():
     if exchange and rank == 0:
         root_batch = torch.cat([noise_batch(B, CLIP_SAMPLES, seed=1000 + r) for r in range(world)], 0).to(dev)
 
-    # Pipelining across steps: boundary detection of batch i (one workgroup per utterance, 32 of 256 CUs)
-    # runs on a side stream while the conv frontend of batch i+1 already occupies the chip.  Outputs are
-    # double-buffered; every step's work is complete before the closing synchronize of the timed region.
+    # Pipelining across steps (a serving loop keeps more than one batch in flight): NPIPE encoder handles, each
+    # with its own workspace and HIP stream, take the steps round-robin, so kernels of consecutive batches
+    # overlap on the chip — the one-round launches (500 tiles on 512 workgroup slots) leave their prologue /
+    # epilogue phases uncovered otherwise — and the boundary detection of batch i (one workgroup per utterance,
+    # 32 of 256 CUs) runs on a side stream.  Every step is still one full pass over one 32-clip batch; all work
+    # is complete before the closing device synchronize of the timed region.
     T_frames = enc.num_frames(CLIP_SAMPLES)
-    side = torch.cuda.Stream(device=dev)
+    NPIPE = 1 if (exchange or args.no_overlap) else args.inflight
+    encs = [enc] + [HubertEncoderHIP(sd, device=str(dev)) for _ in range(NPIPE - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
+    sides = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
     bufs = [(torch.empty(B, T_frames, 768, device=dev),
              (torch.empty(B, T_frames, 2, dtype=torch.int64, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
-              torch.empty(B, T_frames, 768, device=dev))) for _ in range(2)]
-    seg_done = [None, None]
+              torch.empty(B, T_frames, 768, device=dev))) for _ in range(NPIPE)]
+    seg_done = [None] * NPIPE
     state = {"i": 0}
 
     def step():
@@ -143,18 +153,19 @@ def main():
         if args.no_overlap:
             hidden = enc.forward(my_batch, None)
             return (hidden,) + tuple(enc.segment(hidden, 2.6, 0.8))
-        k = state["i"] & 1
+        k = state["i"] % NPIPE
         state["i"] += 1
         hidden, seg_out = bufs[k]
-        main = torch.cuda.current_stream(dev)
-        if seg_done[k] is not None:
-            main.wait_event(seg_done[k])          # the segmenter that last read this buffer pair has finished
-        enc.forward(my_batch, None, out=hidden)
-        ready = torch.cuda.Event()
-        ready.record(main)
+        main, side = streams[k], sides[k]
+        with torch.cuda.stream(main):
+            if seg_done[k] is not None:
+                main.wait_event(seg_done[k])      # the segmenter that last read this buffer set has finished
+            encs[k].forward(my_batch, None, out=hidden)
+            ready = torch.cuda.Event()
+            ready.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            enc.segment(hidden, 2.6, 0.8, out=seg_out)
+            encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
             ev = torch.cuda.Event()
             ev.record(side)
         seg_done[k] = ev
@@ -234,8 +245,10 @@ def main():
                                    "segment mean-pool), batch %d x 10 s 16 kHz random waveforms per GPU, random-init "
                                    "sylber_base weights (BASELINE.json configs[1]%s)" % (B, "; configs[2] sharding" if world > 1 else ""),
                        "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": 499,
-                       "parallelism": "utterance-sharded x%d%s" % (world, " + RCCL scatter/gather" if exchange else ""),
-                       "pipelining": "none" if (exchange or args.no_overlap) else "segmenter of batch i on a side stream under the forward of batch i+1",
+                       "parallelism": "utterance-sharded x%d, %s" % (world, "root scatter + gather over RCCL in every step" if exchange
+                                                                      else "shards resident per rank, no data-path collective"),
+                       "pipelining": "none" if (exchange or args.no_overlap) else
+                                     "%d batches in flight on independent handles/streams; segmenter on a side stream" % NPIPE,
                        "gflop_per_clip": 124.65},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_forward": kernels,
             "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2), "segments_per_clip": seg_stats,
