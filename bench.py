@@ -33,12 +33,16 @@ BATCH_PER_GPU = 32
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
-def gemm_flops_per_forward(B: int) -> dict:
+def gemm_flops_per_forward(B: int, n_samples: int = CLIP_SAMPLES) -> dict:
     """Algorithmic FLOPs (2*MAC) of the launches of the bf16 MFMA GEMM kernel family
-    in one forward over B 10 s clips, keyed by the launch names api.hip uses."""
-    L = [31999, 15999, 7999, 3999, 1999, 999, 499]
+    in one forward over B clips of n_samples, keyed by the launch names api.hip uses."""
     K = [10, 3, 3, 3, 3, 2, 2]
-    T = 499
+    S = [5, 2, 2, 2, 2, 2, 2]
+    L, n = [], n_samples
+    for k, st in zip(K, S):
+        n = (n - k) // st + 1
+        L.append(n)
+    T = L[-1]
     f = {}
     for i in range(1, 7):
         f[f"gemm_conv{i}"] = 2.0 * L[i] * 512 * 512 * K[i] * B
@@ -97,6 +101,8 @@ def main():
                     help="N>1: include the root scatter of waveforms and the gather of all outputs (RCCL) in every step")
     ap.add_argument("--no-overlap", action="store_true", help="run the segmenter on the forward stream (no pipelining)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight (independent handles/streams)")
+    ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS,
+                    help="clip length; 10 = BASELINE configs[1] (default), 60 with --batch 8 = configs[3] (long-form)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +124,8 @@ def main():
     from sylber_amd.synth import noise_batch
     from sylber_amd.weights import synthetic_state_dict
 
+    clip_seconds = args.clip_seconds
+    clip_samples = int(round(clip_seconds * 16000))
     sd = synthetic_state_dict(0)
     enc = HubertEncoderHIP(sd, device=str(dev))
     sharded = ShardedSegmenter(enc)
@@ -125,10 +133,10 @@ def main():
     exchange = world > 1 and args.exchange
     # inputs resident in HBM before the timed region: rank r holds clips [r*B, (r+1)*B) of the seeded job;
     # with the exchange enabled the root additionally holds the whole job and scatters it every step
-    my_batch = noise_batch(B, CLIP_SAMPLES, seed=1000 + rank).to(dev)
+    my_batch = noise_batch(B, clip_samples, seed=1000 + rank).to(dev)
     root_batch = None
     if exchange and rank == 0:
-        root_batch = torch.cat([noise_batch(B, CLIP_SAMPLES, seed=1000 + r) for r in range(world)], 0).to(dev)
+        root_batch = torch.cat([noise_batch(B, clip_samples, seed=1000 + r) for r in range(world)], 0).to(dev)
 
     # Pipelining across steps (a serving loop keeps more than one batch in flight): NPIPE encoder handles, each
     # with its own workspace and HIP stream, take the steps round-robin, so kernels of consecutive batches
@@ -136,7 +144,7 @@ def main():
     # epilogue phases uncovered otherwise — and the boundary detection of batch i (one workgroup per utterance,
     # 32 of 256 CUs) runs on a side stream.  Every step is still one full pass over one 32-clip batch; all work
     # is complete before the closing device synchronize of the timed region.
-    T_frames = enc.num_frames(CLIP_SAMPLES)
+    T_frames = enc.num_frames(clip_samples)
     NPIPE = 1 if (exchange or args.no_overlap) else args.inflight
     encs = [enc] + [HubertEncoderHIP(sd, device=str(dev)) for _ in range(NPIPE - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
@@ -172,9 +180,10 @@ def main():
         return (hidden,) + seg_out
 
     def barrier():
+        torch.cuda.synchronize(dev)               # device-wide: every stream of this rank has drained
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)               # device-wide: main and side stream
+            torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
         step()
@@ -188,7 +197,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_audio = world * B * CLIP_SECONDS * args.steps
+    total_audio = world * B * clip_seconds * args.steps
     value = total_audio / elapsed
 
     # ---- per-kernel device time with HIP events on the launch stream (separate pass: event records
@@ -205,14 +214,14 @@ def main():
         prof = enc.get_profile()
         enc.set_profiling(False)
         kernels = {k: round(v / nprof, 4) for k, v in prof.items()}      # ms per forward
-        fl = gemm_flops_per_forward(B)
+        fl = gemm_flops_per_forward(B, clip_samples)
         gemm_ms = sum(kernels.get(k, 0.0) for k in fl)
         gemm_fl = sum(fl.values())
         n_launch = 6 + 1 + 9 * 5
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath) and B == BATCH_PER_GPU:
+        if os.path.exists(tpath) and B == BATCH_PER_GPU and clip_samples == CLIP_SAMPLES:
             # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
             # (FETCH_SIZE x2 + WRITE_SIZE, separate passes; tools/pmc_traffic.py) -- PMC cannot be read live
             traffic = round(json.load(open(tpath))["gemm_family_bytes_per_launch"])
@@ -242,14 +251,14 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Segmenter forward (conv frontend + HuBERT-9L encoder + boundary detection + "
-                                   "segment mean-pool), batch %d x 10 s 16 kHz random waveforms per GPU, random-init "
-                                   "sylber_base weights (BASELINE.json configs[1]%s)" % (B, "; configs[2] sharding" if world > 1 else ""),
-                       "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": 499,
+                                   "segment mean-pool), batch %d x %g s 16 kHz random waveforms per GPU, random-init "
+                                   "sylber_base weights (BASELINE.json configs[1]%s)" % (B, clip_seconds, "; configs[2] sharding" if world > 1 else ""),
+                       "global_batch": world * B, "clip_seconds": clip_seconds, "frames_per_clip": T_frames,
                        "parallelism": "utterance-sharded x%d, %s" % (world, "root scatter + gather over RCCL in every step" if exchange
                                                                       else "shards resident per rank, no data-path collective"),
                        "pipelining": "none" if (exchange or args.no_overlap) else
                                      "%d batches in flight on independent handles/streams; segmenter on a side stream" % NPIPE,
-                       "gflop_per_clip": 124.65},
+                       "gflop_per_clip": 124.65 if clip_samples == CLIP_SAMPLES else None},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_forward": kernels,
             "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2), "segments_per_clip": seg_stats,
         }
