@@ -234,6 +234,31 @@ class Segmenter:
         hidden = self.speech_model.forward(batch, lengths)
         return hidden, lengths
 
+    def segment(self, input_values=None, features=None, attention_mask=None, mergethreshold=None, normthreshold=None,
+                **kwargs):
+        """Tensor-native sibling of ``__call__`` with the signature of the reference's ``Sylber.segment``
+        (sylber/model/sylber.py:208-247): a padded ``[B, N]`` waveform batch (+ 0/1 ``attention_mask``) or
+        precomputed ``features [B, T, 768]`` in, ``(features, segments, avg_fts)`` out — ``segments`` a list of
+        int64 ``[n, 2]`` arrays, ``avg_fts`` the segment means zero-padded to ``[B, max(n, 1), 768]`` on the
+        device (an utterance without segments contributes one zero row, sylber.py:238-241)."""
+        dev = self.speech_model.device
+        if features is None:
+            x = input_values.to(dev, torch.float32).contiguous()
+            lengths = None if attention_mask is None else [int(v) for v in attention_mask.sum(-1).tolist()]
+            features = self.speech_model.forward(x, lengths)
+        else:
+            features = features.to(dev, torch.float32).contiguous()
+        nt = self.norm_threshold if normthreshold is None else normthreshold
+        mt = self.merge_threshold if mergethreshold is None else mergethreshold
+        seg, nseg, feats = self.speech_model.segment(features, nt, mt)
+        nseg_h = nseg.cpu().numpy()
+        nmax = max(int(nseg_h.max()), 1)
+        seg_h = seg[:, :nmax].cpu().numpy()
+        segments = [seg_h[i, : int(nseg_h[i])].copy() if nseg_h[i] > 0 else np.array([]) for i in range(len(nseg_h))]
+        keep = torch.arange(nmax, device=dev)[None, :] < nseg[:, None]
+        avg_fts = torch.where(keep[:, :, None], feats[:, :nmax], torch.zeros((), device=dev))
+        return features, segments, avg_fts
+
     def __call__(self, wav_file=None, wav=None, in_second=True):
         batch_wavs, is_batch = self._collect(wav_file, wav)
         hidden, _ = self.encode_batch(batch_wavs)

@@ -139,3 +139,26 @@ def test_stereo_file_rows(S, tmp_path):
         w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
     outs = S([p], in_second=False)
     assert isinstance(outs, list) and len(outs) == 2
+
+
+def test_tensor_native_segment_api(S, sd):
+    """`segment(input_values, attention_mask)` mirrors the reference's Sylber.segment (sylber.py:208-247)"""
+    lens = [24000, 16000, 20000]
+    wavs = [syllable_wave(n, 700 + i) for i, n in enumerate(lens)]
+    batch = torch.zeros(3, max(lens))
+    mask = torch.zeros(3, max(lens), dtype=torch.long)
+    for i, w in enumerate(wavs):
+        batch[i, : lens[i]] = w[0]
+        mask[i, : lens[i]] = 1
+    feats, segments, avg_fts = S.segment(input_values=batch, attention_mask=mask)
+    ref = S(wav=wavs, in_second=False)
+    assert feats.shape == (3, 74, 768) and avg_fts.shape[0] == 3 and avg_fts.shape[2] == 768
+    for i, r in enumerate(ref):
+        assert np.array_equal(feats[i].cpu().numpy(), r["hidden_states"])
+        assert np.array_equal(segments[i], r["segments"])
+        n = len(r["segments"])
+        assert np.array_equal(avg_fts[i, :n].cpu().numpy(), r["segment_features"])
+        assert float(avg_fts[i, n:].abs().sum()) == 0.0
+    # precomputed features + explicit thresholds; a threshold nobody reaches gives the single zero row
+    f2, seg2, avg2 = S.segment(features=feats, normthreshold=1e9, mergethreshold=0.5)
+    assert all(s.shape == (0,) for s in seg2) and avg2.shape == (3, 1, 768) and float(avg2.abs().sum()) == 0.0
