@@ -555,7 +555,10 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
 
 
 // ------------------------------------------------------------------------------------------------
-extern "C" void sylber_debug_force_gemm_cfg(int32_t cfg) { gemm_force_cfg(cfg); }
+extern "C" void sylber_debug_force_gemm_cfg(int32_t cfg) {
+    // cfg >= 0: GEMM tile configuration; -1: automatic; -101 / -102: attention with 32 / 64 queries per wave; -100: automatic
+    if (cfg <= -100) attention_force_qw(-cfg - 100); else gemm_force_cfg(cfg);
+}
 
 // GEMM micro-benchmark (development aid): times `iters` launches of the bf16 GEMM on pseudo-random
 // operands with HIP events.  cfg: -1 auto, 0 = 256x128, 1 = 128x192, 2 = 128x128 tiles.

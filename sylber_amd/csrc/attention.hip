@@ -27,13 +27,17 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((glb_vptr)g, (lds_vptr)l, 16, 0, 0);
 }
 
+// QW = 32-query sub-tiles per wave.  QW = 2 halves the LDS fragment reads and the LDS-DMA instructions per
+// MFMA (every K / V^T fragment feeds two MFMAs); the DMA issue is the most expensive instruction of the loop
+// (profiles/r01_mfma_ceiling.md).
+template <int QW>
 __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                 const bf16_t* __restrict__ Vt, const int* __restrict__ valid,
                                                                 bf16_t* __restrict__ ctx, int T, int Tp, int Tpv) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * AT_QBLK + wave * 32;
+    const int q0 = blockIdx.x * (128 * QW) + wave * (32 * QW);
     const int ql = lane & 31, h = lane >> 5;
     int nvalid = valid ? valid[b] : T;
     nvalid = nvalid < T ? nvalid : T;
@@ -43,11 +47,12 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
     const bf16_t* Vb = Vt + bh * 64 * Tpv;
 
     // Q fragments (B operand): lane (q, h) holds d = 16 ks + 8 h .. +8
-    bf16x8_t qf[4];
-    {
-        int qr = q0 + ql; qr = qr < Tp ? qr : Tp - 1;
+    bf16x8_t qf[QW][4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(Qb + (size_t)qr * 64 + ks * 16 + h * 8);
+    for (int qs = 0; qs < QW; ++qs) {
+        int qr = q0 + 32 * qs + ql; qr = qr < Tp ? qr : Tp - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[qs][ks] = *(const bf16x8_t*)(Qb + (size_t)qr * 64 + ks * 16 + h * 8);
     }
     // staging: wave w fills rows [16w, 16w+16) of the K tile and of the V^T tile, 8 rows per instruction
     const int srow = lane >> 3, spos = lane & 7;
@@ -67,12 +72,16 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
     const int swz = (lane >> 1) & 7;
     const int frow = ql * 128;
 
-    f32x16_t oacc[2];
+    f32x16_t oacc[QW][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int qs = 0; qs < QW; ++qs)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qs][i][r] = 0.f;
+    float m_run[QW], l_run[QW];
+#pragma unroll
+    for (int qs = 0; qs < QW; ++qs) { m_run[qs] = -INFINITY; l_run[qs] = 0.f; }
     const float LOG2E = 1.44269504088896341f;
 
     const int nt = (nvalid + AT_KV - 1) / AT_KV;
@@ -85,6 +94,9 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
         }
     }
     for (int t = 0; t < nt; ++t) {
+        // LDS-DMA completion is NOT covered by __syncthreads(): retire this wave's pieces of tile t explicitly,
+        // then meet the other waves (their pieces are retired the same way) before any fragment read.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) {
             char* kb = smem + ((t + 1) & 1) * 2 * AT_TILE;
@@ -100,85 +112,109 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
         const char* vb = kb + AT_TILE;
         const int kv0 = t * AT_KV;
 
-        // ---- S^T = K . Q^T  (two 32-key sub-tiles)
-        f32x16_t sacc[2];
+        // ---- S^T = K . Q^T  (two 32-key sub-tiles x QW query sub-tiles; each K fragment feeds QW MFMAs)
+        f32x16_t sacc[QW][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int qs = 0; qs < QW; ++qs)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[s][r] = 0.f;
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[qs][s2][r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(kb + s * 32 * 128 + frow + (((2 * ks + h) ^ swz) << 4));
-                sacc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[s], 0, 0, 0);
+                const bf16x8_t kf = *(const bf16x8_t*)(kb + s2 * 32 * 128 + frow + (((2 * ks + h) ^ swz) << 4));
+#pragma unroll
+                for (int qs = 0; qs < QW; ++qs)
+                    sacc[qs][s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qs][ks], sacc[qs][s2], 0, 0, 0);
             }
-        }
         // ---- mask + online softmax (lane-local; partner lane^32 holds the other 32 keys of this query)
-        float mx = -INFINITY;
         const bool tail = kv0 + AT_KV > nvalid;
+        bf16x8_t pf[QW][4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int qs = 0; qs < QW; ++qs) {
+            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (tail) {
-                    const int key = kv0 + 32 * s + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= nvalid) sacc[s][r] = -INFINITY;
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (tail) {
+                        const int key = kv0 + 32 * s2 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (key >= nvalid) sacc[qs][s2][r] = -INFINITY;
+                    }
+                    mx = fmaxf(mx, sacc[qs][s2][r]);
                 }
-                mx = fmaxf(mx, sacc[s][r]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);           // finite: key 0 is always valid
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-        const float mb = m_new * LOG2E;
-        float psum = 0.f;
-        bf16x8_t pf[4];
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qs], mx);           // finite: key 0 is always valid
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * LOG2E);
+            const float mb = m_new * LOG2E;
+            float psum = 0.f;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[s][8 * j + e], LOG2E, -mb));
-                    psum += p;
-                    pf[2 * s + j][e] = (__bf16)p;
-                }
-        l_run = fmaf(l_run, alpha, psum);
-        m_run = m_new;
+                    for (int e = 0; e < 8; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qs][s2][8 * j + e], LOG2E, -mb));
+                        psum += p;
+                        pf[qs][2 * s2 + j][e] = (__bf16)p;
+                    }
+            l_run[qs] = fmaf(l_run[qs], alpha, psum);
+            m_run[qs] = m_new;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-        // ---- O^T += V^T . P^T  (four 16-key groups x two 32-wide d blocks)
+                for (int r = 0; r < 16; ++r) oacc[qs][i][r] *= alpha;
+        }
+        // ---- O^T += V^T . P^T  (four 16-key groups x two 32-wide d blocks; each V^T fragment feeds QW MFMAs)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds) {
                 const bf16x8_t vf = *(const bf16x8_t*)(vb + ds * 32 * 128 + frow + (((2 * u + h) ^ swz) << 4));
-                oacc[ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u], oacc[ds], 0, 0, 0);
+#pragma unroll
+                for (int qs = 0; qs < QW; ++qs)
+                    oacc[qs][ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qs][u], oacc[qs][ds], 0, 0, 0);
             }
     }
     // ---- finalize: 1/l, store ctx[b*Tp + q][head*64 + d]
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + ql;
-    if (q < T) {
-        bf16_t* dst = ctx + ((size_t)b * Tp + q) * SYL_HIDDEN + head * 64;
 #pragma unroll
-        for (int ds = 0; ds < 2; ++ds)
+    for (int qs = 0; qs < QW; ++qs) {
+        const float l_tot = l_run[qs] + __shfl_xor(l_run[qs], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + 32 * qs + ql;
+        if (q < T) {
+            bf16_t* dst = ctx + ((size_t)b * Tp + q) * SYL_HIDDEN + head * 64;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack_bf16x2(oacc[ds][4 * g + 0] * inv, oacc[ds][4 * g + 1] * inv);
-                pk.y = pack_bf16x2(oacc[ds][4 * g + 2] * inv, oacc[ds][4 * g + 3] * inv);
-                *(uint2*)(dst + 32 * ds + 8 * g + 4 * h) = pk;
-            }
+            for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(oacc[qs][ds][4 * g + 0] * inv, oacc[qs][ds][4 * g + 1] * inv);
+                    pk.y = pack_bf16x2(oacc[qs][ds][4 * g + 2] * inv, oacc[qs][ds][4 * g + 3] * inv);
+                    *(uint2*)(dst + 32 * ds + 8 * g + 4 * h) = pk;
+                }
+        }
     }
 }
+
+static int g_attn_qw = 0;
+void attention_force_qw(int qw) { g_attn_qw = qw; }
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T, int Tp,
                      int Tpv, hipStream_t s) {
     if (Tpv % 64 != 0 || Tpv < T) { syl_set_error("launch_attention", "Tpv must be a multiple of 64 and >= T"); return 1; }
-    dim3 grid((T + AT_QBLK - 1) / AT_QBLK, SYL_HEADS, B);
-    hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), AT_LDS, s, q, k, vt, valid, ctx, T, Tp, Tpv);
+    // 64 queries per wave when there are enough query blocks to fill the chip, else 32
+    int qw = ((long)((T + 255) / 256) * SYL_HEADS * B >= 512) ? 2 : 1;
+    if (g_attn_qw) qw = g_attn_qw;
+    if (qw == 2) {
+        dim3 grid((T + 255) / 256, SYL_HEADS, B);
+        hipLaunchKernelGGL(attention_bf16_kernel<2>, grid, dim3(256), AT_LDS, s, q, k, vt, valid, ctx, T, Tp, Tpv);
+    } else {
+        dim3 grid((T + 127) / 128, SYL_HEADS, B);
+        hipLaunchKernelGGL(attention_bf16_kernel<1>, grid, dim3(256), AT_LDS, s, q, k, vt, valid, ctx, T, Tp, Tpv);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

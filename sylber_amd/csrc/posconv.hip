@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
     const int nsteps = SYL_POSK / PC_TAPS_PER_STEP;
     stage(0, 0);
     for (int st = 0; st < nsteps; ++st) {
-        __syncthreads();      // step st landed (vmcnt(0) before the barrier; also covers the x window stores)
+        // LDS-DMA completion is NOT covered by __syncthreads(): retire this wave's pieces of step st explicitly
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();      // step st visible; also covers the x window stores
         if (st + 1 < nsteps) stage(st + 1, (st + 1) & 1);
         const char* wb = wring + (st & 1) * PC_STEP;
 #pragma unroll

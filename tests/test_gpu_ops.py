@@ -58,9 +58,12 @@ def test_layernorm(lib, D):
     assert (y.cpu() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("B,T,valid", [(2, 64, None), (3, 143, [143, 100, 1]), (2, 499, [499, 300]), (1, 700, None)])
-def test_attention(lib, B, T, valid):
+@pytest.mark.parametrize("qw", [1, 2])
+@pytest.mark.parametrize("B,T,valid", [(2, 64, None), (3, 143, [143, 100, 1]), (2, 499, [499, 300]), (1, 700, None),
+                                       (6, 499, None)])
+def test_attention(lib, B, T, valid, qw):
     from sylber_amd import _lib
+    lib.sylber_debug_force_gemm_cfg(-100 - qw)      # 32 / 64 queries per wave
     g = torch.Generator().manual_seed(B * 1000 + T)
     q = torch.randn(B, T, 768, generator=g)
     k = torch.randn(B, T, 768, generator=g)
@@ -70,7 +73,10 @@ def test_attention(lib, B, T, valid):
     vd = torch.tensor(valid, dtype=torch.int32).cuda() if valid else None
     o = torch.full((B, T, 768), float("nan"), device="cuda")
     qd, kd, vdev = q.cuda(), k.cuda(), v.cuda()
-    _lib.check(lib.sylber_op_attention(_p(qd), _p(kd), _p(vdev), _p(vd), _p(o), B, T, 0, None), "op_attention")
+    try:
+        _lib.check(lib.sylber_op_attention(_p(qd), _p(kd), _p(vdev), _p(vd), _p(o), B, T, 0, None), "op_attention")
+    finally:
+        lib.sylber_debug_force_gemm_cfg(-100)
     qh = _bf(q * 0.125).view(B, T, 12, 64).transpose(1, 2)
     kh = _bf(k).view(B, T, 12, 64).transpose(1, 2)
     vh = _bf(v).view(B, T, 12, 64).transpose(1, 2)
@@ -103,3 +109,29 @@ def test_linear_every_tile_config(lib, cfg):
             lib.sylber_debug_force_gemm_cfg(-1)
         ref = torch.nn.functional.gelu(_bf(a) @ _bf(w).T + b)
         assert (c.cpu() - ref).abs().max().item() < 2e-3, (cfg, M, N, K)
+
+
+def test_attention_full_batch_no_race(lib):
+    """32 x 499 (1536 workgroups): the whole tensor against torch and bitwise run-to-run reproducibility.
+    (Catches LDS-DMA hand-off races that small grids do not expose.)"""
+    from sylber_amd import _lib
+    B, T = 32, 499
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, T, 768, generator=g); k = torch.randn(B, T, 768, generator=g); v = torch.randn(B, T, 768, generator=g)
+    qd, kd, vdev = q.cuda(), k.cuda(), v.cuda()
+    qh = _bf(q * 0.125).view(B, T, 12, 64).transpose(1, 2)
+    kh = _bf(k).view(B, T, 12, 64).transpose(1, 2)
+    vh = _bf(v).view(B, T, 12, 64).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).transpose(1, 2).reshape(B, T, 768)
+    for qw in (1, 2):
+        outs = []
+        lib.sylber_debug_force_gemm_cfg(-100 - qw)
+        try:
+            for _ in range(3):
+                o = torch.full((B, T, 768), float("nan"), device="cuda")
+                _lib.check(lib.sylber_op_attention(_p(qd), _p(kd), _p(vdev), None, _p(o), B, T, 0, None), "op_attention")
+                outs.append(o.cpu())
+        finally:
+            lib.sylber_debug_force_gemm_cfg(-100)
+        assert (outs[0] - ref).abs().max().item() < 3e-2, qw
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), qw
