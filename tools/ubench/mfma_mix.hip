@@ -27,6 +27,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const unsigned short* sr
     // L2-resident source: all workgroups sweep the same 2 MiB (like the shared W panel / neighbouring X tiles of a GEMM)
     const unsigned short* g = src + (size_t)((blockIdx.x & 7) * 8 + wave) * 16384 + lane * 8;
     char* dma = smem + 65536 + wave * 2048;
+    uint4 st0 = *(const uint4*)g, st1 = *(const uint4*)(g + 8192);
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
         if (MODE & 1) {
@@ -38,6 +39,12 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const unsigned short* sr
             __builtin_amdgcn_global_load_lds((glb_vptr)(g + (it & 15) * 512), (lds_vptr)dma, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_vptr)(g + (it & 15) * 512 + 8192), (lds_vptr)(dma + 1024), 16, 0, 0);
         }
+        if (MODE & 4) {   // register staging: the loads issued last iteration are written to LDS now, new loads issued
+            *(uint4*)(dma + lane * 16) = st0;
+            *(uint4*)(dma + 1024 + lane * 16) = st1;
+            st0 = *(const uint4*)(g + (it & 15) * 512);
+            st1 = *(const uint4*)(g + (it & 15) * 512 + 8192);
+        }
         __builtin_amdgcn_sched_barrier(0);
         for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i >> 1], b[i & 1], c[i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -45,7 +52,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const unsigned short* sr
     unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0;
     for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) s += c[i][r];
-    out[blockIdx.x * 512 + threadIdx.x] = s;
+    out[blockIdx.x * 512 + threadIdx.x] = s + (float)st0.x;
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 template <int MODE> void run(float* out, unsigned short* src, unsigned long long* cyc, const char* name) {
@@ -72,5 +79,7 @@ int main() {
     run<1>(out, src, cyc, "+ 6 ds_read_b128 / 8 mfma");
     run<2>(out, src, cyc, "+ 2 LDS-DMA / 8 mfma");
     run<3>(out, src, cyc, "+ both");
+    run<4>(out, src, cyc, "+ 2 (global_load + ds_write)");
+    run<5>(out, src, cyc, "+ reads + reg-staged loads");
     return 0;
 }
