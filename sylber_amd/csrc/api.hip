@@ -585,7 +585,7 @@ extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t 
     g.xpad_rows = cfg >= 1000 ? (cfg / 1000) : 0;     // ablation flags ride on cfg = flags*1000 + cfg
     cfg = cfg % 1000;
     TmpBuf dbg;
-    const size_t ndbg = (size_t)((M + 127) / 128) * ((N + 127) / 128) * 4 * 5;
+    const size_t ndbg = (size_t)((M + 127) / 128) * ((N + 127) / 128) * 4 * 8;
     if (g.xpad_rows & 16) {
         if (dbg.alloc(ndbg * 8)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }
         HIP_TRY(hipMemset(dbg.p, 0, ndbg * 8));
@@ -608,12 +608,14 @@ extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t 
     if (g.xpad_rows & 16) {
         std::vector<unsigned long long> h(ndbg);
         hipMemcpy(h.data(), dbg.p, ndbg * 8, hipMemcpyDeviceToHost);
-        double tot[5] = {0, 0, 0, 0, 0};
+        double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         size_t nw = 0;
-        for (size_t w = 0; w + 5 <= ndbg; w += 5) { if (!h[w]) continue; for (int i = 0; i < 5; ++i) tot[i] += (double)h[w + i]; ++nw; }
+        for (size_t w = 0; w + 8 <= ndbg; w += 8) { if (!h[w]) continue; for (int i = 0; i < 8; ++i) tot[i] += (double)h[w + i]; ++nw; }
         const double steps = (double)(K / (cfg >= 10 ? 32 : 64)) * (nw ? nw : 1);
         printf("timing (ticks per step, mean over %zu waves; cfg<10: kk0..2 | waits | barrier | frag0+DMA | last mfma; cfg>=10: "
                "reads+DMA issue | waits | barrier | mfma | barrier): %.0f | %.0f | %.0f | %.0f | %.0f\n", nw, tot[0] / steps, tot[1] / steps, tot[2] / steps, tot[3] / steps, tot[4] / steps);
+        printf("   per workgroup: prologue %.0f | K loop %.0f | epilogue %.0f cycles\n", tot[5] / (nw ? nw : 1),
+               (tot[0] + tot[1] + tot[2] + tot[3] + tot[4]) / (nw ? nw : 1), tot[6] / (nw ? nw : 1));
         fflush(stdout);
     }
     return rc;

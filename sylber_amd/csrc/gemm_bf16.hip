@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
     static_assert(NP % 4 == 0, "tile must split evenly over 4 waves");
     constexpr bool NATURAL = (EPI == EPI_V); // A = activations: lane owns a feature column, runs of 4 tokens
     extern __shared__ __attribute__((aligned(256))) char smem[];
+    const unsigned long long t_entry = ((EPI != EPI_PROJ) && (a.xpad_rows & 16)) ? __builtin_readcyclecounter() : 0ull;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
     const bool timing = (EPI != EPI_PROJ) && (a.xpad_rows & 16);
     unsigned long long tacc[5] = {0, 0, 0, 0, 0};
     auto now = [&]() -> unsigned long long { return timing ? __builtin_readcyclecounter() : 0ull; };
+    const unsigned long long t_loop = now();
     for (int t = 0; t < nt; ++t) {
         const char* sb = smem + slot * STAGE;
         const int nslot = slot == NSTAGE - 1 ? 0 : slot + 1;
@@ -372,10 +374,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
             tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += t5 - t4;
         }
     }
+    const unsigned long long t_loop_end = now();
     if (timing && lane == 0 && a.out1) {
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 5;
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 8;
 #pragma unroll
         for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
+        dbg[5] = t_loop - t_entry;
     }
 
     // ---- epilogue
@@ -411,6 +415,11 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
                 epilogue_swapped<EPI, ACT>(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+    }
+    if (timing && lane == 0 && a.out1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 8;
+        dbg[6] = __builtin_readcyclecounter() - t_loop_end;
     }
 }
 
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     }
     if (group == 0) __builtin_amdgcn_s_barrier();    // pairs with group 1's extra barrier
     if (timing && lane == 0 && a.out1 && wave < 4) {
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 5;
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 8;
 #pragma unroll
         for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
     }
