@@ -183,7 +183,7 @@ extern "C" int64_t sylber_workspace_bytes(sylber_t c) { return c ? (int64_t)(c->
 // ------------------------------------------------------------------------------------------------
 struct Plan {
     int B, Lmax, L[7], T, Tp, Tpv, R[7];
-    size_t o_bufA, o_bufB, o_ln512, o_xf32, o_xpad, o_pre, o_hf32, o_hbf16, o_q, o_k, o_vt, o_ctx, o_ffn, o_part, o_ss, o_valid,
+    size_t o_bufA, o_bufB, o_ln512, o_xf32, o_xpad, o_pre, o_stats, o_hbf16, o_q, o_k, o_vt, o_ctx, o_ffn, o_part, o_ss, o_valid,
         total;
     int nchunk;
 };
@@ -207,7 +207,7 @@ static void make_plan(int B, int Lmax, Plan& p) {
     p.o_xf32 = take(M * 768 * 4);
     p.o_xpad = take((size_t)B * (p.Tp + 128) * 768 * 2);
     p.o_pre = take(M * 768 * 4);
-    p.o_hf32 = take(M * 768 * 4);
+    p.o_stats = take(M * 2 * 4);
     p.o_hbf16 = take((M + 128) * 768 * 2);
     p.o_q = take(M * 768 * 2);
     p.o_k = take(M * 768 * 2);
@@ -296,7 +296,7 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
     bf16_t* bufA = (bf16_t*)(w + p.o_bufA); bf16_t* bufB = (bf16_t*)(w + p.o_bufB);
     bf16_t* ln512 = (bf16_t*)(w + p.o_ln512);
     float* xf32 = (float*)(w + p.o_xf32); bf16_t* xpad = (bf16_t*)(w + p.o_xpad);
-    float* pre = (float*)(w + p.o_pre); float* hf32 = (float*)(w + p.o_hf32); bf16_t* hbf = (bf16_t*)(w + p.o_hbf16);
+    float* pre = (float*)(w + p.o_pre); float* stats = (float*)(w + p.o_stats); bf16_t* hbf = (bf16_t*)(w + p.o_hbf16);
     bf16_t* q = (bf16_t*)(w + p.o_q); bf16_t* k = (bf16_t*)(w + p.o_k); bf16_t* vt = (bf16_t*)(w + p.o_vt);
     bf16_t* ctx = (bf16_t*)(w + p.o_ctx); bf16_t* ffn = (bf16_t*)(w + p.o_ffn);
     double* part = (double*)(w + p.o_part); float* ss = (float*)(w + p.o_ss); int* valid = (int*)(w + p.o_valid);
@@ -349,11 +349,14 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         LnArgs a = {};
         a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = M; a.D = 768;
         if (last) { a.out_f32 = hidden_dev; a.ld_f32 = 768; a.Tp = p.Tp; a.T = p.T; }
-        else { a.out_f32 = hf32; a.ld_f32 = 768; a.out_bf16 = hbf; a.ld_bf16 = 768; }
+        else { a.out_bf16 = hbf; a.ld_bf16 = 768; a.out_stats = stats; }   // no fp32 copy: see EPI_F32_RESLN
         return launch_layernorm(a, s);
     };
     RUN("layernorm", run_ln(c->enc_ln_w, c->enc_ln_b, c->stop_stage == 2));
     if (c->stop_stage == 2) return 0;
+    // the residual of every block is the previous LayerNorm's output; it is re-derived in the GEMM epilogue from
+    // the pre-LN sum still sitting in `pre` (updated in place) + that LayerNorm's row statistics and affine
+    const float* res_g = c->enc_ln_w; const float* res_b = c->enc_ln_b;
     // ---- encoder layers (post-LN)
     for (int l = 0; l < c->num_layers; ++l) {
         const LayerDev& d = c->L[l];
@@ -367,8 +370,8 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, s));
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
-        o.out0 = pre; o.ld0 = 768; o.res = hf32; o.ldres = 768;
-        RUN("gemm_out", launch_gemm_bf16(EPI_F32_RES, o, s));
+        o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
+        RUN("gemm_out", launch_gemm_bf16(EPI_F32_RESLN, o, s));
         RUN("layernorm", run_ln(d.ln1w, d.ln1b, false));
         GemmArgs f1 = {};
         f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = 1;
@@ -376,9 +379,10 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         RUN("gemm_ffn1", launch_gemm_bf16(EPI_BF16, f1, s));
         GemmArgs f2 = {};
         f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
-        f2.out0 = pre; f2.ld0 = 768; f2.res = hf32; f2.ldres = 768;
-        RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RES, f2, s));
+        f2.out0 = pre; f2.ld0 = 768; f2.res = pre; f2.ldres = 768; f2.ln_stats = stats; f2.ln_gamma = d.ln1w; f2.ln_beta = d.ln1b;
+        RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RESLN, f2, s));
         RUN("layernorm", run_ln(d.ln2w, d.ln2b, last));
+        res_g = d.ln2w; res_b = d.ln2b;
         if (last) break;
     }
     return 0;

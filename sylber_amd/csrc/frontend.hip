@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
         for (int j = 0; j < 4; ++j) { const float d = x[i][j] - mean; q = fmaf(d, d, q); }
     const float var = wave_sum(q) * (1.0f / D);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (a.out_stats && lane == 0) *(float2*)(a.out_stats + (size_t)m * 2) = make_float2(mean, rstd);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = i * 256 + lane * 4;

@@ -61,6 +61,16 @@ __device__ __forceinline__ void epilogue_swapped(const GemmArgs& a, const f32x16
         } else if constexpr (EPI == EPI_F32_RES) {
             const float4 rr = *(const float4*)(a.res + (size_t)m * a.ldres + n);
             *(float4*)((float*)a.out0 + (size_t)m * a.ld0 + n) = make_float4(v0 + rr.x, v1 + rr.y, v2 + rr.z, v3 + rr.w);
+        } else if constexpr (EPI == EPI_F32_RESLN) {
+            // residual = LayerNorm(res row) re-applied here with the row statistics the LayerNorm kernel left
+            // behind (same expression as layernorm_kernel -> bitwise the value it would have stored)
+            const float4 rr = *(const float4*)(a.res + (size_t)m * a.ldres + n);
+            const float2 st = *(const float2*)(a.ln_stats + (size_t)m * 2);
+            const float4 gg = *(const float4*)(a.ln_gamma + n);
+            const float4 be = *(const float4*)(a.ln_beta + n);
+            const float h0 = fmaf((rr.x - st.x) * st.y, gg.x, be.x), h1 = fmaf((rr.y - st.x) * st.y, gg.y, be.y);
+            const float h2 = fmaf((rr.z - st.x) * st.y, gg.z, be.z), h3 = fmaf((rr.w - st.x) * st.y, gg.w, be.w);
+            *(float4*)((float*)a.out0 + (size_t)m * a.ld0 + n) = make_float4(v0 + h0, v1 + h1, v2 + h2, v3 + h3);
         } else if constexpr (EPI == EPI_QK) {
             // n < 1536 here (q and k thirds); head-major [B,H,Tp,64]
             const int which = n >= SYL_HIDDEN;            // 0 = q, 1 = k
@@ -116,7 +126,7 @@ __device__ __forceinline__ void epilogue_v_natural(const GemmArgs& a, const f32x
 // frame zeroing are applied on the way in; the residual add on the way out.
 template <int FN, int EPI>
 struct StagedEpi {
-    static constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_RES || EPI == EPI_PROJ);
+    static constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_RES || EPI == EPI_F32_RESLN || EPI == EPI_PROJ);
     static constexpr int ES = F32OUT ? 4 : 2;
     static constexpr int ROWB = 32 * FN * ES;       // payload bytes per row
     static constexpr int RS = ROWB + 16;            // padded row stride
@@ -690,6 +700,7 @@ int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s) {
             if (a.act == 2) return launch_t<EPI_F32, 2>(a, s);
             return launch_t<EPI_F32, 0>(a, s);
         case EPI_F32_RES: return launch_t<EPI_F32_RES, 0>(a, s);
+        case EPI_F32_RESLN: return launch_t<EPI_F32_RESLN, 0>(a, s);
         case EPI_QK: return launch_t<EPI_QK, 0>(a, s);
         case EPI_V: return launch_t<EPI_V, 0>(a, s);
         case EPI_PROJ: return launch_t<EPI_PROJ, 0>(a, s);

@@ -14,6 +14,8 @@ enum GemmEpi {
     EPI_QK = 3,         // N = 1536: q (x0.125) -> out0, k -> out1, both [B,H,Tp,64] bf16
     EPI_PROJ = 4,       // feature projection: zero padded frames; out0 f32 [M][768]; out1 bf16 xpad
     EPI_V = 5,          // N = 768: v -> out2 = Vt [B,H,64,Tpv] bf16 (key axis bit-swapped), natural orientation
+    EPI_F32_RESLN = 6,  // out0 f32 = acc + bias + LN(res[m][n]) with LN = (x - mean[m]) * rstd[m] * gamma[n] + beta[n]
+                        // (the residual IS a LayerNorm output that is never materialised in fp32; out0 may alias res)
 };
 
 struct GemmArgs {
@@ -28,6 +30,8 @@ struct GemmArgs {
     int Tp, Tpv, T;               // rows per utterance in M, Vt row stride, real frames
     const int* valid;             // [B] valid frames (EPI_PROJ)
     int xpad_rows;                // rows per utterance of the zero-padded pos-conv input (EPI_PROJ)
+    const float* ln_stats;        // [M][2] (mean, rstd) of the rows of `res` (EPI_F32_RESLN)
+    const float* ln_gamma; const float* ln_beta;
 };
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
@@ -67,6 +71,7 @@ struct LnArgs {
     const float* gamma; const float* beta;
     float* out_f32; long ld_f32;
     bf16_t* out_bf16; long ld_bf16;
+    float* out_stats;             // optional [M][2] (mean, rstd): lets a later GEMM epilogue re-apply this LayerNorm
     int M, D;
     int Tp, T;        // compaction of the f32 output (final hidden states); 0 = none
 };
