@@ -561,7 +561,9 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
 // ------------------------------------------------------------------------------------------------
 extern "C" void sylber_debug_force_gemm_cfg(int32_t cfg) {
     // cfg >= 0: GEMM tile configuration; -1: automatic; -101 / -102: attention with 32 / 64 queries per wave; -100: automatic
-    if (cfg <= -100) attention_force_qw(-cfg - 100); else gemm_force_cfg(cfg);
+    if (cfg <= -200) gemm_set_wg_per_cu(-cfg - 200);          // -200: one workgroup per tile; -201 / -202: persistent, 1 / 2 per CU
+    else if (cfg <= -100) attention_force_qw(-cfg - 100);
+    else gemm_force_cfg(cfg);
 }
 
 // GEMM micro-benchmark (development aid): times `iters` launches of the bf16 GEMM on pseudo-random

@@ -206,11 +206,14 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
     }
 }
 
+static int g_gemm_wg_per_cu = 0;   // 0 = one workgroup per tile; k = persistent launch of k x 256 workgroups
+void gemm_set_wg_per_cu(int k) { g_gemm_wg_per_cu = k; }
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT>
-__global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) {
+template <int FM, int FN, int BK, int NSTAGE, bool PRIO, int EPI, int ACT>
+__device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile_id, char* smem) {
     constexpr int BM = 64 * FM, BN = 64 * FN;
     constexpr int RB = BK * 2;               // bytes per LDS row (128 or 64)
     constexpr int CPR = RB / 16;             // 16-B chunks per row
@@ -221,7 +224,6 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
     constexpr int NPW = NP / 4;              // pieces per wave
     static_assert(NP % 4 == 0, "tile must split evenly over 4 waves");
     constexpr bool NATURAL = (EPI == EPI_V); // A = activations: lane owns a feature column, runs of 4 tokens
-    extern __shared__ __attribute__((aligned(256))) char smem[];
     const unsigned long long t_entry = ((EPI != EPI_PROJ) && (a.xpad_rows & 16)) ? __builtin_readcyclecounter() : 0ull;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
 
     const int tiles_n = (a.N + BN - 1) / BN;
     const int tiles_m = (a.M + BM - 1) / BM;
-    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int wg = xcd_remap(tile_id, tiles_m * tiles_n);
     const int m0 = (wg / tiles_n) * BM;
     const int n0 = (wg % tiles_n) * BN;
 
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
     }
     const unsigned long long t_loop_end = now();
     if (timing && lane == 0 && a.out1) {
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)tile_id * 4 + wave) * 8;
 #pragma unroll
         for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
         dbg[5] = t_loop - t_entry;
@@ -428,8 +430,24 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) 
     }
     if (timing && lane == 0 && a.out1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)tile_id * 4 + wave) * 8;
         dbg[6] = __builtin_readcyclecounter() - t_loop_end;
+    }
+}
+
+// One launch = min(#tiles, workgroups_per_cu x 256) persistent workgroups walking the tile list with stride
+// gridDim.x.  With `per_cu = 1` a launch holds only ONE of the two LDS slots of a CU, so the GEMM of the other
+// in-flight batch (a different kernel, in a different phase) can take the second one: its K loop then runs
+// under this launch's HBM-bound epilogue and vice versa, instead of two workgroups of the SAME launch hitting
+// their epilogues together.
+template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT>
+__global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    constexpr int BM = 64 * FM, BN = 64 * FN;
+    const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gemm_bf16_tile<FM, FN, BK, NSTAGE, PRIO, EPI, ACT>(a, tile, smem);
+        if (tile + (int)gridDim.x < ntiles) __builtin_amdgcn_s_barrier();   // LDS (operand ring / epilogue staging) is reused
     }
 }
 
@@ -445,7 +463,9 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS, s, a);
+    int grid = tiles;
+    if (g_gemm_wg_per_cu > 0 && tiles > g_gemm_wg_per_cu * 256) grid = g_gemm_wg_per_cu * 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

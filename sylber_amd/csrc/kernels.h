@@ -36,6 +36,7 @@ struct GemmArgs {
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
 void gemm_force_cfg(int cfg);   // -1 = automatic tile-shape choice
+void gemm_set_wg_per_cu(int k); // 4-wave GEMM: 0 = one workgroup per tile, k = persistent launch of k x 256 workgroups
 
 // fp32 parity-mode GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), same epilogues on fp32 tensors
 struct GemmArgsF32 {

@@ -135,3 +135,21 @@ def test_attention_full_batch_no_race(lib):
             lib.sylber_debug_force_gemm_cfg(-100)
         assert (outs[0] - ref).abs().max().item() < 3e-2, qw
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), qw
+
+
+@pytest.mark.parametrize("per_cu", [1, 2])
+def test_linear_persistent_grid(lib, per_cu):
+    """the 4-wave GEMM as a persistent launch (k x 256 workgroups walking the tile list) gives the same result"""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 70000, 768, 768          # 547 x 4 tiles of 128x192 -> several tiles per workgroup
+    a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+    c = torch.full((M, N), float("nan"), device="cuda")
+    lib.sylber_debug_force_gemm_cfg(-200 - per_cu)
+    try:
+        _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 0, 0, None), "op_linear")
+    finally:
+        lib.sylber_debug_force_gemm_cfg(-200)
+    ref = _bf(a) @ _bf(w).T + b
+    assert (c.cpu() - ref).abs().max().item() < 2e-3
