@@ -103,8 +103,6 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight (independent handles/streams)")
     ap.add_argument("--gemm-wg-per-cu", type=int, default=0,
                     help="4-wave GEMM launches: 0 = one workgroup per tile, k = persistent k x 256 workgroups")
-    ap.add_argument("--gemm-wg-per-cu", type=int, default=0,
-                    help="4-wave GEMM launches: 0 = one workgroup per tile, k = persistent k x 256 workgroups")
     ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS,
                     help="clip length; 10 = BASELINE configs[1] (default), 60 with --batch 8 = configs[3] (long-form)")
     args = ap.parse_args()
@@ -132,8 +130,6 @@ def main():
     clip_samples = int(round(clip_seconds * 16000))
     sd = synthetic_state_dict(0)
     enc = HubertEncoderHIP(sd, device=str(dev))
-    if args.gemm_wg_per_cu:
-        enc.lib.sylber_debug_force_gemm_cfg(-200 - args.gemm_wg_per_cu)
     if args.gemm_wg_per_cu:
         enc.lib.sylber_debug_force_gemm_cfg(-200 - args.gemm_wg_per_cu)
     sharded = ShardedSegmenter(enc)

@@ -53,3 +53,10 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "segment_ref" not in src and "hubert_ref" not in src, f
+
+
+def test_bench_cli_parses():
+    """bench.py's argument parser must build (a duplicated flag once broke the default run)"""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
