@@ -591,7 +591,7 @@ extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t 
     g.xpad_rows = cfg >= 1000 ? (cfg / 1000) : 0;     // ablation flags ride on cfg = flags*1000 + cfg
     cfg = cfg % 1000;
     TmpBuf dbg;
-    const size_t ndbg = (size_t)((M + 127) / 128) * ((N + 127) / 128) * 4 * 8;
+    const size_t ndbg = (size_t)((M + 127) / 128) * ((N + 127) / 128) * 4 * 8 + 64;
     if (g.xpad_rows & 16) {
         if (dbg.alloc(ndbg * 8)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }
         HIP_TRY(hipMemset(dbg.p, 0, ndbg * 8));

@@ -493,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     constexpr bool NATURAL = (EPI == EPI_V);
     static_assert(WM * WN == 8, "8 waves");
     extern __shared__ __attribute__((aligned(256))) char smem[];
+    const unsigned long long t_entry = ((EPI != EPI_PROJ) && (a.xpad_rows & 16)) ? __builtin_readcyclecounter() : 0ull;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int group = wave >> 2;                     // waves w and w+4 share a SIMD
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     __builtin_amdgcn_s_barrier();
     if (group == 1) __builtin_amdgcn_s_barrier();    // stagger: group 1 runs one barrier behind
     int slot = 0;
+    const unsigned long long t_loop = now();
     for (int s = 0; s < nt; ++s) {
         const char* sb = smem + slot * STAGE;
         bf16x8_t xf[2][FM], wf[2][FN];
@@ -628,10 +630,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
         slot = (slot + 1) & 3;
     }
     if (group == 0) __builtin_amdgcn_s_barrier();    // pairs with group 1's extra barrier
+    const unsigned long long t_loop_end = now();
     if (timing && lane == 0 && a.out1 && wave < 4) {
         unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 8;
 #pragma unroll
         for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
+        dbg[5] = t_loop - t_entry;
     }
 
     if constexpr (NATURAL) {
@@ -640,9 +644,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
                 epilogue_v_natural(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN + fn * 32 + frow, lane);
-    } else if constexpr (EPI == EPI_QK || EPI == EPI_PROJ) {
-        // measured A/B (MI355X): the LDS-staged, line-coalesced epilogue wins for the scattered head-major /
-        // dual-output epilogues (+7 % qk, +40 % proj) and is neutral-to-slightly-negative for the others
+    } else if (EPI == EPI_QK || EPI == EPI_PROJ || EPI == EPI_BF16 || (abl & 32)) {
+        // measured A/B (MI355X, instrumented): in this one-workgroup-per-CU kernel the LDS-staged, line-coalesced
+        // epilogue cuts the bf16 epilogue from 29.8 k to 19.4 k cycles per 256x256 tile (FFN1 +7-9 %, convs neutral)
         static_assert(8 * StagedEpi<FN, EPI>::BYTES <= 4 * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();                 // every wave is done reading operand tiles
         char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
@@ -655,6 +659,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
                 epilogue_swapped<EPI, ACT>(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+    }
+    if (timing && lane == 0 && a.out1 && wave < 4) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 8;
+        dbg[6] = __builtin_readcyclecounter() - t_loop_end;
     }
 }
 
