@@ -114,9 +114,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # SYLBER_DIST_BACKEND=gloo is a development aid: it lets the N>1 control flow (rendezvous, barriers,
+        # max-over-ranks) be exercised with several ranks sharing the one GPU of a development box
+        backend = os.environ.get("SYLBER_DIST_BACKEND", "nccl")
+        local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -198,7 +204,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_audio = world * B * clip_seconds * args.steps
