@@ -89,6 +89,20 @@ int sylber_forward(sylber_t h, const float* wav_dev, const int32_t* lengths_host
 int sylber_segment(sylber_t h, const float* hidden_dev, int32_t B, int32_t T, int32_t D, float norm_thr,
                    float merge_thr, int64_t* seg_dev, int32_t* nseg_dev, float* feat_dev, void* stream);
 
+/* ---- file ingest on the device (replaces sylber.py:83-86) -------------------
+ *   wav, sr = torchaudio.load(file); if sr != 16000: wav = torchaudio.transforms.Resample(sr, 16000)(wav);
+ *   wav = (wav - wav.mean()) / wav.std()
+ * pcm_dev      interleaved little-endian PCM frames as they sit in the file's data chunk, on the device
+ * sample_width bytes per sample: 1 (uint8), 2 (int16), 3 (int24), 4 (int32); scaled to [-1, 1) like torchaudio.load
+ * normalize    non-zero: (x - mean) / unbiased std over all channels x frames
+ * wav_out_dev  [channels, sylber_ingest_num_frames(frames_in, sr_in)] fp32, every channel one future batch row
+ * workspace_dev sylber_ingest_workspace_bytes(sr_in) bytes, 8-byte aligned, owned by the caller
+ * Stateless (no handle); stream-ordered.  Resampler: torchaudio's sinc_interp_hann defaults (csrc/ingest.hip). */
+int64_t sylber_ingest_num_frames(int64_t frames_in, int32_t sr_in);
+int64_t sylber_ingest_workspace_bytes(int32_t sr_in);
+int sylber_ingest(const void* pcm_dev, int32_t sample_width, int32_t channels, int64_t frames_in, int32_t sr_in,
+                  int32_t normalize, float* wav_out_dev, void* workspace_dev, void* stream);
+
 /* ---- introspection used by parity tests and the benchmark ------------------------------------ */
 /* run sylber_forward only up to a stage: 0 = all, 1 = conv stack, 2 = +projection/pos-conv/LN,
  * 3 + l = through encoder layer l.  The stage output is written to hidden_dev in place of the final

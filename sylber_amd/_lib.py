@@ -43,6 +43,9 @@ EXPORTS = {
     "sylber_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "sylber_debug_force_gemm_cfg": (None, [c_int32]),
     "sylber_debug_gemm_bench": (c_int, [c_int32] * 8 + [POINTER(c_float)]),
+    "sylber_ingest_num_frames": (c_int64, [c_int64, c_int32]),
+    "sylber_ingest_workspace_bytes": (c_int64, [c_int32]),
+    "sylber_ingest": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "sylber_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                     c_void_p]),
 }

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .ingest import ingest_file
 from .weights import (NUM_LAYERS, expected_shapes, fold_pos_conv_weight, normalize_keys, synthetic_state_dict)
 
 FRAME_RATE = 50  # sylber.py:132
@@ -27,22 +28,25 @@ def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
 
 
 def load_wav_file(path: str) -> torch.Tensor:
-    """16 kHz PCM ``.wav`` -> float32 [C, N] in [-1, 1] (what torchaudio.load returns at
-    sylber.py:83).  Resampling (sylber.py:84-85) is not on the hot path of this build."""
-    with _wave.open(str(path), "rb") as w:
-        sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
-        raw = w.readframes(n)
-    if sr != 16000:
-        raise NotImplementedError("only 16 kHz input is supported by this build (got %d Hz); resample first" % sr)
+    """PCM ``.wav`` -> float32 [C, N] in [-1, 1) on the HOST (what torchaudio.load returns at sylber.py:83), 16 kHz
+    files only.  Kept for tests and tools; ``Segmenter.__call__(wav_file=...)`` ingests on the device instead
+    (sylber_amd/ingest.py: decode + resample + normalise in HIP)."""
+    from .ingest import read_pcm
+    pcm = read_pcm(path)
+    if pcm.sample_rate != 16000:
+        raise NotImplementedError("load_wav_file is the host-side 16 kHz reader (got %d Hz); use sylber_amd.ingest" % pcm.sample_rate)
+    raw, width = pcm.data, pcm.sample_width
     if width == 2:
-        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+        x = raw.view("<i2").astype(np.float32) / 32768.0
     elif width == 4:
-        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+        x = raw.view("<i4").astype(np.float32) / 2147483648.0
     elif width == 1:
-        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        x = (raw.astype(np.float32) - 128.0) / 128.0
     else:
-        raise ValueError("unsupported sample width %d" % width)
-    return torch.from_numpy(x.reshape(-1, nch).T.copy())
+        b = raw.reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    return torch.from_numpy(x.reshape(-1, pcm.channels).T.copy())
 
 
 class HubertEncoderHIP:
@@ -207,9 +211,8 @@ class Segmenter:
         if wav_file is not None:
             is_batch = isinstance(wav_file, list)
             for f in (wav_file if is_batch else [wav_file]):
-                x = load_wav_file(f)
-                x = (x - x.mean()) / x.std()          # sylber.py:86 (unbiased std over all elements)
-                batch_wavs.append(x)
+                # sylber.py:83-86 on the device: decode, resample to 16 kHz, (x - mean) / unbiased std
+                batch_wavs.append(ingest_file(f, self.speech_model.device, normalize=True))
         else:
             assert wav is not None
             is_batch = isinstance(wav, list)
