@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight (independent handles/streams)")
     ap.add_argument("--gemm-wg-per-cu", type=int, default=0,
                     help="4-wave GEMM launches: 0 = one workgroup per tile, k = persistent k x 256 workgroups")
+    ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
+                    help="bf16 = BASELINE configs[1] (the headline); fp8 = configs[4]: FFN GEMMs on MXFP8 operands (not the headline)")
     ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS,
                     help="clip length; 10 = BASELINE configs[1] (default), 60 with --batch 8 = configs[3] (long-form)")
     args = ap.parse_args()
@@ -135,7 +137,7 @@ def main():
     clip_seconds = args.clip_seconds
     clip_samples = int(round(clip_seconds * 16000))
     sd = synthetic_state_dict(0)
-    enc = HubertEncoderHIP(sd, device=str(dev))
+    enc = HubertEncoderHIP(sd, device=str(dev), precision=args.precision)
     if args.gemm_wg_per_cu:
         enc.lib.sylber_debug_force_gemm_cfg(-200 - args.gemm_wg_per_cu)
     sharded = ShardedSegmenter(enc)
@@ -156,7 +158,7 @@ def main():
     # is complete before the closing device synchronize of the timed region.
     T_frames = enc.num_frames(clip_samples)
     NPIPE = 1 if (exchange or args.no_overlap) else args.inflight
-    encs = [enc] + [HubertEncoderHIP(sd, device=str(dev)) for _ in range(NPIPE - 1)]
+    encs = [enc] + [HubertEncoderHIP(sd, device=str(dev), precision=args.precision) for _ in range(NPIPE - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
     sides = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
     bufs = [(torch.empty(B, T_frames, 768, device=dev),
@@ -259,7 +261,8 @@ def main():
             "metric": "audio-sec/s encoded (sylber_base, 16 kHz, batched 10 s clips)",
             "value": round(value, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16 + mxfp8 (e4m3, E8M0 block scales) FFN GEMMs",
+            "data": "synthetic",
             "config": {"workload": "Segmenter forward (conv frontend + HuBERT-9L encoder + boundary detection + "
                                    "segment mean-pool), batch %d x %g s 16 kHz random waveforms per GPU, random-init "
                                    "sylber_base weights (BASELINE.json configs[1]%s)" % (B, clip_seconds, "; configs[2] sharding" if world > 1 else ""),

@@ -40,6 +40,7 @@ EXPORTS = {
     "sylber_workspace_bytes": (c_int64, [c_void_p]),
     "sylber_op_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  c_void_p]),
+    "sylber_op_mx_quantize": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "sylber_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "sylber_debug_force_gemm_cfg": (None, [c_int32]),
     "sylber_debug_gemm_bench": (c_int, [c_int32] * 8 + [POINTER(c_float)]),

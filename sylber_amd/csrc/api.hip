@@ -26,6 +26,7 @@ extern "C" int32_t sylber_num_frames(int32_t n) {
 
 struct LayerDev {
     bf16_t *wqkv, *wo, *w1, *w2;
+    uint8_t *w1q = nullptr, *w1s = nullptr, *w2q = nullptr, *w2s = nullptr;   // SYLBER_FP8: MXFP8 FFN weights + E8M0 scales
     float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
 };
 
@@ -35,6 +36,7 @@ struct sylber_ctx {
     int device = 0, precision = 0, num_layers = 9;
     // weights
     char* wbase = nullptr; size_t wbytes = 0;
+    char* f8base = nullptr; size_t f8bytes = 0;
     float *conv0_w, *gn_w, *gn_b, *fp_ln_w, *fp_ln_b, *fp_b, *pos_b, *enc_ln_w, *enc_ln_b;
     bf16_t* conv_w[7];
     bf16_t *fp_w, *pos_w;
@@ -70,7 +72,7 @@ struct Packer {
 extern "C" int sylber_create(const SylberWeights* w, int device, int precision, sylber_t* out) {
     if (!w || !out) { syl_set_error("sylber_create", "null argument"); return 1; }
     if (w->num_layers < 1 || w->num_layers > SYLBER_MAX_LAYERS) { syl_set_error("sylber_create", "num_layers out of range"); return 1; }
-    if (precision != SYLBER_BF16 && precision != SYLBER_FP32) { syl_set_error("sylber_create", "unknown precision"); return 1; }
+    if (precision != SYLBER_BF16 && precision != SYLBER_FP32 && precision != SYLBER_FP8) { syl_set_error("sylber_create", "unknown precision"); return 1; }
     const bool f32 = precision == SYLBER_FP32;
     HIP_TRY(hipSetDevice(device));
     sylber_ctx* c = new sylber_ctx();
@@ -154,6 +156,31 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
         c->L32[l].wqkv = (float*)(b + lo[l].wqkv); c->L32[l].wo = (float*)(b + lo[l].wo);
         c->L32[l].w1 = (float*)(b + lo[l].w1); c->L32[l].w2 = (float*)(b + lo[l].w2);
     }
+    if (precision == SYLBER_FP8) {
+        // FFN weights once more as MXFP8 (e4m3 + one E8M0 scale per 32 input features), quantised on the device
+        // from the fp32 originals with the same kernel the activations' op-level entry point uses
+        const size_t per_layer = (size_t)3072 * 768 + (size_t)3072 * 24 + (size_t)768 * 3072 + (size_t)768 * 96;
+        c->f8bytes = per_layer * w->num_layers;
+        float* tmp = nullptr;
+        if (hipMalloc((void**)&c->f8base, c->f8bytes) != hipSuccess || hipMalloc((void**)&tmp, (size_t)3072 * 768 * 4) != hipSuccess) {
+            if (c->f8base) hipFree(c->f8base);
+            hipFree(c->wbase); delete c; syl_set_error("sylber_create", "hipMalloc(fp8 weights) failed"); return 1;
+        }
+        int bad = 0;
+        for (int l = 0; l < w->num_layers && !bad; ++l) {
+            LayerDev& d = c->L[l];
+            uint8_t* q = (uint8_t*)c->f8base + per_layer * l;
+            d.w1q = q; d.w1s = d.w1q + (size_t)3072 * 768; d.w2q = d.w1s + (size_t)3072 * 24; d.w2s = d.w2q + (size_t)768 * 3072;
+            bad |= hipMemcpy(tmp, w->layers[l].ff1_w, (size_t)3072 * 768 * 4, hipMemcpyHostToDevice) != hipSuccess;
+            bad |= launch_mx_quant_rows(tmp, 768, d.w1q, 768, d.w1s, 24, 3072, 768, nullptr);
+            bad |= hipDeviceSynchronize() != hipSuccess;
+            bad |= hipMemcpy(tmp, w->layers[l].ff2_w, (size_t)768 * 3072 * 4, hipMemcpyHostToDevice) != hipSuccess;
+            bad |= launch_mx_quant_rows(tmp, 3072, d.w2q, 3072, d.w2s, 96, 768, 3072, nullptr);
+            bad |= hipDeviceSynchronize() != hipSuccess;
+        }
+        hipFree(tmp);
+        if (bad) { hipFree(c->f8base); hipFree(c->wbase); delete c; syl_set_error("sylber_create", "fp8 weight quantisation failed"); return 1; }
+    }
     *out = c;
     return 0;
 }
@@ -162,6 +189,7 @@ extern "C" void sylber_destroy(sylber_t c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->wbase) hipFree(c->wbase);
+    if (c->f8base) hipFree(c->f8base);
     if (c->ws) hipFree(c->ws);
     if (c->seg_scratch) hipFree(c->seg_scratch);
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -178,7 +206,7 @@ extern "C" int sylber_set_profiling(sylber_t c, int32_t enable) {
     c->profiling = enable;
     return 0;
 }
-extern "C" int64_t sylber_workspace_bytes(sylber_t c) { return c ? (int64_t)(c->ws_bytes + c->seg_scratch_floats * 4 + c->wbytes) : 0; }
+extern "C" int64_t sylber_workspace_bytes(sylber_t c) { return c ? (int64_t)(c->ws_bytes + c->seg_scratch_floats * 4 + c->wbytes + c->f8bytes) : 0; }
 
 // ------------------------------------------------------------------------------------------------
 struct Plan {
@@ -345,10 +373,16 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
     }
     // ---- positional conv + residual, encoder LayerNorm
     RUN("posconv", launch_posconv(xpad, c->pos_w, c->pos_b, xf32, pre, B, p.Tp, 1, s));
-    auto run_ln = [&](const float* gam, const float* bet, bool last) -> int {
+    // SYLBER_FP8: the FFN runs on MXFP8 operands; the LayerNorm in front of it then emits e4m3 + E8M0 block scales
+    // instead of bf16 (into the same buffer), and FFN1 leaves its GELU output as MXFP8 for FFN2
+    const bool f8 = c->precision == SYLBER_FP8;
+    uint8_t* h8 = (uint8_t*)hbf; uint8_t* h8s = h8 + (((size_t)M * 768 + 255) & ~(size_t)255);
+    uint8_t* ffn8 = (uint8_t*)ffn; uint8_t* ffn8s = ffn8 + (((size_t)M * 3072 + 255) & ~(size_t)255);
+    auto run_ln = [&](const float* gam, const float* bet, bool last, bool to_fp8 = false) -> int {
         LnArgs a = {};
         a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = M; a.D = 768;
         if (last) { a.out_f32 = hidden_dev; a.ld_f32 = 768; a.Tp = p.Tp; a.T = p.T; }
+        else if (to_fp8) { a.out_fp8 = h8; a.ld_fp8 = 768; a.out_scale = h8s; a.ld_scale = 24; a.out_stats = stats; }
         else { a.out_bf16 = hbf; a.ld_bf16 = 768; a.out_stats = stats; }   // no fp32 copy: see EPI_F32_RESLN
         return launch_layernorm(a, s);
     };
@@ -372,7 +406,18 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
         o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
         RUN("gemm_out", launch_gemm_bf16(EPI_F32_RESLN, o, s));
-        RUN("layernorm", run_ln(d.ln1w, d.ln1b, false));
+        RUN("layernorm", run_ln(d.ln1w, d.ln1b, false, f8));
+        if (f8) {
+            GemmF8Args f1 = {};
+            f1.g.M = M; f1.g.N = 3072; f1.g.K = 768; f1.g.bias = d.b1; f1.g.act = 1; f1.g.out0 = ffn8; f1.g.ld0 = 3072;
+            f1.X8 = h8; f1.ldx8 = 768; f1.XS = h8s; f1.ldxs = 24; f1.W8 = d.w1q; f1.WS = d.w1s; f1.out_scale = ffn8s; f1.ldos = 96;
+            RUN("gemm_ffn1", launch_gemm_mxfp8(EPI_MXFP8, f1, s));
+            GemmF8Args f2 = {};
+            f2.g.M = M; f2.g.N = 768; f2.g.K = 3072; f2.g.bias = d.b2; f2.g.out0 = pre; f2.g.ld0 = 768; f2.g.res = pre; f2.g.ldres = 768;
+            f2.g.ln_stats = stats; f2.g.ln_gamma = d.ln1w; f2.g.ln_beta = d.ln1b;
+            f2.X8 = ffn8; f2.ldx8 = 3072; f2.XS = ffn8s; f2.ldxs = 96; f2.W8 = d.w2q; f2.WS = d.w2s;
+            RUN("gemm_ffn2", launch_gemm_mxfp8(EPI_F32_RESLN, f2, s));
+        } else {
         GemmArgs f1 = {};
         f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = 1;
         f1.out0 = ffn; f1.ld0 = 3072;
@@ -381,6 +426,7 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
         f2.out0 = pre; f2.ld0 = 768; f2.res = pre; f2.ldres = 768; f2.ln_stats = stats; f2.ln_gamma = d.ln1w; f2.ln_beta = d.ln1b;
         RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RESLN, f2, s));
+        }
         RUN("layernorm", run_ln(d.ln2w, d.ln2b, last));
         res_g = d.ln2w; res_b = d.ln2b;
         if (last) break;
@@ -504,7 +550,23 @@ struct TmpBuf {
 extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, float* c_dev, int32_t M,
                                 int32_t N, int32_t K, int32_t act, int32_t precision, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (precision != SYLBER_BF16) { syl_set_error("sylber_op_linear", "only bf16"); return 1; }
+    if (precision == SYLBER_FP8) {
+        // both operands quantised to MXFP8 on the device, contraction on the block-scaled fp8 MFMA
+        if (K % 128 != 0) { syl_set_error("sylber_op_linear", "fp8 needs K % 128 == 0"); return 1; }
+        TmpBuf a8, as, w8, wsc;
+        if (a8.alloc((size_t)M * K) || as.alloc((size_t)M * (K / 32)) || w8.alloc((size_t)N * K) || wsc.alloc((size_t)N * (K / 32))) {
+            syl_set_error("sylber_op_linear", "alloc"); return 1;
+        }
+        if (launch_mx_quant_rows(a_dev, K, (uint8_t*)a8.p, K, (uint8_t*)as.p, K / 32, M, K, s)) return 1;
+        if (launch_mx_quant_rows(w_dev, K, (uint8_t*)w8.p, K, (uint8_t*)wsc.p, K / 32, N, K, s)) return 1;
+        GemmF8Args g = {};
+        g.g.M = M; g.g.N = N; g.g.K = K; g.g.bias = bias_dev; g.g.act = act; g.g.out0 = c_dev; g.g.ld0 = N;
+        g.X8 = (uint8_t*)a8.p; g.ldx8 = K; g.XS = (uint8_t*)as.p; g.ldxs = K / 32; g.W8 = (uint8_t*)w8.p; g.WS = (uint8_t*)wsc.p;
+        if (launch_gemm_mxfp8(EPI_F32, g, s)) return 1;
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }
+    if (precision != SYLBER_BF16) { syl_set_error("sylber_op_linear", "precision must be bf16 or fp8"); return 1; }
     TmpBuf ab, wb;
     if (ab.alloc(((size_t)M + 128) * K * 2) || wb.alloc(((size_t)N + 128) * K * 2)) { syl_set_error("sylber_op_linear", "alloc"); return 1; }
     if (launch_f32_to_bf16(a_dev, (bf16_t*)ab.p, (size_t)M * K, s)) return 1;
@@ -515,6 +577,11 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
     if (launch_gemm_bf16(EPI_F32, g, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
+}
+
+extern "C" int sylber_op_mx_quantize(const float* x_dev, int32_t R, int32_t K, uint8_t* data_dev, uint8_t* scale_dev, void* stream) {
+    if (!x_dev || !data_dev || !scale_dev) { syl_set_error("sylber_op_mx_quantize", "null argument"); return 1; }
+    return launch_mx_quant_rows(x_dev, K, data_dev, K, scale_dev, K / 32, R, K, (hipStream_t)stream);
 }
 
 extern "C" int sylber_op_layernorm(const float* x_dev, const float* res_dev, const float* g_dev, const float* b_dev,
@@ -561,7 +628,8 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
 // ------------------------------------------------------------------------------------------------
 extern "C" void sylber_debug_force_gemm_cfg(int32_t cfg) {
     // cfg >= 0: GEMM tile configuration; -1: automatic; -101 / -102: attention with 32 / 64 queries per wave; -100: automatic
-    if (cfg <= -200) gemm_set_wg_per_cu(-cfg - 200);          // -200: one workgroup per tile; -201 / -202: persistent, 1 / 2 per CU
+    if (cfg <= -300) gemm_mxfp8_force_cfg(-cfg - 300);         // -300: MXFP8 GEMM 128x192 tiles (default); -301: 128x128
+    else if (cfg <= -200) gemm_set_wg_per_cu(-cfg - 200);     // -200: one workgroup per tile; -201 / -202: persistent, 1 / 2 per CU
     else if (cfg <= -100) attention_force_qw(-cfg - 100);
     else gemm_force_cfg(cfg);
 }

@@ -65,6 +65,23 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return hx + e;
 }
 
+// ---- OCP microscaling FP8 (MXFP8: e4m3 elements, one E8M0 power-of-two scale per 32 elements along K) ----------
+// scale of a block with absolute maximum `amax`: the smallest 2^e with amax <= 448 * 2^e (448 = e4m3 max), so no
+// element saturates; returned biased (e + 127), clamped to [0, 254]; an all-zero block gets 1.0
+__device__ __forceinline__ unsigned mx_e8m0(float amax) {
+    const unsigned u = __float_as_uint(amax);
+    if (u == 0u) return 127u;
+    const int b = (int)(u >> 23) - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);   // 448 = 1.75 * 2^8
+    return (unsigned)(b < 0 ? 0 : (b > 254 ? 254 : b));
+}
+__device__ __forceinline__ float mx_inv_scale(unsigned e8m0) { return __uint_as_float((254u - e8m0) << 23); }
+// four floats -> four e4m3 bytes (v_cvt_pk_fp8_f32: round to nearest even, OCP format on gfx950)
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
 // ---- wave64 reductions ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -235,6 +235,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
             uint2 pk; pk.x = pack_bf16x2(y0, y1); pk.y = pack_bf16x2(y2, y3);
             *(uint2*)(a.out_bf16 + (size_t)m * a.ld_bf16 + c) = pk;
         }
+        if (a.out_fp8) {
+            // a 32-feature scale block = the 4 values of 8 consecutive lanes
+            float amax = fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fmaxf(fabsf(y2), fabsf(y3)));
+            amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+            const unsigned e = mx_e8m0(amax);
+            const float inv = mx_inv_scale(e);
+            *(unsigned*)(a.out_fp8 + (size_t)m * a.ld_fp8 + c) = pack_fp8x4(y0 * inv, y1 * inv, y2 * inv, y3 * inv);
+            if ((lane & 7) == 0) a.out_scale[(size_t)m * a.ld_scale + (c >> 5)] = (uint8_t)e;
+        }
     }
 }
 

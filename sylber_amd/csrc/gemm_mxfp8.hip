@@ -1,0 +1,296 @@
+// MXFP8 GEMM for gfx950 (BASELINE.json configs[4]: fp8 MFMA for the FFN GEMMs):
+//     out[m][n] = sum_k (X8[m][k] * 2^(XS[m][k/32]-127)) * (W8[n][k] * 2^(WS[n][k/32]-127))   (+ fused epilogue)
+// Operands are OCP microscaling FP8: e4m3 elements with one E8M0 power-of-two scale per 32 elements along K.  The
+// contraction runs on v_mfma_scale_f32_32x32x64_f8f6f4 — the only gfx950 matrix instruction that runs fp8 at twice
+// the bf16 rate — which applies the block scales in hardware (fp32 accumulation).
+//
+// Operand layout of that instruction, probed on the hardware (tools/ubench/mfma_f8_probe.hip):
+//   * lane l = (r = l & 31, h = l >> 5) supplies row r of its operand; its 32 bytes are k = 16h .. 16h+15 (registers
+//     0-3) and k = 32+16h .. 32+16h+15 (registers 4-7) of the 64-wide K slice;
+//   * the scale of (row r, K block h) is taken from lane (r, h): byte OPSEL of that lane's scale register;
+//   * C/D layout as for every 32x32 MFMA: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h.
+//
+// Structure (4 waves as 2x2, two workgroups per CU): tile (64 FM) x (64 FN), K step 128 BYTES — the same 128-byte
+// LDS rows, global_load_lds_dwordx4 staging and source-side XOR swizzle as the bf16 kernel (gemm_bf16.hip), so a
+// stage moves the same bytes but feeds twice the FLOPs.  2-slot ring with ONE barrier per K step: all fragments of
+// tile t are read into registers, then (barrier) the slot is refilled with tile t+2 while the MFMAs of tile t issue,
+// the LDS-DMA instructions interleaved between them.  Scale words (4 bytes = the 4 K blocks of a stage per row) go
+// global -> VGPR one stage ahead (they are 3 % of the operand bytes and every lane needs exactly its own rows').
+// "Swapped" orientation (A = weights, B = activations): a lane owns one token and runs of 4 output features.
+#include "kernels.h"
+#include "gemm_epilogue.h"
+
+typedef __attribute__((address_space(3))) void* lds_vptr8;
+typedef const __attribute__((address_space(1))) void* glb_vptr8;
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void glds16b(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((glb_vptr8)g, (lds_vptr8)l, 16, 0, 0);
+}
+#define F8_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// ---- quantiser: f32 rows -> MXFP8 (used for the weights at create time and by the op-level entry point) -------
+__global__ __launch_bounds__(256) void mx_quant_rows_kernel(const float* __restrict__ in, long ld_in, uint8_t* __restrict__ out,
+                                                            long ld_out, uint8_t* __restrict__ sc, long ld_sc, int R, int K) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int qpr = K >> 2;                         // quads per row (multiple of 8)
+    const long r = idx / qpr;
+    const int c = (int)(idx - r * qpr) * 4;
+    const bool ok = r < R;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v = *(const float4*)(in + r * ld_in + c);
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const unsigned e = mx_e8m0(amax);
+    const float inv = mx_inv_scale(e);
+    if (!ok) return;
+    *(unsigned*)(out + r * ld_out + c) = pack_fp8x4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+    if ((threadIdx.x & 7) == 0) sc[r * ld_sc + (c >> 5)] = (uint8_t)e;
+}
+
+int launch_mx_quant_rows(const float* in, long ld_in, uint8_t* out, long ld_out, uint8_t* sc, long ld_sc, int R, int K, hipStream_t s) {
+    if (K % 32 != 0 || K <= 0 || R <= 0) { syl_set_error("launch_mx_quant_rows", "K must be a positive multiple of 32"); return 1; }
+    const long quads = (long)R * (K / 4);
+    hipLaunchKernelGGL(mx_quant_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, in, ld_in, out, ld_out, sc, ld_sc, R, K);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- MXFP8 output epilogue (FFN1): act(acc + bias) -> e4m3 + one E8M0 scale per (token, 32 features) ----------
+// A 32x32 fragment IS one scale block per token: a lane holds 16 of its token's 32 values, lane^32 the other 16.
+// Rows are transposed through a private LDS region and leave as 16-byte chunks over whole lines.
+template <int FN>
+struct StagedF8 {
+    static constexpr int ROWB = 32 * FN;            // payload bytes per row
+    static constexpr int RS = ROWB + 16;
+    static constexpr int CH = ROWB / 16;
+    static constexpr int BYTES = 32 * RS;
+};
+
+template <int FN, int ACT>
+__device__ __forceinline__ void epilogue_mxfp8_rows32(const GemmF8Args& a, const f32x16_t (&acc)[FN], int mrow0, int ncol0, char* lds, int lane) {
+    using S = StagedF8<FN>;
+    const int ml = lane & 31, h = lane >> 5;
+    const int m = mrow0 + ml;
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        float v[16];
+        float amax = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = ncol0 + 32 * fn + 8 * g + 4 * h;
+            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.g.bias && n < a.g.N) bb = *(const float4*)(a.g.bias + n);
+            v[4 * g + 0] = apply_act<ACT>(acc[fn][4 * g + 0] + bb.x); v[4 * g + 1] = apply_act<ACT>(acc[fn][4 * g + 1] + bb.y);
+            v[4 * g + 2] = apply_act<ACT>(acc[fn][4 * g + 2] + bb.z); v[4 * g + 3] = apply_act<ACT>(acc[fn][4 * g + 3] + bb.w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(v[4 * g + j]));
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const unsigned e = mx_e8m0(amax);
+        const float inv = mx_inv_scale(e);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(unsigned*)(lds + ml * S::RS + 32 * fn + 8 * g + 4 * h) =
+                pack_fp8x4(v[4 * g + 0] * inv, v[4 * g + 1] * inv, v[4 * g + 2] * inv, v[4 * g + 3] * inv);
+        if (h == 0 && m < a.g.M && ncol0 + 32 * fn < a.g.N) a.out_scale[(size_t)m * a.ldos + ((ncol0 + 32 * fn) >> 5)] = (uint8_t)e;
+    }
+#pragma unroll
+    for (int it = 0; it < (S::CH + 1) / 2; ++it) {
+        const int idx = it * 64 + lane;
+        const int r = idx / S::CH, c = idx - r * S::CH;
+        const int mo = mrow0 + r;
+        const int n = ncol0 + c * 16;
+        if (r >= 32 || mo >= a.g.M || n >= a.g.N) continue;
+        *(uint4*)((uint8_t*)a.g.out0 + (size_t)mo * a.g.ld0 + n) = *(const uint4*)(lds + r * S::RS + c * 16);
+    }
+}
+
+template <int FM, int FN, int EPI, int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const GemmF8Args a) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int RB = 128;                  // bytes (= fp8 elements) per LDS row = K step
+    constexpr int XT = BM * RB, WT = BN * RB, STAGE = XT + WT;
+    constexpr int NP = (BM + BN) / 8;        // 1-KiB pieces per stage (8 rows each)
+    constexpr int NPW = NP / 4;
+    constexpr int NMT = 2 * FM * FN;         // MFMAs per stage per wave
+    static_assert(NP % 4 == 0, "tile must split evenly over 4 waves");
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = a.g.M, N = a.g.N, K = a.g.K;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+    // ---- staging (identical byte geometry to the bf16 kernel's 128-byte rows)
+    const int srow = lane >> 3, spos = lane & 7;
+    const uint8_t* gp[NPW];
+    int lds_off[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int p = wave + 4 * i;
+        const bool isx = p < BM / 8;
+        const int r = (isx ? p : p - BM / 8) * 8 + srow;
+        const int c = spos ^ ((r >> 1) & 7);
+        if (isx) { int xm = m0 + r; xm = xm < M ? xm : M - 1; gp[i] = a.X8 + (size_t)xm * a.ldx8 + c * 16; }
+        else { int wr = n0 + r; wr = wr < N ? wr : N - 1; gp[i] = a.W8 + (size_t)wr * K + c * 16; }
+        lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / 8) * 1024;
+    }
+    auto stage = [&](int kt, int slot) {
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) glds16b(gp[i] + (size_t)kt * RB, base + lds_off[i]);
+    };
+
+    // ---- fragment addresses: MFMA j of a stage reads 16-byte chunks 4j + h and 4j + 2 + h of its row
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int swz = (lane >> 1) & 7;
+    int koff[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { koff[j][0] = ((4 * j + fhalf) ^ swz) << 4; koff[j][1] = ((4 * j + 2 + fhalf) ^ swz) << 4; }
+    const int xrow_off = (wm * 32 * FM + frow) * RB;
+    const int wrow_off = XT + (wn * 32 * FN + frow) * RB;
+
+    // ---- scale words: one u32 (4 K blocks) per row and stage, straight to registers
+    const uint8_t* xsp[FM]; const uint8_t* wsp[FN];
+#pragma unroll
+    for (int f = 0; f < FM; ++f) { int r = m0 + wm * 32 * FM + f * 32 + frow; r = r < M ? r : M - 1; xsp[f] = a.XS + (size_t)r * a.ldxs; }
+#pragma unroll
+    for (int f = 0; f < FN; ++f) { int r = n0 + wn * 32 * FN + f * 32 + frow; r = r < N ? r : N - 1; wsp[f] = a.WS + (size_t)r * (K >> 5); }
+    unsigned xs[FM], ws[FN], xs_n[FM], ws_n[FN];
+    auto load_scales = [&](int kt, unsigned (&x)[FM], unsigned (&w)[FN]) {
+#pragma unroll
+        for (int f = 0; f < FM; ++f) x[f] = *(const unsigned*)(xsp[f] + 4 * kt);
+#pragma unroll
+        for (int f = 0; f < FN; ++f) w[f] = *(const unsigned*)(wsp[f] + 4 * kt);
+    };
+
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = K / RB;
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    load_scales(0, xs_n, ws_n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // tiles 0 and 1 are in LDS
+    for (int t = 0; t < nt; ++t) {
+        const int slot = t & 1;
+        const char* sb = smem + slot * STAGE;
+        // scales of tile t (loaded one iteration ago); lane half h uses bytes h and 2 + h -> shift once, OPSEL 0 / 2
+#pragma unroll
+        for (int f = 0; f < FM; ++f) xs[f] = xs_n[f] >> (8 * fhalf);
+#pragma unroll
+        for (int f = 0; f < FN; ++f) ws[f] = ws_n[f] >> (8 * fhalf);
+        v8i_t xf[2][FM], wf[2][FN];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int f = 0; f < FM; ++f) {
+                const uint4 lo = *(const uint4*)(sb + xrow_off + f * 32 * RB + koff[j][0]);
+                const uint4 hi = *(const uint4*)(sb + xrow_off + f * 32 * RB + koff[j][1]);
+                xf[j][f] = (v8i_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+            }
+#pragma unroll
+            for (int f = 0; f < FN; ++f) {
+                const uint4 lo = *(const uint4*)(sb + wrow_off + f * 32 * RB + koff[j][0]);
+                const uint4 hi = *(const uint4*)(sb + wrow_off + f * 32 * RB + koff[j][1]);
+                wf[j][f] = (v8i_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+            }
+        }
+        // ONE barrier per K step: behind it (a) every wave holds its fragments of tile t in registers, so this slot
+        // may be refilled with tile t+2, and (b) every wave's pieces of tile t+1 (issued under the MFMAs of tile t-1)
+        // have landed, so the next iteration may read the other slot
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        F8_FENCE();
+        if (t + 1 < nt) load_scales(t + 1, xs_n, ws_n);
+        const bool refill = t + 2 < nt;
+        char* dbase = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) {
+            const int j = i / (FM * FN), fm = (i % (FM * FN)) / FN, fn = i % FN;
+            if (j == 0)
+                acc[fm][fn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[0][fn], xf[0][fm], acc[fm][fn], 0, 0, 0, (int)ws[fn], 0, (int)xs[fm]);
+            else
+                acc[fm][fn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[1][fn], xf[1][fm], acc[fm][fn], 0, 0, 2, (int)ws[fn], 2, (int)xs[fm]);
+            // LDS-DMA pieces of tile t+2 spread evenly between the MFMAs
+#pragma unroll
+            for (int p = 0; p < NPW; ++p) {
+                if (((p + 1) * NMT + NPW - 1) / NPW - 1 == i) {
+                    F8_FENCE();
+                    if (refill) glds16b(gp[p] + (size_t)(t + 2) * RB, dbase + lds_off[p]);
+                    F8_FENCE();
+                }
+            }
+        }
+    }
+
+    // ---- epilogue
+    if constexpr (EPI == EPI_MXFP8) {
+        static_assert(4 * StagedF8<FN>::BYTES <= 2 * STAGE, "epilogue staging must fit the ring");
+        __builtin_amdgcn_s_barrier();
+        char* my = smem + wave * StagedF8<FN>::BYTES;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+            epilogue_mxfp8_rows32<FN, ACT>(a, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
+    } else {
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                epilogue_swapped<EPI, ACT>(a.g, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+    }
+}
+
+template <int FM, int FN, int EPI, int ACT>
+static int launch_f8(const GemmF8Args& a, hipStream_t s) {
+    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    const int tiles = ((a.g.M + BM - 1) / BM) * ((a.g.N + BN - 1) / BN);
+    static bool attr_set = false;
+    auto kern = gemm_mxfp8_kernel<FM, FN, EPI, ACT>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int g_f8_cfg = 0;            // 0 = 128x192, 1 = 128x128
+void gemm_mxfp8_force_cfg(int cfg) { g_f8_cfg = cfg; }
+
+template <int EPI, int ACT>
+static int launch_f8_t(const GemmF8Args& a, hipStream_t s) {
+    if (g_f8_cfg == 1) return launch_f8<2, 2, EPI, ACT>(a, s);
+    return launch_f8<2, 3, EPI, ACT>(a, s);
+}
+
+int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s) {
+    if (a.g.K % 128 != 0 || a.g.K <= 0 || a.g.M <= 0 || a.g.N <= 0) { syl_set_error("launch_gemm_mxfp8", "K must be a positive multiple of 128"); return 1; }
+    if (a.g.N % 4 != 0) { syl_set_error("launch_gemm_mxfp8", "N must be a multiple of 4"); return 1; }
+    if ((a.ldx8 & 15) || (a.ldxs & 3)) { syl_set_error("launch_gemm_mxfp8", "operand rows must be 16-byte / scale rows 4-byte aligned"); return 1; }
+    switch (epi) {
+        case EPI_MXFP8:
+            if (a.g.N % 32 != 0) { syl_set_error("launch_gemm_mxfp8", "MXFP8 output needs N % 32 == 0"); return 1; }
+            if (a.g.act == 1) return launch_f8_t<EPI_MXFP8, 1>(a, s);
+            return launch_f8_t<EPI_MXFP8, 0>(a, s);
+        case EPI_F32:
+            if (a.g.act == 1) return launch_f8_t<EPI_F32, 1>(a, s);
+            return launch_f8_t<EPI_F32, 0>(a, s);
+        case EPI_F32_RESLN: return launch_f8_t<EPI_F32_RESLN, 0>(a, s);
+    }
+    syl_set_error("launch_gemm_mxfp8", "unsupported epilogue");
+    return 1;
+}

@@ -14,6 +14,7 @@ enum GemmEpi {
     EPI_QK = 3,         // N = 1536: q (x0.125) -> out0, k -> out1, both [B,H,Tp,64] bf16
     EPI_PROJ = 4,       // feature projection: zero padded frames; out0 f32 [M][768]; out1 bf16 xpad
     EPI_V = 5,          // N = 768: v -> out2 = Vt [B,H,64,Tpv] bf16 (key axis bit-swapped), natural orientation
+    EPI_MXFP8 = 7,      // MXFP8 GEMM only: out0 e4m3 [M][ld0] + out_scale e8m0 [M][N/32] = mx(act(acc + bias))
     EPI_F32_RESLN = 6,  // out0 f32 = acc + bias + LN(res[m][n]) with LN = (x - mean[m]) * rstd[m] * gamma[n] + beta[n]
                         // (the residual IS a LayerNorm output that is never materialised in fp32; out0 may alias res)
 };
@@ -35,6 +36,20 @@ struct GemmArgs {
 };
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
+
+// MXFP8 GEMM (gemm_mxfp8.hip): e4m3 operands [rows][K] with one E8M0 scale per 32 elements along K, [rows][K/32];
+// `g` carries M, N, K, bias, act, the outputs and the residual / LayerNorm fields (g.X, g.W, g.ldx are unused)
+struct GemmF8Args {
+    GemmArgs g;
+    const uint8_t* X8; long ldx8;
+    const uint8_t* XS; long ldxs;
+    const uint8_t* W8;              // [N][K]
+    const uint8_t* WS;              // [N][K/32]
+    uint8_t* out_scale; long ldos;  // EPI_MXFP8
+};
+int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s);   // epi: EPI_MXFP8, EPI_F32, EPI_F32_RESLN
+void gemm_mxfp8_force_cfg(int cfg);
+int launch_mx_quant_rows(const float* in, long ld_in, uint8_t* out, long ld_out, uint8_t* sc, long ld_sc, int R, int K, hipStream_t s);
 void gemm_force_cfg(int cfg);   // -1 = automatic tile-shape choice
 void gemm_set_wg_per_cu(int k); // 4-wave GEMM: 0 = one workgroup per tile, k = persistent launch of k x 256 workgroups
 
@@ -72,6 +87,8 @@ struct LnArgs {
     const float* gamma; const float* beta;
     float* out_f32; long ld_f32;
     bf16_t* out_bf16; long ld_bf16;
+    uint8_t* out_fp8; long ld_fp8;        // optional MXFP8 copy of the output (D = 768): e4m3 rows +
+    uint8_t* out_scale; long ld_scale;    //   one E8M0 scale per 32 features
     float* out_stats;             // optional [M][2] (mean, rstd): lets a later GEMM epilogue re-apply this LayerNorm
     int M, D;
     int Tp, T;        // compaction of the f32 output (final hidden states); 0 = none
