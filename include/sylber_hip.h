@@ -122,8 +122,9 @@ int64_t sylber_workspace_bytes(sylber_t h);
 /* C[M,N] (fp32) = A[M,K] (fp32, cast to bf16) x W[N,K]^T (fp32, cast to bf16) + bias[N] (nullable); act: 0 none, 1 gelu */
 int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, float* c_dev, int32_t M,
                      int32_t N, int32_t K, int32_t act, int32_t precision, void* stream);   /* precision: SYLBER_BF16 or SYLBER_FP8 (K % 128 == 0) */
-/* MXFP8 quantiser used by SYLBER_FP8: x [R,K] fp32 -> data [R,K] e4m3 + scale [R,K/32] E8M0 (K % 32 == 0); the
- * block scale is the smallest power of two 2^e with amax <= 448 * 2^e, elements are x / 2^e rounded to nearest even */
+/* MXFP8 quantiser used by SYLBER_FP8: x [R,K] fp32 -> data [R,K] e4m3 + E8M0 scales, one per 32 elements along K,
+ * stored K-pair-major [K/64, R, 2] (K % 64 == 0; the layout the GEMM's scale fetch wants); the block scale is the
+ * smallest power of two 2^e with amax <= 448 * 2^e, elements are x / 2^e rounded to nearest even */
 int sylber_op_mx_quantize(const float* x_dev, int32_t R, int32_t K, uint8_t* data_dev, uint8_t* scale_dev, void* stream);
 /* y = LayerNorm(x [+ res]) over the last dim D (512 or 768), eps 1e-5 */
 int sylber_op_layernorm(const float* x_dev, const float* res_dev, const float* g_dev, const float* b_dev,

@@ -172,10 +172,10 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
             uint8_t* q = (uint8_t*)c->f8base + per_layer * l;
             d.w1q = q; d.w1s = d.w1q + (size_t)3072 * 768; d.w2q = d.w1s + (size_t)3072 * 24; d.w2s = d.w2q + (size_t)768 * 3072;
             bad |= hipMemcpy(tmp, w->layers[l].ff1_w, (size_t)3072 * 768 * 4, hipMemcpyHostToDevice) != hipSuccess;
-            bad |= launch_mx_quant_rows(tmp, 768, d.w1q, 768, d.w1s, 24, 3072, 768, nullptr);
+            bad |= launch_mx_quant_rows(tmp, 768, d.w1q, 768, d.w1s, 3072, 3072, 768, nullptr);
             bad |= hipDeviceSynchronize() != hipSuccess;
             bad |= hipMemcpy(tmp, w->layers[l].ff2_w, (size_t)768 * 3072 * 4, hipMemcpyHostToDevice) != hipSuccess;
-            bad |= launch_mx_quant_rows(tmp, 3072, d.w2q, 3072, d.w2s, 96, 768, 3072, nullptr);
+            bad |= launch_mx_quant_rows(tmp, 3072, d.w2q, 3072, d.w2s, 768, 768, 3072, nullptr);
             bad |= hipDeviceSynchronize() != hipSuccess;
         }
         hipFree(tmp);
@@ -376,13 +376,14 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
     // SYLBER_FP8: the FFN runs on MXFP8 operands; the LayerNorm in front of it then emits e4m3 + E8M0 block scales
     // instead of bf16 (into the same buffer), and FFN1 leaves its GELU output as MXFP8 for FFN2
     const bool f8 = c->precision == SYLBER_FP8;
-    uint8_t* h8 = (uint8_t*)hbf; uint8_t* h8s = h8 + (((size_t)M * 768 + 255) & ~(size_t)255);
-    uint8_t* ffn8 = (uint8_t*)ffn; uint8_t* ffn8s = ffn8 + (((size_t)M * 3072 + 255) & ~(size_t)255);
+    const long Mp = ((long)M + 255) & ~255L;            // row pitch of the activations' scale arrays
+    uint8_t* h8 = (uint8_t*)hbf; uint8_t* h8s = h8 + (((size_t)M * 768 + 255) & ~(size_t)255);       // 24 Mp bytes
+    uint8_t* ffn8 = (uint8_t*)ffn; uint8_t* ffn8s = ffn8 + (((size_t)M * 3072 + 255) & ~(size_t)255);  // 96 Mp bytes
     auto run_ln = [&](const float* gam, const float* bet, bool last, bool to_fp8 = false) -> int {
         LnArgs a = {};
         a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = M; a.D = 768;
         if (last) { a.out_f32 = hidden_dev; a.ld_f32 = 768; a.Tp = p.Tp; a.T = p.T; }
-        else if (to_fp8) { a.out_fp8 = h8; a.ld_fp8 = 768; a.out_scale = h8s; a.ld_scale = 24; a.out_stats = stats; }
+        else if (to_fp8) { a.out_fp8 = h8; a.ld_fp8 = 768; a.out_scale = h8s; a.scale_rows = Mp; a.out_stats = stats; }
         else { a.out_bf16 = hbf; a.ld_bf16 = 768; a.out_stats = stats; }   // no fp32 copy: see EPI_F32_RESLN
         return launch_layernorm(a, s);
     };
@@ -410,12 +411,12 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         if (f8) {
             GemmF8Args f1 = {};
             f1.g.M = M; f1.g.N = 3072; f1.g.K = 768; f1.g.bias = d.b1; f1.g.act = 1; f1.g.out0 = ffn8; f1.g.ld0 = 3072;
-            f1.X8 = h8; f1.ldx8 = 768; f1.XS = h8s; f1.ldxs = 24; f1.W8 = d.w1q; f1.WS = d.w1s; f1.out_scale = ffn8s; f1.ldos = 96;
+            f1.X8 = h8; f1.ldx8 = 768; f1.XS = h8s; f1.xs_rows = Mp; f1.W8 = d.w1q; f1.WS = d.w1s; f1.ws_rows = 3072; f1.out_scale = ffn8s; f1.os_rows = Mp;
             RUN("gemm_ffn1", launch_gemm_mxfp8(EPI_MXFP8, f1, s));
             GemmF8Args f2 = {};
             f2.g.M = M; f2.g.N = 768; f2.g.K = 3072; f2.g.bias = d.b2; f2.g.out0 = pre; f2.g.ld0 = 768; f2.g.res = pre; f2.g.ldres = 768;
             f2.g.ln_stats = stats; f2.g.ln_gamma = d.ln1w; f2.g.ln_beta = d.ln1b;
-            f2.X8 = ffn8; f2.ldx8 = 3072; f2.XS = ffn8s; f2.ldxs = 96; f2.W8 = d.w2q; f2.WS = d.w2s;
+            f2.X8 = ffn8; f2.ldx8 = 3072; f2.XS = ffn8s; f2.xs_rows = Mp; f2.W8 = d.w2q; f2.WS = d.w2s; f2.ws_rows = 768;
             RUN("gemm_ffn2", launch_gemm_mxfp8(EPI_F32_RESLN, f2, s));
         } else {
         GemmArgs f1 = {};
@@ -554,14 +555,16 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
         // both operands quantised to MXFP8 on the device, contraction on the block-scaled fp8 MFMA
         if (K % 128 != 0) { syl_set_error("sylber_op_linear", "fp8 needs K % 128 == 0"); return 1; }
         TmpBuf a8, as, w8, wsc;
-        if (a8.alloc((size_t)M * K) || as.alloc((size_t)M * (K / 32)) || w8.alloc((size_t)N * K) || wsc.alloc((size_t)N * (K / 32))) {
+        const long Mp = ((long)M + 255) & ~255L, Np = ((long)N + 255) & ~255L;
+        if (a8.alloc((size_t)M * K) || as.alloc((size_t)Mp * (K / 32)) || w8.alloc((size_t)N * K) || wsc.alloc((size_t)Np * (K / 32))) {
             syl_set_error("sylber_op_linear", "alloc"); return 1;
         }
-        if (launch_mx_quant_rows(a_dev, K, (uint8_t*)a8.p, K, (uint8_t*)as.p, K / 32, M, K, s)) return 1;
-        if (launch_mx_quant_rows(w_dev, K, (uint8_t*)w8.p, K, (uint8_t*)wsc.p, K / 32, N, K, s)) return 1;
+        HIP_TRY(hipMemsetAsync(as.p, 127, (size_t)Mp * (K / 32), s)); HIP_TRY(hipMemsetAsync(wsc.p, 127, (size_t)Np * (K / 32), s));
+        if (launch_mx_quant_rows(a_dev, K, (uint8_t*)a8.p, K, (uint8_t*)as.p, Mp, M, K, s)) return 1;
+        if (launch_mx_quant_rows(w_dev, K, (uint8_t*)w8.p, K, (uint8_t*)wsc.p, Np, N, K, s)) return 1;
         GemmF8Args g = {};
         g.g.M = M; g.g.N = N; g.g.K = K; g.g.bias = bias_dev; g.g.act = act; g.g.out0 = c_dev; g.g.ld0 = N;
-        g.X8 = (uint8_t*)a8.p; g.ldx8 = K; g.XS = (uint8_t*)as.p; g.ldxs = K / 32; g.W8 = (uint8_t*)w8.p; g.WS = (uint8_t*)wsc.p;
+        g.X8 = (uint8_t*)a8.p; g.ldx8 = K; g.XS = (uint8_t*)as.p; g.xs_rows = Mp; g.W8 = (uint8_t*)w8.p; g.WS = (uint8_t*)wsc.p; g.ws_rows = Np;
         if (launch_gemm_mxfp8(EPI_F32, g, s)) return 1;
         HIP_TRY(hipStreamSynchronize(s));
         return 0;
@@ -581,7 +584,7 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
 
 extern "C" int sylber_op_mx_quantize(const float* x_dev, int32_t R, int32_t K, uint8_t* data_dev, uint8_t* scale_dev, void* stream) {
     if (!x_dev || !data_dev || !scale_dev) { syl_set_error("sylber_op_mx_quantize", "null argument"); return 1; }
-    return launch_mx_quant_rows(x_dev, K, data_dev, K, scale_dev, K / 32, R, K, (hipStream_t)stream);
+    return launch_mx_quant_rows(x_dev, K, data_dev, K, scale_dev, R, R, K, (hipStream_t)stream);
 }
 
 extern "C" int sylber_op_layernorm(const float* x_dev, const float* res_dev, const float* g_dev, const float* b_dev,
@@ -628,7 +631,7 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
 // ------------------------------------------------------------------------------------------------
 extern "C" void sylber_debug_force_gemm_cfg(int32_t cfg) {
     // cfg >= 0: GEMM tile configuration; -1: automatic; -101 / -102: attention with 32 / 64 queries per wave; -100: automatic
-    if (cfg <= -300) gemm_mxfp8_force_cfg(-cfg - 300);         // -300: MXFP8 GEMM 128x192 tiles (default); -301: 128x128
+    if (cfg <= -300) gemm_mxfp8_force_cfg(-cfg - 301);         // -300: MXFP8 GEMM tile automatic; -301 - k: force tile config k (0..3)
     else if (cfg <= -200) gemm_set_wg_per_cu(-cfg - 200);     // -200: one workgroup per tile; -201 / -202: persistent, 1 / 2 per CU
     else if (cfg <= -100) attention_force_qw(-cfg - 100);
     else gemm_force_cfg(cfg);
@@ -643,8 +646,56 @@ __global__ void fill_random_bf16(bf16_t* p, size_t n, unsigned seed) {
         p[i] = f2bf(((float)(x & 0xffff) / 32768.0f - 1.0f) * 0.5f);
     }
 }
+__global__ void fill_random_fp8(uint8_t* p, size_t n, unsigned seed, int scale_bytes) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        unsigned b = x & 0xffu;
+        if ((b & 0x7fu) == 0x7fu) b ^= 1u;                    // no NaN codes
+        p[i] = scale_bytes ? (uint8_t)(124u + (b & 7u)) : (uint8_t)b;
+    }
+}
+
+// MXFP8 leg of the micro-benchmark: cfg = 100 + tile config (0 = 128x192, 1 = 128x128, 2 = 256x256 8-wave, 3 = 256x192 8-wave); epi 0 = MXFP8 output (FFN1),
+// 1 = fp32 output, 6 = fp32 residual + LayerNorm re-derivation (FFN2)
+static int gemm_bench_f8(int M, int N, int K, int epi, int act, int cfg, int iters, float* ms_out) {
+    TmpBuf xb, xs, wb, wsb, ob, os, bb, st;
+    const long Mp = ((long)M + 255) & ~255L, Np = ((long)N + 255) & ~255L;
+    if (xb.alloc((size_t)M * K) || xs.alloc((size_t)Mp * (K / 32)) || wb.alloc((size_t)N * K) || wsb.alloc((size_t)Np * (K / 32)) ||
+        ob.alloc((size_t)M * N * 4) || os.alloc((size_t)Mp * (N / 32 + 2)) || bb.alloc((size_t)N * 4 * 3) || st.alloc((size_t)M * 8)) {
+        syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1;
+    }
+    hipLaunchKernelGGL(fill_random_fp8, dim3(2048), dim3(256), 0, 0, (uint8_t*)xb.p, (size_t)M * K, 1u, 0);
+    hipLaunchKernelGGL(fill_random_fp8, dim3(2048), dim3(256), 0, 0, (uint8_t*)wb.p, (size_t)N * K, 2u, 0);
+    hipLaunchKernelGGL(fill_random_fp8, dim3(256), dim3(256), 0, 0, (uint8_t*)xs.p, (size_t)Mp * (K / 32), 3u, 1);
+    hipLaunchKernelGGL(fill_random_fp8, dim3(256), dim3(256), 0, 0, (uint8_t*)wsb.p, (size_t)Np * (K / 32), 4u, 1);
+    HIP_TRY(hipMemset(bb.p, 0, (size_t)N * 12)); HIP_TRY(hipMemset(st.p, 0, (size_t)M * 8)); HIP_TRY(hipMemset(ob.p, 0, (size_t)M * N * 4));
+    GemmF8Args g = {};
+    g.g.M = M; g.g.N = N; g.g.K = K; g.g.bias = (float*)bb.p; g.g.act = act; g.g.out0 = ob.p; g.g.ld0 = N;
+    g.g.res = (float*)ob.p; g.g.ldres = N; g.g.ln_stats = (float*)st.p; g.g.ln_gamma = (float*)bb.p + N; g.g.ln_beta = (float*)bb.p + 2 * N;
+    g.X8 = (uint8_t*)xb.p; g.ldx8 = K; g.XS = (uint8_t*)xs.p; g.xs_rows = Mp; g.W8 = (uint8_t*)wb.p; g.WS = (uint8_t*)wsb.p; g.ws_rows = Np;
+    g.out_scale = (uint8_t*)os.p; g.os_rows = Mp;
+    const int e = epi == 0 ? EPI_MXFP8 : (epi == 6 ? EPI_F32_RESLN : EPI_F32);
+    gemm_mxfp8_force_cfg(cfg);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    int rc = 0;
+    for (int i = 0; i < 3 && !rc; ++i) rc = launch_gemm_mxfp8(e, g, 0);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_gemm_mxfp8(e, g, 0);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    gemm_mxfp8_force_cfg(-1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
+}
+
 extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
                                        int32_t iters, float* ms_out) {
+    if (cfg >= 100 && cfg < 200) return gemm_bench_f8(M, N, K, epi, act, cfg - 100, iters, ms_out);
     TmpBuf xb, wb, ob, rb, bb;
     const size_t xn = (size_t)(M + 8) * ldx + K, wn = (size_t)N * K;
     if (xb.alloc(xn * 2) || wb.alloc(wn * 2) || ob.alloc((size_t)M * N * 4) || rb.alloc((size_t)M * N * 4) || bb.alloc((size_t)N * 4)) {

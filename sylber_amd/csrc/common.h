@@ -65,6 +65,27 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return hx + e;
 }
 
+// two values at once on the packed-fp32 VALU (v_pk_mul_f32 / v_pk_fma_f32 issue at the scalar rate but carry two
+// lanes' worth of work each): same polynomial, bitwise the same results as gelu_fast
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_fast2(float& a, float& b) {
+    const f32x2_t x = {a, b};
+    const f32x2_t u = x * x;
+    f32x2_t q = __builtin_elementwise_fma((f32x2_t)(6.949803233e-11f), u, (f32x2_t)(-6.356798643e-09f));
+    q = __builtin_elementwise_fma(q, u, (f32x2_t)(2.570604920e-07f));
+    q = __builtin_elementwise_fma(q, u, (f32x2_t)(-6.139445304e-06f));
+    q = __builtin_elementwise_fma(q, u, (f32x2_t)(9.818511899e-05f));
+    q = __builtin_elementwise_fma(q, u, (f32x2_t)(-1.133762766e-03f));
+    q = __builtin_elementwise_fma(q, u, (f32x2_t)(9.886963293e-03f));
+    q = __builtin_elementwise_fma(q, u, (f32x2_t)(-6.643489748e-02f));
+    q = __builtin_elementwise_fma(q, u, (f32x2_t)(3.989362717e-01f));
+    const f32x2_t hx = x * (f32x2_t)(0.5f);
+    const f32x2_t qu = q * u;
+    const float e0 = u.x > 17.64f ? fabsf(hx.x) : qu.x;
+    const float e1 = u.y > 17.64f ? fabsf(hx.y) : qu.y;
+    a = hx.x + e0; b = hx.y + e1;
+}
+
 // ---- OCP microscaling FP8 (MXFP8: e4m3 elements, one E8M0 power-of-two scale per 32 elements along K) ----------
 // scale of a block with absolute maximum `amax`: the smallest 2^e with amax <= 448 * 2^e (448 = e4m3 max), so no
 // element saturates; returned biased (e + 127), clamped to [0, 254]; an all-zero block gets 1.0
@@ -73,6 +94,11 @@ __device__ __forceinline__ unsigned mx_e8m0(float amax) {
     if (u == 0u) return 127u;
     const int b = (int)(u >> 23) - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);   // 448 = 1.75 * 2^8
     return (unsigned)(b < 0 ? 0 : (b > 254 ? 254 : b));
+}
+// scale storage: "K-pair-major" [K/64][rows][2] — the two scales a row contributes to one 64-wide MFMA K slice are
+// adjacent, and the scales of 8 consecutive rows for one slice are one 16-byte run (one lane of an LDS-DMA instruction)
+__host__ __device__ __forceinline__ size_t mx_scale_index(long row, int block, long rows) {
+    return (size_t)(block >> 1) * (size_t)rows * 2 + (size_t)row * 2 + (size_t)(block & 1);
 }
 __device__ __forceinline__ float mx_inv_scale(unsigned e8m0) { return __uint_as_float((254u - e8m0) << 23); }
 // four floats -> four e4m3 bytes (v_cvt_pk_fp8_f32: round to nearest even, OCP format on gfx950)

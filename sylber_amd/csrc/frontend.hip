@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
             const unsigned e = mx_e8m0(amax);
             const float inv = mx_inv_scale(e);
             *(unsigned*)(a.out_fp8 + (size_t)m * a.ld_fp8 + c) = pack_fp8x4(y0 * inv, y1 * inv, y2 * inv, y3 * inv);
-            if ((lane & 7) == 0) a.out_scale[(size_t)m * a.ld_scale + (c >> 5)] = (uint8_t)e;
+            if ((lane & 7) == 0) a.out_scale[mx_scale_index(m, c >> 5, a.scale_rows)] = (uint8_t)e;
         }
     }
 }

@@ -97,7 +97,7 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
                 v0 += bb.x; v1 += bb.y; v2 += bb.z; v3 += bb.w;
             }
             if constexpr (EPI == EPI_BF16 || EPI == EPI_F32) {
-                v0 = apply_act<ACT>(v0); v1 = apply_act<ACT>(v1); v2 = apply_act<ACT>(v2); v3 = apply_act<ACT>(v3);
+                apply_act4<ACT>(v0, v1, v2, v3);
             }
             if constexpr (EPI == EPI_QK) {
                 if (n < SYL_HIDDEN) { v0 *= 0.125f; v1 *= 0.125f; v2 *= 0.125f; v3 *= 0.125f; }

@@ -8,6 +8,12 @@ __device__ __forceinline__ float apply_act(float v) {
     if constexpr (ACT == 2) return gelu_erf(v);
     return v;
 }
+// four values of one run: the fast GELU goes through the packed-fp32 pipe two at a time
+template <int ACT>
+__device__ __forceinline__ void apply_act4(float& v0, float& v1, float& v2, float& v3) {
+    if constexpr (ACT == 1) { gelu_fast2(v0, v1); gelu_fast2(v2, v3); }
+    else { v0 = apply_act<ACT>(v0); v1 = apply_act<ACT>(v1); v2 = apply_act<ACT>(v2); v3 = apply_act<ACT>(v3); }
+}
 
 // Epilogue for one 32x32 fragment in SWAPPED orientation: lane owns token m (column l&31) and 16
 // output features n = nb + (r&3) + 8*(r>>2) + 4*(l>>5): four runs of 4 consecutive n.
@@ -25,13 +31,11 @@ __device__ __forceinline__ void epilogue_swapped(const GemmArgs& a, const f32x16
             v0 += bb.x; v1 += bb.y; v2 += bb.z; v3 += bb.w;
         }
         if constexpr (EPI == EPI_BF16) {
-            v0 = apply_act<ACT>(v0); v1 = apply_act<ACT>(v1);
-            v2 = apply_act<ACT>(v2); v3 = apply_act<ACT>(v3);
+            apply_act4<ACT>(v0, v1, v2, v3);
             uint2 pk; pk.x = pack_bf16x2(v0, v1); pk.y = pack_bf16x2(v2, v3);
             *(uint2*)((bf16_t*)a.out0 + (size_t)m * a.ld0 + n) = pk;
         } else if constexpr (EPI == EPI_F32) {
-            v0 = apply_act<ACT>(v0); v1 = apply_act<ACT>(v1);
-            v2 = apply_act<ACT>(v2); v3 = apply_act<ACT>(v3);
+            apply_act4<ACT>(v0, v1, v2, v3);
             *(float4*)((float*)a.out0 + (size_t)m * a.ld0 + n) = make_float4(v0, v1, v2, v3);
         } else if constexpr (EPI == EPI_F32_RES) {
             const float4 rr = *(const float4*)(a.res + (size_t)m * a.ldres + n);

@@ -31,7 +31,7 @@ __device__ __forceinline__ void glds16b(const void* g, void* l) {
 
 // ---- quantiser: f32 rows -> MXFP8 (used for the weights at create time and by the op-level entry point) -------
 __global__ __launch_bounds__(256) void mx_quant_rows_kernel(const float* __restrict__ in, long ld_in, uint8_t* __restrict__ out,
-                                                            long ld_out, uint8_t* __restrict__ sc, long ld_sc, int R, int K) {
+                                                            long ld_out, uint8_t* __restrict__ sc, long sc_rows, int R, int K) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int qpr = K >> 2;                         // quads per row (multiple of 8)
     const long r = idx / qpr;
@@ -47,13 +47,13 @@ __global__ __launch_bounds__(256) void mx_quant_rows_kernel(const float* __restr
     const float inv = mx_inv_scale(e);
     if (!ok) return;
     *(unsigned*)(out + r * ld_out + c) = pack_fp8x4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
-    if ((threadIdx.x & 7) == 0) sc[r * ld_sc + (c >> 5)] = (uint8_t)e;
+    if ((threadIdx.x & 7) == 0) sc[mx_scale_index(r, c >> 5, sc_rows)] = (uint8_t)e;
 }
 
-int launch_mx_quant_rows(const float* in, long ld_in, uint8_t* out, long ld_out, uint8_t* sc, long ld_sc, int R, int K, hipStream_t s) {
-    if (K % 32 != 0 || K <= 0 || R <= 0) { syl_set_error("launch_mx_quant_rows", "K must be a positive multiple of 32"); return 1; }
+int launch_mx_quant_rows(const float* in, long ld_in, uint8_t* out, long ld_out, uint8_t* sc, long sc_rows, int R, int K, hipStream_t s) {
+    if (K % 64 != 0 || K <= 0 || R <= 0) { syl_set_error("launch_mx_quant_rows", "K must be a positive multiple of 64"); return 1; }
     const long quads = (long)R * (K / 4);
-    hipLaunchKernelGGL(mx_quant_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, in, ld_in, out, ld_out, sc, ld_sc, R, K);
+    hipLaunchKernelGGL(mx_quant_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, in, ld_in, out, ld_out, sc, sc_rows, R, K);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -83,8 +83,9 @@ __device__ __forceinline__ void epilogue_mxfp8_rows32(const GemmF8Args& a, const
             const int n = ncol0 + 32 * fn + 8 * g + 4 * h;
             float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.g.bias && n < a.g.N) bb = *(const float4*)(a.g.bias + n);
-            v[4 * g + 0] = apply_act<ACT>(acc[fn][4 * g + 0] + bb.x); v[4 * g + 1] = apply_act<ACT>(acc[fn][4 * g + 1] + bb.y);
-            v[4 * g + 2] = apply_act<ACT>(acc[fn][4 * g + 2] + bb.z); v[4 * g + 3] = apply_act<ACT>(acc[fn][4 * g + 3] + bb.w);
+            v[4 * g + 0] = acc[fn][4 * g + 0] + bb.x; v[4 * g + 1] = acc[fn][4 * g + 1] + bb.y;
+            v[4 * g + 2] = acc[fn][4 * g + 2] + bb.z; v[4 * g + 3] = acc[fn][4 * g + 3] + bb.w;
+            apply_act4<ACT>(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(v[4 * g + j]));
         }
@@ -95,7 +96,7 @@ __device__ __forceinline__ void epilogue_mxfp8_rows32(const GemmF8Args& a, const
         for (int g = 0; g < 4; ++g)
             *(unsigned*)(lds + ml * S::RS + 32 * fn + 8 * g + 4 * h) =
                 pack_fp8x4(v[4 * g + 0] * inv, v[4 * g + 1] * inv, v[4 * g + 2] * inv, v[4 * g + 3] * inv);
-        if (h == 0 && m < a.g.M && ncol0 + 32 * fn < a.g.N) a.out_scale[(size_t)m * a.ldos + ((ncol0 + 32 * fn) >> 5)] = (uint8_t)e;
+        if (h == 0 && m < a.g.M && ncol0 + 32 * fn < a.g.N) a.out_scale[mx_scale_index(m, (ncol0 + 32 * fn) >> 5, a.os_rows)] = (uint8_t)e;
     }
 #pragma unroll
     for (int it = 0; it < (S::CH + 1) / 2; ++it) {
@@ -155,18 +156,23 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const GemmF8Args a) 
     const int xrow_off = (wm * 32 * FM + frow) * RB;
     const int wrow_off = XT + (wn * 32 * FN + frow) * RB;
 
-    // ---- scale words: one u32 (4 K blocks) per row and stage, straight to registers
+    // ---- scale words: the 4 K blocks of a stage per row = two adjacent-pair u16 loads, straight to registers
     const uint8_t* xsp[FM]; const uint8_t* wsp[FN];
 #pragma unroll
-    for (int f = 0; f < FM; ++f) { int r = m0 + wm * 32 * FM + f * 32 + frow; r = r < M ? r : M - 1; xsp[f] = a.XS + (size_t)r * a.ldxs; }
+    for (int f = 0; f < FM; ++f) { int r = m0 + wm * 32 * FM + f * 32 + frow; r = r < M ? r : M - 1; xsp[f] = a.XS + (size_t)r * 2; }
 #pragma unroll
-    for (int f = 0; f < FN; ++f) { int r = n0 + wn * 32 * FN + f * 32 + frow; r = r < N ? r : N - 1; wsp[f] = a.WS + (size_t)r * (K >> 5); }
+    for (int f = 0; f < FN; ++f) { int r = n0 + wn * 32 * FN + f * 32 + frow; r = r < N ? r : N - 1; wsp[f] = a.WS + (size_t)r * 2; }
+    const size_t xs_step = (size_t)a.xs_rows * 2, ws_step = (size_t)a.ws_rows * 2;      // bytes per 64-wide K slice
     unsigned xs[FM], ws[FN], xs_n[FM], ws_n[FN];
     auto load_scales = [&](int kt, unsigned (&x)[FM], unsigned (&w)[FN]) {
 #pragma unroll
-        for (int f = 0; f < FM; ++f) x[f] = *(const unsigned*)(xsp[f] + 4 * kt);
+        for (int f = 0; f < FM; ++f)
+            x[f] = (unsigned)*(const unsigned short*)(xsp[f] + (size_t)(2 * kt) * xs_step) |
+                   ((unsigned)*(const unsigned short*)(xsp[f] + (size_t)(2 * kt + 1) * xs_step) << 16);
 #pragma unroll
-        for (int f = 0; f < FN; ++f) w[f] = *(const unsigned*)(wsp[f] + 4 * kt);
+        for (int f = 0; f < FN; ++f)
+            w[f] = (unsigned)*(const unsigned short*)(wsp[f] + (size_t)(2 * kt) * ws_step) |
+                   ((unsigned)*(const unsigned short*)(wsp[f] + (size_t)(2 * kt + 1) * ws_step) << 16);
     };
 
     f32x16_t acc[FM][FN];
@@ -252,6 +258,185 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const GemmF8Args a) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 8-wave variant (one workgroup per CU, tiles 256x256 / 256x192): the structure of gemm8_bf16_kernel (gemm_bf16.hip)
+// — K step = one 64-byte LDS row = ONE 64-wide MFMA per fragment pair, 4-slot ring, the two wave groups staggered by
+// one barrier (one in the matrix pipe while the other reads LDS) — so a step moves the same bytes and costs the same
+// MFMA cycles as the bf16 kernel's 32-wide step but contracts twice the K.  The scales ride along as ONE extra
+// 1-KiB LDS-DMA piece per step: lanes 0-31 fetch the X scales of 8 rows each (16 contiguous bytes in the
+// K-pair-major layout), lanes 32-63 the W scales; a lane then reads its (row, half) byte with ds_read_u8.
+template <int N> __device__ __forceinline__ void f8_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int FM, int FN, int WM, int WN, int EPI, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm8_mxfp8_kernel(const GemmF8Args a) {
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
+    constexpr int RB = 64;
+    constexpr int XT = BM * RB, WT = BN * RB, SC = 1024, STAGE = XT + WT + SC;
+    constexpr int NPT = (BM + BN) / 16;              // operand pieces (16 rows x 64 B) per step
+    constexpr int NP = NPT + 1;                      // + the scale piece
+    constexpr int NPW_HI = (NP + 7) / 8, NPW_LO = NP / 8;
+    constexpr int NMF = FM * FN;
+    static_assert(WM * WN == 8, "8 waves");
+    static_assert(BM <= 256 && BN <= 256, "one scale piece covers 256 + 256 rows");
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int group = wave >> 2;
+    const int wm = wave / WN, wn = wave % WN;
+    const bool hi = wave < (NP % 8 == 0 ? 8 : NP % 8);
+    const int M = a.g.M, N = a.g.N, K = a.g.K;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+    const int srow = lane >> 2, spos = lane & 3;
+    const uint8_t* gp[NPW_HI];
+    long gstep[NPW_HI];                              // bytes per K step of that piece's source
+    int lds_off[NPW_HI];
+#pragma unroll
+    for (int i = 0; i < NPW_HI; ++i) {
+        int p = wave + 8 * i;
+        p = p < NP ? p : NP - 1;
+        if (p == NPT) {                              // the scale piece
+            if (lane < 32) { long r = m0 + 8 * lane; r = r + 8 <= a.xs_rows ? r : a.xs_rows - 8; gp[i] = a.XS + r * 2; gstep[i] = a.xs_rows * 2; }
+            else { long r = n0 + 8 * (lane - 32); r = r + 8 <= a.ws_rows ? r : a.ws_rows - 8; gp[i] = a.WS + r * 2; gstep[i] = a.ws_rows * 2; }
+            lds_off[i] = XT + WT;
+        } else {
+            const bool isx = p < BM / 16;
+            const int r = (isx ? p : p - BM / 16) * 16 + srow;
+            const int c = spos ^ ((r >> 2) & 3);
+            if (isx) { int xm = m0 + r; xm = xm < M ? xm : M - 1; gp[i] = a.X8 + (size_t)xm * a.ldx8 + c * 16; }
+            else { int wr = n0 + r; wr = wr < N ? wr : N - 1; gp[i] = a.W8 + (size_t)wr * K + c * 16; }
+            gstep[i] = RB;
+            lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / 16) * 1024;
+        }
+    }
+    auto stage = [&](int ks, int slot) {
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < NPW_HI; ++i)
+            if (i < NPW_LO || hi) glds16b(gp[i] + (size_t)ks * gstep[i], base + lds_off[i]);
+    };
+    auto wait_steps = [&](int nsteps_in_flight) {
+        if (hi) {
+            if (nsteps_in_flight >= 2) f8_wait_vmcnt<2 * NPW_HI>(); else if (nsteps_in_flight == 1) f8_wait_vmcnt<NPW_HI>(); else f8_wait_vmcnt<0>();
+        } else {
+            if (nsteps_in_flight >= 2) f8_wait_vmcnt<2 * NPW_LO>(); else if (nsteps_in_flight == 1) f8_wait_vmcnt<NPW_LO>(); else f8_wait_vmcnt<0>();
+        }
+    };
+
+    const int frow = lane & 31;
+    const int swz = (lane >> 2) & 3;
+    const int fhalf = lane >> 5;
+    const int koff0 = (((0 + fhalf) ^ swz) << 4), koff1 = (((2 + fhalf) ^ swz) << 4);
+    const int xrow_off = (wm * 32 * FM + frow) * RB;
+    const int wrow_off = XT + (wn * 32 * FN + frow) * RB;
+    const int xsc_off = XT + WT + (wm * 32 * FM + frow) * 2 + fhalf;
+    const int wsc_off = XT + WT + 512 + (wn * 32 * FN + frow) * 2 + fhalf;
+
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = K / 64;
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    if (nt > 2) stage(2, 2);
+    wait_steps(nt > 2 ? 2 : nt - 1);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    if (group == 1) __builtin_amdgcn_s_barrier();    // stagger: group 1 runs one barrier behind
+    int slot = 0;
+    for (int s = 0; s < nt; ++s) {
+        const char* sb = smem + slot * STAGE;
+        // ---- A: fragments + scales of step s; retire step s+1
+        F8_FENCE();
+        v8i_t xf[FM], wf[FN];
+        int xsc[FM], wsc[FN];
+#pragma unroll
+        for (int f = 0; f < FM; ++f) {
+            const uint4 lo = *(const uint4*)(sb + xrow_off + f * 32 * RB + koff0);
+            const uint4 hi4 = *(const uint4*)(sb + xrow_off + f * 32 * RB + koff1);
+            xf[f] = (v8i_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi4.x, (int)hi4.y, (int)hi4.z, (int)hi4.w};
+            xsc[f] = *(const uint8_t*)(sb + xsc_off + f * 64);
+        }
+#pragma unroll
+        for (int f = 0; f < FN; ++f) {
+            const uint4 lo = *(const uint4*)(sb + wrow_off + f * 32 * RB + koff0);
+            const uint4 hi4 = *(const uint4*)(sb + wrow_off + f * 32 * RB + koff1);
+            wf[f] = (v8i_t){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi4.x, (int)hi4.y, (int)hi4.z, (int)hi4.w};
+            wsc[f] = *(const uint8_t*)(sb + wsc_off + f * 64);
+        }
+        {
+            const int after = nt - 2 - s;
+            wait_steps(after >= 1 ? 1 : 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        F8_FENCE();
+        __builtin_amdgcn_s_barrier();
+        F8_FENCE();
+        // ---- B: MFMAs of step s with the LDS-DMA of step s+3 spread between them (slot of step s-1)
+        const bool dma = s + 3 < nt;
+        char* dbase = smem + ((slot + 3) & 3) * STAGE;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NMF; ++i) {
+            const int fm = i / FN, fn = i % FN;
+            acc[fm][fn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[fn], xf[fm], acc[fm][fn], 0, 0, 0, wsc[fn], 0, xsc[fm]);
+#pragma unroll
+            for (int q = 0; q < NPW_HI; ++q) {
+                if (((q + 1) * NMF + NPW_HI - 1) / NPW_HI - 1 == i) {
+                    F8_FENCE();
+                    if (dma && (q < NPW_LO || hi)) glds16b(gp[q] + (size_t)(s + 3) * gstep[q], dbase + lds_off[q]);
+                    F8_FENCE();
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        F8_FENCE();
+        __builtin_amdgcn_s_barrier();
+        slot = (slot + 1) & 3;
+    }
+    if (group == 0) __builtin_amdgcn_s_barrier();    // pairs with group 1's extra barrier
+
+    if constexpr (EPI == EPI_MXFP8) {
+        static_assert(8 * StagedF8<FN>::BYTES <= 4 * STAGE, "epilogue staging must fit the ring");
+        __builtin_amdgcn_s_barrier();
+        char* my = smem + wave * StagedF8<FN>::BYTES;
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+            epilogue_mxfp8_rows32<FN, ACT>(a, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
+    } else {
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                epilogue_swapped<EPI, ACT>(a.g, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+    }
+}
+
+template <int FM, int FN, int WM, int WN, int EPI, int ACT>
+static int launch_f8_8(const GemmF8Args& a, hipStream_t s) {
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
+    constexpr int LDS = 4 * ((BM + BN) * 64 + 1024);
+    if ((a.xs_rows & 7) || (a.ws_rows & 7) || a.xs_rows < 8 || a.ws_rows < 8) { syl_set_error("launch_gemm_mxfp8", "scale pitches must be multiples of 8"); return 1; }
+    const int tiles = ((a.g.M + BM - 1) / BM) * ((a.g.N + BN - 1) / BN);
+    static bool attr_set = false;
+    auto kern = gemm8_mxfp8_kernel<FM, FN, WM, WN, EPI, ACT>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int FM, int FN, int EPI, int ACT>
 static int launch_f8(const GemmF8Args& a, hipStream_t s) {
     constexpr int BM = 64 * FM, BN = 64 * FN;
@@ -268,19 +453,30 @@ static int launch_f8(const GemmF8Args& a, hipStream_t s) {
     return 0;
 }
 
-static int g_f8_cfg = 0;            // 0 = 128x192, 1 = 128x128
+// tile configurations: 0 = 128x192 (4 waves, 2 workgroups/CU), 1 = 128x128 (same), 2 = 256x256 (8 waves), 3 = 256x192
+// (8 waves); -1 = automatic: the 8-wave tile whose launch needs the fewest rounds over 256 CUs
+static int g_f8_cfg = -1;
 void gemm_mxfp8_force_cfg(int cfg) { g_f8_cfg = cfg; }
 
 template <int EPI, int ACT>
 static int launch_f8_t(const GemmF8Args& a, hipStream_t s) {
-    if (g_f8_cfg == 1) return launch_f8<2, 2, EPI, ACT>(a, s);
+    int cfg = g_f8_cfg;
+    if (cfg < 0) {
+        const long t2 = (long)((a.g.M + 255) / 256) * ((a.g.N + 255) / 256), t3 = (long)((a.g.M + 255) / 256) * ((a.g.N + 191) / 192);
+        const double c2 = (double)((t2 + 255) / 256) * 256 * 256, c3 = (double)((t3 + 255) / 256) * 256 * 192;
+        cfg = c2 <= c3 ? 2 : 3;
+    }
+    if (cfg == 1) return launch_f8<2, 2, EPI, ACT>(a, s);
+    if (cfg == 2) return launch_f8_8<4, 2, 2, 4, EPI, ACT>(a, s);
+    if (cfg == 3) return launch_f8_8<2, 3, 4, 2, EPI, ACT>(a, s);
     return launch_f8<2, 3, EPI, ACT>(a, s);
 }
 
 int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s) {
     if (a.g.K % 128 != 0 || a.g.K <= 0 || a.g.M <= 0 || a.g.N <= 0) { syl_set_error("launch_gemm_mxfp8", "K must be a positive multiple of 128"); return 1; }
     if (a.g.N % 4 != 0) { syl_set_error("launch_gemm_mxfp8", "N must be a multiple of 4"); return 1; }
-    if ((a.ldx8 & 15) || (a.ldxs & 3)) { syl_set_error("launch_gemm_mxfp8", "operand rows must be 16-byte / scale rows 4-byte aligned"); return 1; }
+    if (a.g.K % 128 != 0) { syl_set_error("launch_gemm_mxfp8", "K must be a multiple of 128"); return 1; }
+    if (a.ldx8 & 15) { syl_set_error("launch_gemm_mxfp8", "operand rows must be 16-byte aligned"); return 1; }
     switch (epi) {
         case EPI_MXFP8:
             if (a.g.N % 32 != 0) { syl_set_error("launch_gemm_mxfp8", "MXFP8 output needs N % 32 == 0"); return 1; }

@@ -37,19 +37,21 @@ struct GemmArgs {
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
 
-// MXFP8 GEMM (gemm_mxfp8.hip): e4m3 operands [rows][K] with one E8M0 scale per 32 elements along K, [rows][K/32];
+// MXFP8 GEMM (gemm_mxfp8.hip): e4m3 operands [rows][K] with one E8M0 scale per 32 elements along K stored
+// K-pair-major [K/64][rows_pitch][2] (common.h mx_scale_index; pitches are multiples of 8, and the scale arrays of
+// the activations are allocated for M rounded up to 256 rows);
 // `g` carries M, N, K, bias, act, the outputs and the residual / LayerNorm fields (g.X, g.W, g.ldx are unused)
 struct GemmF8Args {
     GemmArgs g;
     const uint8_t* X8; long ldx8;
-    const uint8_t* XS; long ldxs;
+    const uint8_t* XS; long xs_rows;
     const uint8_t* W8;              // [N][K]
-    const uint8_t* WS;              // [N][K/32]
-    uint8_t* out_scale; long ldos;  // EPI_MXFP8
+    const uint8_t* WS; long ws_rows;
+    uint8_t* out_scale; long os_rows;  // EPI_MXFP8: scales of the output, pitch os_rows
 };
 int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s);   // epi: EPI_MXFP8, EPI_F32, EPI_F32_RESLN
 void gemm_mxfp8_force_cfg(int cfg);
-int launch_mx_quant_rows(const float* in, long ld_in, uint8_t* out, long ld_out, uint8_t* sc, long ld_sc, int R, int K, hipStream_t s);
+int launch_mx_quant_rows(const float* in, long ld_in, uint8_t* out, long ld_out, uint8_t* sc, long sc_rows, int R, int K, hipStream_t s);
 void gemm_force_cfg(int cfg);   // -1 = automatic tile-shape choice
 void gemm_set_wg_per_cu(int k); // 4-wave GEMM: 0 = one workgroup per tile, k = persistent launch of k x 256 workgroups
 
@@ -88,7 +90,7 @@ struct LnArgs {
     float* out_f32; long ld_f32;
     bf16_t* out_bf16; long ld_bf16;
     uint8_t* out_fp8; long ld_fp8;        // optional MXFP8 copy of the output (D = 768): e4m3 rows +
-    uint8_t* out_scale; long ld_scale;    //   one E8M0 scale per 32 features
+    uint8_t* out_scale; long scale_rows;  //   one E8M0 scale per 32 features, K-pair-major with this row pitch
     float* out_stats;             // optional [M][2] (mean, rstd): lets a later GEMM epilogue re-apply this LayerNorm
     int M, D;
     int Tp, T;        // compaction of the f32 output (final hidden states); 0 = none

@@ -22,10 +22,10 @@ def _quant_gpu(x):
     xd = torch.from_numpy(x).cuda()
     R, K = x.shape
     d = torch.empty(R, K, dtype=torch.uint8, device="cuda")
-    s = torch.empty(R, K // 32, dtype=torch.uint8, device="cuda")
+    s = torch.empty(K // 64, R, 2, dtype=torch.uint8, device="cuda")        # K-pair-major scale layout of the library
     _lib.check(lib.sylber_op_mx_quantize(_p(xd), R, K, _p(d), _p(s), None), "mx_quantize")
     torch.cuda.synchronize()
-    return d.cpu().numpy(), s.cpu().numpy()
+    return d.cpu().numpy(), s.cpu().numpy().transpose(1, 0, 2).reshape(R, K // 32)
 
 
 def test_quantiser_bit_exact():
@@ -42,7 +42,9 @@ def test_quantiser_bit_exact():
 
 
 @pytest.mark.parametrize("M,N,K,act,cfg", [(300, 256, 128, 0, 0), (1000, 768, 3072, 0, 0), (515, 3072, 768, 1, 0),
-                                            (129, 100, 256, 0, 1), (2000, 192, 384, 0, 1)])
+                                            (129, 100, 256, 0, 1), (2000, 192, 384, 0, 1), (300, 256, 128, 0, 2),
+                                            (1000, 768, 3072, 0, 3), (515, 3072, 768, 1, 2), (129, 100, 256, 0, 3),
+                                            (2100, 500, 640, 0, 2), (777, 768, 768, 0, -1)])
 def test_mxfp8_linear_matches_oracle(M, N, K, act, cfg):
     from sylber_amd import _lib
     lib = _lib.load()
@@ -53,7 +55,7 @@ def test_mxfp8_linear_matches_oracle(M, N, K, act, cfg):
     bias = rng.standard_normal(N).astype(np.float32)
     ad, wd, bd = torch.from_numpy(a).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(bias).cuda()
     out = torch.empty(M, N, device="cuda")
-    lib.sylber_debug_force_gemm_cfg(-300 - cfg)
+    lib.sylber_debug_force_gemm_cfg(-301 - cfg)             # -300 = automatic tile, -301 - k = tile config k
     try:
         _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(out), M, N, K, act, 2, None), "op_linear fp8")
     finally:
@@ -75,7 +77,7 @@ def test_mxfp8_linear_matches_oracle(M, N, K, act, cfg):
         assert rel < 0.06
 
 
-@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
 def test_mxfp8_linear_exact_on_integer_data(cfg):
     """small integers and power-of-two block scales are exact in e4m3 x E8M0 and in the MFMA: any layout, OPSEL or
     scale-routing mistake shows up as a wrong integer"""
@@ -87,7 +89,7 @@ def test_mxfp8_linear_exact_on_integer_data(cfg):
     w = rng.integers(-2, 3, (N, K)).astype(np.float32) * (2.0 ** rng.integers(-2, 3, (N, K // 32))).repeat(32, 1).astype(np.float32)
     ad, wd = torch.from_numpy(a).cuda(), torch.from_numpy(w).cuda()
     out = torch.empty(M, N, device="cuda")
-    lib.sylber_debug_force_gemm_cfg(-300 - cfg)
+    lib.sylber_debug_force_gemm_cfg(-301 - cfg)
     try:
         _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), None, _p(out), M, N, K, 0, 2, None), "op_linear fp8")
     finally:
