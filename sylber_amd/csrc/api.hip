@@ -27,6 +27,7 @@ extern "C" int32_t sylber_num_frames(int32_t n) {
 struct LayerDev {
     bf16_t *wqkv, *wo, *w1, *w2;
     uint8_t *w1q = nullptr, *w1s = nullptr, *w2q = nullptr, *w2s = nullptr;   // SYLBER_FP8: MXFP8 FFN weights + E8M0 scales
+    uint8_t *wqkvq = nullptr, *wqkvs = nullptr;                                // and the fused q/k/v projection
     float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
 };
 
@@ -159,7 +160,8 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
     if (precision == SYLBER_FP8) {
         // FFN weights once more as MXFP8 (e4m3 + one E8M0 scale per 32 input features), quantised on the device
         // from the fp32 originals with the same kernel the activations' op-level entry point uses
-        const size_t per_layer = (size_t)3072 * 768 + (size_t)3072 * 24 + (size_t)768 * 3072 + (size_t)768 * 96;
+        const size_t per_layer = (size_t)3072 * 768 + (size_t)3072 * 24 + (size_t)768 * 3072 + (size_t)768 * 96 +
+                                 (size_t)2304 * 768 + (size_t)2304 * 24;
         c->f8bytes = per_layer * w->num_layers;
         float* tmp = nullptr;
         if (hipMalloc((void**)&c->f8base, c->f8bytes) != hipSuccess || hipMalloc((void**)&tmp, (size_t)3072 * 768 * 4) != hipSuccess) {
@@ -171,6 +173,15 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
             LayerDev& d = c->L[l];
             uint8_t* q = (uint8_t*)c->f8base + per_layer * l;
             d.w1q = q; d.w1s = d.w1q + (size_t)3072 * 768; d.w2q = d.w1s + (size_t)3072 * 24; d.w2s = d.w2q + (size_t)768 * 3072;
+            d.wqkvq = d.w2s + (size_t)768 * 96; d.wqkvs = d.wqkvq + (size_t)2304 * 768;
+            {
+                const SylberLayerWeights& lw = w->layers[l];
+                bad |= hipMemcpy(tmp, lw.q_w, (size_t)768 * 768 * 4, hipMemcpyHostToDevice) != hipSuccess;
+                bad |= hipMemcpy(tmp + (size_t)768 * 768, lw.k_w, (size_t)768 * 768 * 4, hipMemcpyHostToDevice) != hipSuccess;
+                bad |= hipMemcpy(tmp + (size_t)2 * 768 * 768, lw.v_w, (size_t)768 * 768 * 4, hipMemcpyHostToDevice) != hipSuccess;
+                bad |= launch_mx_quant_rows(tmp, 768, d.wqkvq, 768, d.wqkvs, 2304, 2304, 768, nullptr);
+                bad |= hipDeviceSynchronize() != hipSuccess;
+            }
             bad |= hipMemcpy(tmp, w->layers[l].ff1_w, (size_t)3072 * 768 * 4, hipMemcpyHostToDevice) != hipSuccess;
             bad |= launch_mx_quant_rows(tmp, 768, d.w1q, 768, d.w1s, 3072, 3072, 768, nullptr);
             bad |= hipDeviceSynchronize() != hipSuccess;
@@ -387,7 +398,7 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         else { a.out_bf16 = hbf; a.ld_bf16 = 768; a.out_stats = stats; }   // no fp32 copy: see EPI_F32_RESLN
         return launch_layernorm(a, s);
     };
-    RUN("layernorm", run_ln(c->enc_ln_w, c->enc_ln_b, c->stop_stage == 2));
+    RUN("layernorm", run_ln(c->enc_ln_w, c->enc_ln_b, c->stop_stage == 2, f8));
     if (c->stop_stage == 2) return 0;
     // the residual of every block is the previous LayerNorm's output; it is re-derived in the GEMM epilogue from
     // the pre-LN sum still sitting in `pre` (updated in place) + that LayerNorm's row statistics and affine
@@ -396,12 +407,22 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
     for (int l = 0; l < c->num_layers; ++l) {
         const LayerDev& d = c->L[l];
         const bool last = (l == c->num_layers - 1) || (c->stop_stage == 3 + l);
+        if (f8) {
+            GemmF8Args g = {};
+            g.g.M = M; g.g.N = 1536; g.g.K = 768; g.g.bias = d.bqkv; g.g.out0 = q; g.g.out1 = k; g.g.out2 = vt;
+            g.g.Tp = p.Tp; g.g.Tpv = p.Tpv; g.g.T = p.T;
+            g.X8 = h8; g.ldx8 = 768; g.XS = h8s; g.xs_rows = Mp; g.W8 = d.wqkvq; g.WS = d.wqkvs; g.ws_rows = 2304;
+            RUN("gemm_qk", launch_gemm_mxfp8(EPI_QK, g, s));
+            g.W8 = d.wqkvq + (size_t)1536 * 768; g.WS = d.wqkvs + (size_t)1536 * 2; g.g.bias = d.bqkv + 1536; g.g.N = 768;
+            RUN("gemm_v", launch_gemm_mxfp8(EPI_V, g, s));
+        } else {
         GemmArgs g = {};
         g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 1536; g.K = 768; g.bias = d.bqkv;
         g.out0 = q; g.out1 = k; g.out2 = vt; g.Tp = p.Tp; g.Tpv = p.Tpv; g.T = p.T;
         RUN("gemm_qk", launch_gemm_bf16(EPI_QK, g, s));
         g.W = d.wqkv + (size_t)1536 * 768; g.bias = d.bqkv + 1536; g.N = 768;
         RUN("gemm_v", launch_gemm_bf16(EPI_V, g, s));
+        }
         RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, s));
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
@@ -428,7 +449,7 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         f2.out0 = pre; f2.ld0 = 768; f2.res = pre; f2.ldres = 768; f2.ln_stats = stats; f2.ln_gamma = d.ln1w; f2.ln_beta = d.ln1b;
         RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RESLN, f2, s));
         }
-        RUN("layernorm", run_ln(d.ln2w, d.ln2b, last));
+        RUN("layernorm", run_ln(d.ln2w, d.ln2b, last, f8));
         res_g = d.ln2w; res_b = d.ln2b;
         if (last) break;
     }

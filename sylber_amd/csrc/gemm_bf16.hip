@@ -29,120 +29,6 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 #include "gemm_epilogue.h"
 
-// V projection (its own launch, EPI_V), NATURAL orientation: lane owns feature n (column l&31) and 16
-// tokens m = mb + (r&3) + 8*(r>>2) + 4*(l>>5): four runs of 4 consecutive tokens -> 8-byte stores
-// into the key-contiguous Vt[b][head][d][t] image the attention kernel reads as MFMA A-operand.
-__device__ __forceinline__ void epilogue_v_natural(const GemmArgs& a, const f32x16_t& acc, int mb, int n, int lane) {
-    if (n >= a.N) return;
-    const int h = lane >> 5;
-    const float bias = a.bias ? a.bias[n] : 0.f;
-    const int nn = n;                            // the V launch has its own weight/bias slice: N = 768
-    const int head = nn >> 6, d = nn & 63;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int m = mb + 8 * g + 4 * h;       // multiple of 4; Tp % 4 == 0 so the run stays in one utterance
-        if (m >= a.M) continue;
-        const int b = m / a.Tp, t = m - b * a.Tp;
-        // key axis stored with bits 2 and 3 swapped: a 16-B chunk then holds exactly the 8 keys one
-        // half-wave contributes to a 16-key P.V MFMA (see attention.hip)
-        const int pos = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
-        uint2 pk;
-        pk.x = pack_bf16x2(acc[4 * g + 0] + bias, acc[4 * g + 1] + bias);
-        pk.y = pack_bf16x2(acc[4 * g + 2] + bias, acc[4 * g + 3] + bias);
-        *(uint2*)((bf16_t*)a.out2 + (((size_t)b * SYL_HEADS + head) * 64 + d) * a.Tpv + pos) = pk;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Coalesced epilogue through LDS (swapped orientation).  Straight from the MFMA layout a lane owns ONE
-// output row and runs of 4 columns, so a store instruction would touch 32 rows with 16-32 bytes each
-// (measured: 20-48 % of the kernel on the hot-path shapes).  Instead every wave transposes one 32-row block
-// of its tile through a private LDS region (row stride padded by 16 B: 2-way worst case on ds_write_b64)
-// and reads it back as 16-byte chunks with consecutive lanes on consecutive chunks of a row, so global
-// loads (fp32 residual) and stores run over whole 128-byte lines.  Bias / activation / q-scaling / padded
-// frame zeroing are applied on the way in; the residual add on the way out.
-template <int FN, int EPI>
-struct StagedEpi {
-    static constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_F32_RES || EPI == EPI_F32_RESLN || EPI == EPI_PROJ);
-    static constexpr int ES = F32OUT ? 4 : 2;
-    static constexpr int ROWB = 32 * FN * ES;       // payload bytes per row
-    static constexpr int RS = ROWB + 16;            // padded row stride
-    static constexpr int CH = ROWB / 16;            // 16-byte chunks per row
-    static constexpr int BYTES = 32 * RS;           // private LDS bytes per wave
-};
-
-template <int FN, int EPI, int ACT>
-__device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_t (&acc)[FN], int mrow0, int ncol0, char* lds,
-                                                int lane) {
-    using S = StagedEpi<FN, EPI>;
-    const int ml = lane & 31, h = lane >> 5;
-    const int m = mrow0 + ml;
-    // ---- in: MFMA layout -> row-major LDS
-    bool zero_row = false;
-    if constexpr (EPI == EPI_PROJ) {
-        const int mm = m < a.M ? m : a.M - 1;
-        const int b = mm / a.Tp, t = mm - b * a.Tp;
-        const int nv = a.valid[b] < a.T ? a.valid[b] : a.T;
-        zero_row = t >= nv;                              // TP:428-431 zero padded frames (and rows beyond T)
-    }
-#pragma unroll
-    for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nl = 32 * fn + 8 * g + 4 * h;
-            const int n = ncol0 + nl;
-            float v0 = acc[fn][4 * g + 0], v1 = acc[fn][4 * g + 1], v2 = acc[fn][4 * g + 2], v3 = acc[fn][4 * g + 3];
-            if (a.bias && n < a.N) {
-                const float4 bb = *(const float4*)(a.bias + n);
-                v0 += bb.x; v1 += bb.y; v2 += bb.z; v3 += bb.w;
-            }
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_F32) {
-                apply_act4<ACT>(v0, v1, v2, v3);
-            }
-            if constexpr (EPI == EPI_QK) {
-                if (n < SYL_HIDDEN) { v0 *= 0.125f; v1 *= 0.125f; v2 *= 0.125f; v3 *= 0.125f; }
-            }
-            if constexpr (EPI == EPI_PROJ) { if (zero_row) { v0 = v1 = v2 = v3 = 0.f; } }
-            if constexpr (S::F32OUT) {
-                *(float4*)(lds + ml * S::RS + nl * 4) = make_float4(v0, v1, v2, v3);
-            } else {
-                uint2 pk; pk.x = pack_bf16x2(v0, v1); pk.y = pack_bf16x2(v2, v3);
-                *(uint2*)(lds + ml * S::RS + nl * 2) = pk;
-            }
-        }
-    // ---- out: 16-byte chunks, consecutive lanes on consecutive chunks of a row
-#pragma unroll
-    for (int it = 0; it < S::CH / 2; ++it) {
-        const int idx = it * 64 + lane;
-        const int r = idx / S::CH, c = idx - r * S::CH;
-        const int mo = mrow0 + r;
-        const int n = ncol0 + c * (16 / S::ES);
-        if (mo >= a.M || n >= a.N) continue;
-        const uint4 raw = *(const uint4*)(lds + r * S::RS + c * 16);
-        if constexpr (EPI == EPI_BF16) {
-            *(uint4*)((bf16_t*)a.out0 + (size_t)mo * a.ld0 + n) = raw;
-        } else if constexpr (EPI == EPI_F32) {
-            *(uint4*)((float*)a.out0 + (size_t)mo * a.ld0 + n) = raw;
-        } else if constexpr (EPI == EPI_F32_RES) {
-            const float4 rr = *(const float4*)(a.res + (size_t)mo * a.ldres + n);
-            const float4 v = __builtin_bit_cast(float4, raw);
-            *(float4*)((float*)a.out0 + (size_t)mo * a.ld0 + n) = make_float4(v.x + rr.x, v.y + rr.y, v.z + rr.z, v.w + rr.w);
-        } else if constexpr (EPI == EPI_QK) {
-            const int which = n >= SYL_HIDDEN;
-            const int nn = n - which * SYL_HIDDEN;
-            const int head = nn >> 6, d = nn & 63;
-            const int b = mo / a.Tp, t = mo - b * a.Tp;
-            *(uint4*)((bf16_t*)(which ? a.out1 : a.out0) + (((size_t)b * SYL_HEADS + head) * a.Tp + t) * 64 + d) = raw;
-        } else if constexpr (EPI == EPI_PROJ) {
-            const float4 v = __builtin_bit_cast(float4, raw);
-            *(float4*)((float*)a.out0 + (size_t)mo * a.ld0 + n) = v;
-            const int b = mo / a.Tp, t = mo - b * a.Tp;
-            uint2 pk; pk.x = pack_bf16x2(v.x, v.y); pk.y = pack_bf16x2(v.z, v.w);
-            *(uint2*)((bf16_t*)a.out1 + ((size_t)b * a.xpad_rows + 64 + t) * SYL_HIDDEN + n) = pk;
-        }
-    }
-}
-
 static int g_gemm_wg_per_cu = 0;   // 0 = one workgroup per tile; k = persistent launch of k x 256 workgroups
 void gemm_set_wg_per_cu(int k) { g_gemm_wg_per_cu = k; }
 

@@ -49,7 +49,7 @@ struct GemmF8Args {
     const uint8_t* WS; long ws_rows;
     uint8_t* out_scale; long os_rows;  // EPI_MXFP8: scales of the output, pitch os_rows
 };
-int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s);   // epi: EPI_MXFP8, EPI_F32, EPI_F32_RESLN
+int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s);   // epi: EPI_MXFP8, EPI_F32, EPI_F32_RESLN, EPI_QK, EPI_V
 void gemm_mxfp8_force_cfg(int cfg);
 int launch_mx_quant_rows(const float* in, long ld_in, uint8_t* out, long ld_out, uint8_t* sc, long sc_rows, int R, int K, hipStream_t s);
 void gemm_force_cfg(int cfg);   // -1 = automatic tile-shape choice
