@@ -106,6 +106,41 @@ int64_t sylber_ingest_workspace_bytes(int32_t sr_in);
 int sylber_ingest(const void* pcm_dev, int32_t sample_width, int32_t channels, int64_t frames_in, int32_t sr_in,
                   int32_t normalize, float* wav_out_dev, void* workspace_dev, void* stream);
 
+/* ---- the two callers right behind the path, on device-resident outputs of sylber_segment --- */
+/* N4: k-means tokenisation, KMQuantizer.get_indices (sylber/model/quantizer.py:86-111; codebook look-up of
+ * vector_quantize_pytorch's EuclideanCodebook: argmin_c ||x - c||, first index on ties).
+ *   feats_dev [n, D] fp32 (D % 16 == 0), centroids_dev [K, D] fp32, normalize != 0: x / sqrt(sum x^2 + 1e-8) * 6 first
+ *   idx_dev [n] int32; workspace_dev: sylber_km_workspace_floats(n, K, D) floats.  Exact-fp32 contraction. */
+int64_t sylber_km_workspace_floats(int32_t n, int32_t K, int32_t D);
+int sylber_km_assign(const float* feats_dev, int32_t n, const float* centroids_dev, int32_t K, int32_t D, int32_t normalize,
+                     int32_t* idx_dev, float* workspace_dev, void* stream);
+/* KMQuantizer.decode (quantizer.py:127-133): out[r] = centroids[clip(idx[r], 0)] */
+int sylber_km_decode(const int32_t* idx_dev, int32_t n, const float* centroids_dev, int32_t K, int32_t D, float* out_dev, void* stream);
+
+/* N3: front half of SegmentSynthesis.resynthesize (sylber/model/segment_synthesis.py:103-140): segment means broadcast
+ * back to their frames -> `MLP` conditioner (Linear -> RFF -> ... -> Linear, segment_synthesis.py:17-53) -> frames with
+ * hidden-state norm < norm_thr zeroed.  HOST pointers to fp32 tensors in nn.Linear / nn.LayerNorm layout. */
+#define SYLBER_MLP_MAX_HIDDEN 4
+typedef struct {
+    int32_t input_dim, output_dim, num_hidden;
+    int32_t hidden_dims[SYLBER_MLP_MAX_HIDDEN];                 /* each 512 or 768 */
+    struct {
+        const float *lin_w, *lin_b;                             /* mlp.{2i}: Linear(in, dim) */
+        const float *ff1_w, *ff1_b, *ff2_w, *ff2_b, *ln_w, *ln_b; /* mlp.{2i+1}: RFF.linear1 / linear2 / norm */
+    } hidden[SYLBER_MLP_MAX_HIDDEN];
+    const float *out_w, *out_b;                                 /* mlp.{2 num_hidden}: Linear(dim, output_dim) */
+} SylberMlpWeights;
+typedef struct sylber_mlp* sylber_mlp_t;
+int sylber_mlp_create(const SylberMlpWeights* w, int device, sylber_mlp_t* out);
+void sylber_mlp_destroy(sylber_mlp_t m);
+int64_t sylber_condition_workspace_floats(sylber_mlp_t m, int32_t B, int32_t S);
+/* hidden_dev [B,T,D], seg_dev [B,T,2], nseg_dev [B], feat_dev [B,T,D]: the buffers of sylber_forward / sylber_segment;
+ * S: segment slots per utterance to run through the MLP (max nseg <= S <= T);
+ * avg_hidden_dev [B,T,D] (nullable): averaged_target_hidden_states; cond_dev [B,T,output_dim]: the conditioning input */
+int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg_dev, const int32_t* nseg_dev, const float* feat_dev,
+                     int32_t B, int32_t T, int32_t S, float norm_thr, float* avg_hidden_dev, float* cond_dev, float* workspace_dev,
+                     void* stream);
+
 /* ---- introspection used by parity tests and the benchmark ------------------------------------ */
 /* run sylber_forward only up to a stage: 0 = all, 1 = conv stack, 2 = +projection/pos-conv/LN,
  * 3 + l = through encoder layer l.  The stage output is written to hidden_dev in place of the final

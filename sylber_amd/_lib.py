@@ -19,6 +19,16 @@ class SylberLayerWeights(ctypes.Structure):
         "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ln2_w", "ln2_b")]
 
 
+class SylberMlpHidden(ctypes.Structure):
+    _fields_ = [(n, c_float_p) for n in ("lin_w", "lin_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ln_w", "ln_b")]
+
+
+class SylberMlpWeights(ctypes.Structure):
+    """mirror of SylberMlpWeights in include/sylber_hip.h"""
+    _fields_ = [("input_dim", c_int32), ("output_dim", c_int32), ("num_hidden", c_int32), ("hidden_dims", c_int32 * 4),
+                ("hidden", SylberMlpHidden * 4), ("out_w", c_float_p), ("out_b", c_float_p)]
+
+
 class SylberWeights(ctypes.Structure):
     _fields_ = [("num_layers", c_int32), ("conv_w", c_float_p * 7), ("gn_w", c_float_p), ("gn_b", c_float_p),
                 ("fp_ln_w", c_float_p), ("fp_ln_b", c_float_p), ("fp_w", c_float_p), ("fp_b", c_float_p),
@@ -47,6 +57,14 @@ EXPORTS = {
     "sylber_ingest_num_frames": (c_int64, [c_int64, c_int32]),
     "sylber_ingest_workspace_bytes": (c_int64, [c_int32]),
     "sylber_ingest": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "sylber_km_workspace_floats": (c_int64, [c_int32, c_int32, c_int32]),
+    "sylber_km_assign": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "sylber_km_decode": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "sylber_mlp_create": (c_int, [POINTER(SylberMlpWeights), c_int, POINTER(c_void_p)]),
+    "sylber_mlp_destroy": (None, [c_void_p]),
+    "sylber_condition_workspace_floats": (c_int64, [c_void_p, c_int32, c_int32]),
+    "sylber_condition": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
     "sylber_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                     c_void_p]),
 }

@@ -1,0 +1,259 @@
+// The two callers right behind the Segmenter path, fed with device-resident outputs
+// of sylber_segment:
+//   N4  k-means tokenisation of the pooled segment features: KMQuantizer.get_indices / decode
+//       (sylber/model/quantizer.py:86-135; the codebook look-up itself is vector_quantize_pytorch's
+//       EuclideanCodebook — a third-party dependency absent from the image — : indices = argmax_c -cdist(x, c))
+//   N3  front half of SegmentSynthesis.resynthesize (sylber/model/segment_synthesis.py:103-140): every frame of a
+//       segment takes the segment's mean feature, the `MLP` conditioner (Linear -> RFF -> ... -> Linear, :17-53)
+//       maps it to the conditioning embedding, frames whose hidden-state norm is below the threshold are zeroed.
+// Both are small next to the encoder (tens of GFLOP); they run in exact fp32 on the f32 MFMA GEMM of the parity
+// mode (fp32_path.hip) so that near-ties of the arg-min and the LayerNorms see the reference's arithmetic class.
+#include "kernels.h"
+#include "../../include/sylber_hip.h"
+#include <cstring>
+#include <vector>
+
+// ---- N4 ---------------------------------------------------------------------------------------------------------
+// token / (||token|| + eps-under-the-root) * 6  (quantizer.py:104-105: token/(((token**2).sum(-1)+1e-8)**.5)[...,None]*6)
+__global__ __launch_bounds__(256) void km_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int D) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= n) return;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = x[(size_t)r * D + c]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    const float nrm = sqrtf(s + 1e-8f);
+    for (int c = lane; c < D; c += 64) y[(size_t)r * D + c] = x[(size_t)r * D + c] / nrm * 6.0f;
+}
+__global__ __launch_bounds__(256) void km_sqnorm_kernel(const float* __restrict__ c, float* __restrict__ out, int K, int D) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= K) return;
+    float s = 0.f;
+    for (int j = lane; j < D; j += 64) { const float v = c[(size_t)r * D + j]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+// idx[r] = argmin_c (||c||^2 - 2 x.c)  (the ||x||^2 term and the square root of cdist are monotone / constant per
+// row); ties -> the smallest index, like argmax over -cdist returns the first maximum
+__global__ __launch_bounds__(256) void km_argmin_kernel(const float* __restrict__ dots, long ld, const float* __restrict__ cn,
+                                                        int32_t* __restrict__ idx, int n, int K) {
+    __shared__ float bv[4]; __shared__ int bi[4];
+    const int r = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float best = INFINITY; int besti = 0x7fffffff;
+    for (int c = threadIdx.x; c < K; c += 256) {
+        const float d = fmaf(-2.0f, dots[(size_t)r * ld + c], cn[c]);
+        if (d < best || (d == best && c < besti)) { best = d; besti = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(besti, o, 64);
+        if (ov < best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) if (bv[w] < best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        idx[r] = besti;
+    }
+}
+
+extern "C" int64_t sylber_km_workspace_floats(int32_t n, int32_t K, int32_t D) {
+    if (n < 1 || K < 1 || D < 1) return -1;
+    return (int64_t)n * ((K + 3) & ~3) + (int64_t)n * D + ((K + 3) & ~3) + 64;
+}
+
+extern "C" int sylber_km_assign(const float* feats_dev, int32_t n, const float* centroids_dev, int32_t K, int32_t D, int32_t normalize,
+                                int32_t* idx_dev, float* workspace_dev, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!feats_dev || !centroids_dev || !idx_dev || !workspace_dev) { syl_set_error("sylber_km_assign", "null argument"); return 1; }
+    if (n < 1 || K < 1 || D < 16 || D % 16) { syl_set_error("sylber_km_assign", "need n, K >= 1 and D a multiple of 16"); return 1; }
+    const int Kp = (K + 3) & ~3;
+    float* dots = workspace_dev;                         // [n][Kp]
+    float* xn = dots + (size_t)n * Kp;                   // [n][D] (normalised copy)
+    float* cn = xn + (size_t)n * D;                      // [Kp]
+    const float* x = feats_dev;
+    if (normalize) {
+        hipLaunchKernelGGL(km_normalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, feats_dev, xn, n, D);
+        x = xn;
+    }
+    hipLaunchKernelGGL(km_sqnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, s, centroids_dev, cn, K, D);
+    HIP_TRY(hipGetLastError());
+    // x . c on the exact-fp32 MFMA GEMM; N must be a multiple of 4: the last (Kp - K) columns re-read centroid K-1
+    GemmArgsF32 g = {};
+    g.X = x; g.ldx = D; g.W = centroids_dev; g.M = n; g.N = K; g.K = D; g.out0 = dots; g.ld0 = Kp;
+    if (K % 4) {
+        // run the aligned part on the GEMM and leave the ragged tail to a second, 4-wide launch over the last 4 rows
+        g.N = K & ~3;
+        if (g.N > 0 && launch_gemm_f32(g, s)) return 1;
+        GemmArgsF32 t = g;
+        t.W = centroids_dev + (size_t)(K - 4 < 0 ? 0 : K - 4) * D; t.N = 4; t.out0 = dots + (K - 4 < 0 ? 0 : K - 4);
+        if (K >= 4) { if (launch_gemm_f32(t, s)) return 1; }
+        else { syl_set_error("sylber_km_assign", "K < 4 with K % 4 != 0 is not supported"); return 1; }
+    } else if (launch_gemm_f32(g, s)) return 1;
+    hipLaunchKernelGGL(km_argmin_kernel, dim3(n), dim3(256), 0, s, dots, (long)Kp, cn, idx_dev, n, K);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// KMQuantizer.decode (quantizer.py:127-133): rows of the codebook; negative indices are clipped to 0
+__global__ __launch_bounds__(256) void km_decode_kernel(const int32_t* __restrict__ idx, const float* __restrict__ c, float* __restrict__ out,
+                                                        int n, int K, int D) {
+    const int r = blockIdx.x;
+    int i = idx[r]; i = i < 0 ? 0 : (i >= K ? K - 1 : i);
+    for (int j = threadIdx.x; j < D; j += 256) out[(size_t)r * D + j] = c[(size_t)i * D + j];
+}
+extern "C" int sylber_km_decode(const int32_t* idx_dev, int32_t n, const float* centroids_dev, int32_t K, int32_t D, float* out_dev, void* stream) {
+    if (!idx_dev || !centroids_dev || !out_dev || n < 1 || K < 1 || D < 1) { syl_set_error("sylber_km_decode", "bad argument"); return 1; }
+    hipLaunchKernelGGL(km_decode_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, idx_dev, centroids_dev, out_dev, n, K, D);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- N3 ---------------------------------------------------------------------------------------------------------
+struct sylber_mlp {
+    int device = 0, input_dim = 0, output_dim = 0, num_hidden = 0, dims[SYLBER_MLP_MAX_HIDDEN] = {0};
+    float* base = nullptr; size_t bytes = 0;
+    struct { float *lin_w, *lin_b, *ff1_w, *ff1_b, *ff2_w, *ff2_b, *ln_w, *ln_b; } h[SYLBER_MLP_MAX_HIDDEN];
+    float *out_w = nullptr, *out_b = nullptr;
+};
+
+extern "C" int sylber_mlp_create(const SylberMlpWeights* w, int device, sylber_mlp_t* out) {
+    if (!w || !out) { syl_set_error("sylber_mlp_create", "null argument"); return 1; }
+    if (w->num_hidden < 1 || w->num_hidden > SYLBER_MLP_MAX_HIDDEN || w->input_dim % 16 || w->output_dim % 4 || w->input_dim < 16 || w->output_dim < 4) {
+        syl_set_error("sylber_mlp_create", "need 1..4 hidden layers, input_dim % 16 == 0, output_dim % 4 == 0"); return 1;
+    }
+    for (int i = 0; i < w->num_hidden; ++i)
+        if (w->hidden_dims[i] != 512 && w->hidden_dims[i] != 768) { syl_set_error("sylber_mlp_create", "hidden dims must be 512 or 768 (LayerNorm kernel)"); return 1; }
+    HIP_TRY(hipSetDevice(device));
+    sylber_mlp* m = new sylber_mlp();
+    m->device = device; m->input_dim = w->input_dim; m->output_dim = w->output_dim; m->num_hidden = w->num_hidden;
+    std::vector<float> host;
+    auto add = [&](const float* src, size_t n) { size_t o = (host.size() + 63) & ~(size_t)63; host.resize(o + n); std::copy(src, src + n, host.begin() + o); return o; };
+    size_t off[SYLBER_MLP_MAX_HIDDEN][8], o_ow, o_ob;
+    int in = w->input_dim;
+    for (int i = 0; i < w->num_hidden; ++i) {
+        const int d = w->hidden_dims[i];
+        m->dims[i] = d;
+        const auto& hw = w->hidden[i];
+        if (!hw.lin_w || !hw.lin_b || !hw.ff1_w || !hw.ff1_b || !hw.ff2_w || !hw.ff2_b || !hw.ln_w || !hw.ln_b) { delete m; syl_set_error("sylber_mlp_create", "missing tensor"); return 1; }
+        off[i][0] = add(hw.lin_w, (size_t)d * in); off[i][1] = add(hw.lin_b, d);
+        off[i][2] = add(hw.ff1_w, (size_t)d * d); off[i][3] = add(hw.ff1_b, d);
+        off[i][4] = add(hw.ff2_w, (size_t)d * d); off[i][5] = add(hw.ff2_b, d);
+        off[i][6] = add(hw.ln_w, d); off[i][7] = add(hw.ln_b, d);
+        in = d;
+    }
+    if (!w->out_w || !w->out_b) { delete m; syl_set_error("sylber_mlp_create", "missing tensor"); return 1; }
+    o_ow = add(w->out_w, (size_t)w->output_dim * in); o_ob = add(w->out_b, w->output_dim);
+    m->bytes = host.size() * 4;
+    if (hipMalloc((void**)&m->base, m->bytes) != hipSuccess || hipMemcpy(m->base, host.data(), m->bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        if (m->base) hipFree(m->base);
+        delete m; syl_set_error("sylber_mlp_create", "weight upload failed"); return 1;
+    }
+    for (int i = 0; i < w->num_hidden; ++i) {
+        float** f[8] = {&m->h[i].lin_w, &m->h[i].lin_b, &m->h[i].ff1_w, &m->h[i].ff1_b, &m->h[i].ff2_w, &m->h[i].ff2_b, &m->h[i].ln_w, &m->h[i].ln_b};
+        for (int j = 0; j < 8; ++j) *f[j] = m->base + off[i][j];
+    }
+    m->out_w = m->base + o_ow; m->out_b = m->base + o_ob;
+    *out = m;
+    return 0;
+}
+extern "C" void sylber_mlp_destroy(sylber_mlp_t m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->base) hipFree(m->base);
+    delete m;
+}
+
+static int mlp_maxdim(const sylber_mlp* m) {
+    int d = m->input_dim > m->output_dim ? m->input_dim : m->output_dim;
+    for (int i = 0; i < m->num_hidden; ++i) d = d > m->dims[i] ? d : m->dims[i];
+    return d;
+}
+extern "C" int64_t sylber_condition_workspace_floats(sylber_mlp_t m, int32_t B, int32_t S) {
+    if (!m || B < 1 || S < 1) return -1;
+    const int64_t R = (int64_t)B * S + 1;
+    return R * m->input_dim + 3 * R * mlp_maxdim(m) + R * m->output_dim + 256;
+}
+
+// rows (b, j < S): the pooled feature of segment j of utterance b (zeros beyond nseg[b]); row B*S: zeros (frames
+// outside every segment keep averaged_target_hidden_states = 0, segment_synthesis.py:115)
+__global__ __launch_bounds__(256) void cond_gather_kernel(const float* __restrict__ feat, const int32_t* __restrict__ nseg, float* __restrict__ rows,
+                                                          int B, int T, int S, int D) {
+    const int r = blockIdx.x;
+    const bool real = r < B * S;
+    const int b = real ? r / S : 0, j = real ? r - b * S : 0;
+    const bool ok = real && j < nseg[b];
+    for (int c = threadIdx.x; c < D; c += 256) rows[(size_t)r * D + c] = ok ? feat[((size_t)b * T + j) * D + c] : 0.f;
+}
+
+// one wave per frame: its segment (the LAST one containing it, like the sequential slice assignment at :126), the
+// hidden-state norm ((h**2).sum(-1)+1e-8)**.5 (:110), and the masked conditioning row (:138-139)
+__global__ __launch_bounds__(256) void cond_scatter_kernel(const float* __restrict__ hidden, const int64_t* __restrict__ seg,
+                                                           const int32_t* __restrict__ nseg, const float* __restrict__ feat,
+                                                           const float* __restrict__ mlp_rows, int B, int T, int S, int D, int OD, float thr,
+                                                           float* __restrict__ avg_out, float* __restrict__ cond_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long f = (long)blockIdx.x * 4 + wave;
+    if (f >= (long)B * T) return;
+    const int b = (int)(f / T), t = (int)(f - (long)b * T);
+    const float* h = hidden + (size_t)f * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s = fmaf(h[c], h[c], s);
+    s = wave_sum(s);
+    const bool silent = sqrtf(s + 1e-8f) < thr;
+    int n = nseg[b]; n = n < S ? n : S;
+    int j = -1;
+    for (int q = lane; q < n; q += 64) {
+        const int64_t s0 = seg[((size_t)b * T + q) * 2], s1 = seg[((size_t)b * T + q) * 2 + 1];
+        if (t >= s0 && t < s1) j = q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int oj = __shfl_xor(j, o, 64); j = oj > j ? oj : j; }
+    const float* src = mlp_rows + (size_t)(j >= 0 ? b * S + j : B * S) * OD;
+    for (int c = lane; c < OD; c += 64) cond_out[(size_t)f * OD + c] = silent ? 0.f : src[c];
+    if (avg_out) for (int c = lane; c < D; c += 64) avg_out[(size_t)f * D + c] = j >= 0 ? feat[((size_t)b * T + j) * D + c] : 0.f;
+}
+
+extern "C" int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg_dev, const int32_t* nseg_dev, const float* feat_dev,
+                                int32_t B, int32_t T, int32_t S, float norm_thr, float* avg_hidden_dev, float* cond_dev, float* workspace_dev,
+                                void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!m || !hidden_dev || !seg_dev || !nseg_dev || !feat_dev || !cond_dev || !workspace_dev) { syl_set_error("sylber_condition", "null argument"); return 1; }
+    if (B < 1 || T < 1 || S < 1 || S > T) { syl_set_error("sylber_condition", "need B, T >= 1 and 1 <= S <= T"); return 1; }
+    HIP_TRY(hipSetDevice(m->device));
+    const int D = m->input_dim, R = B * S + 1, MD = mlp_maxdim(m);
+    float* x0 = workspace_dev;
+    float* ha = x0 + (size_t)R * D; float* hb = ha + (size_t)R * MD; float* hc = hb + (size_t)R * MD;
+    float* yo = hc + (size_t)R * MD;
+    hipLaunchKernelGGL(cond_gather_kernel, dim3(R), dim3(256), 0, s, feat_dev, nseg_dev, x0, B, T, S, D);
+    HIP_TRY(hipGetLastError());
+    const float* cur = x0; int in = D;
+    for (int i = 0; i < m->num_hidden; ++i) {
+        const int d = m->dims[i];
+        GemmArgsF32 g = {};
+        g.X = cur; g.ldx = in; g.W = m->h[i].lin_w; g.M = R; g.N = d; g.K = in; g.bias = m->h[i].lin_b; g.out0 = ha; g.ld0 = d;
+        if (launch_gemm_f32(g, s)) return 1;                                   // x = Linear(in, d)(x)
+        GemmArgsF32 f1 = {};
+        f1.X = ha; f1.ldx = d; f1.W = m->h[i].ff1_w; f1.M = R; f1.N = d; f1.K = d; f1.bias = m->h[i].ff1_b; f1.act = 2; f1.out0 = hb; f1.ld0 = d;
+        if (launch_gemm_f32(f1, s)) return 1;                                  // relu(linear1(x))   (RFF, :28)
+        GemmArgsF32 f2 = {};
+        f2.X = hb; f2.ldx = d; f2.W = m->h[i].ff2_w; f2.M = R; f2.N = d; f2.K = d; f2.bias = m->h[i].ff2_b; f2.out0 = hc; f2.ld0 = d;
+        if (launch_gemm_f32(f2, s)) return 1;                                  // x2 = linear2(.)
+        LnArgs l = {};
+        l.in = hc; l.in_bf16 = 0; l.ld_in = d; l.res = ha; l.ld_res = d; l.gamma = m->h[i].ln_w; l.beta = m->h[i].ln_b;
+        l.out_f32 = hb; l.ld_f32 = d; l.M = R; l.D = d;
+        if (launch_layernorm(l, s)) return 1;                                  // x = norm(x + x2)   (:29-30)
+        // the result lives in hb: the next layer's Linear reads it into ha before hb is overwritten again
+        cur = hb; in = d;
+    }
+    GemmArgsF32 go = {};
+    go.X = cur; go.ldx = in; go.W = m->out_w; go.M = R; go.N = m->output_dim; go.K = in; go.bias = m->out_b; go.out0 = yo; go.ld0 = m->output_dim;
+    if (launch_gemm_f32(go, s)) return 1;
+    const long frames = (long)B * T;
+    hipLaunchKernelGGL(cond_scatter_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, s, hidden_dev, seg_dev, nseg_dev, feat_dev, yo, B, T, S, D,
+                       m->output_dim, norm_thr, avg_hidden_dev, cond_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgsF32 a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x = acc[4 * g + e] + (a.bias ? a.bias[n + e] : 0.f);
-            if (a.act) x = gelu_erf(x);
+            if (a.act == 1) x = gelu_erf(x);
+            else if (a.act == 2) x = fmaxf(x, 0.f);
             if (a.res) x += a.res[(size_t)m * a.ldres + n + e];
             if (zero_row) x = 0.f;
             v[e] = x;

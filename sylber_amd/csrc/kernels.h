@@ -60,7 +60,7 @@ struct GemmArgsF32 {
     const float* X; long ldx;
     const float* W;
     int M, N, K;
-    const float* bias; int act;       // act: 0 none, 1 erf-GELU
+    const float* bias; int act;       // act: 0 none, 1 erf-GELU, 2 ReLU
     float* out0; long ld0;
     const float* res; long ldres;
     int Tp, T; const int* valid;      // feature projection: zero frames t >= min(valid[b], T) (Tp > 0 enables row -> (b,t))

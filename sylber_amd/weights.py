@@ -136,3 +136,29 @@ def fold_pos_conv_weight(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
         v = sd[POS_V_KEYS[0]].float()
         return (g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).contiguous()
     return sd["encoder.pos_conv_embed.conv.weight"].float().contiguous()
+
+
+def synthetic_mlp_state_dict(seed: int = 0, input_dim: int = HIDDEN, output_dim: int = 256,
+                             hidden_dims=(512, 512)) -> Dict[str, torch.Tensor]:
+    """Seeded weights of the resynthesis conditioner ``MLP`` in the key layout of its ``state_dict()``
+    (sylber/model/segment_synthesis.py:35-53: ``mlp.{2i}`` Linear, ``mlp.{2i+1}`` RFF with ``linear1``, ``linear2``,
+    ``norm``; last entry the output Linear; sylber_configs/sylber_resynthesis.yaml gives 768 -> [512, 512] -> 256)."""
+    g = torch.Generator().manual_seed(10_000 + seed)
+
+    def randn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * std
+
+    sd: Dict[str, torch.Tensor] = {}
+    d_in = input_dim
+    for i, d in enumerate(hidden_dims):
+        sd["mlp.%d.weight" % (2 * i)] = randn(d, d_in, std=1.0 / math.sqrt(d_in))
+        sd["mlp.%d.bias" % (2 * i)] = randn(d, std=0.1)
+        for nm in ("linear1", "linear2"):
+            sd["mlp.%d.%s.weight" % (2 * i + 1, nm)] = randn(d, d, std=1.0 / math.sqrt(d))
+            sd["mlp.%d.%s.bias" % (2 * i + 1, nm)] = randn(d, std=0.1)
+        sd["mlp.%d.norm.weight" % (2 * i + 1)] = 1.0 + randn(d, std=0.1)
+        sd["mlp.%d.norm.bias" % (2 * i + 1)] = randn(d, std=0.1)
+        d_in = d
+    sd["mlp.%d.weight" % (2 * len(hidden_dims))] = randn(output_dim, d_in, std=1.0 / math.sqrt(d_in))
+    sd["mlp.%d.bias" % (2 * len(hidden_dims))] = randn(output_dim, std=0.1)
+    return sd

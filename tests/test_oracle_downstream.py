@@ -1,0 +1,52 @@
+"""CPU tier, rows N3 / N4: the oracle's conditioner MLP against the golden produced by the reference's own ``MLP``
+class (tools/gen_golden_mlp.py), and the nearest-centroid restatement against brute force."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import downstream_ref as R
+from sylber_amd.weights import synthetic_mlp_state_dict
+
+
+def test_mlp_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mlp_front.npz"))
+    sd = synthetic_mlp_state_dict(0)
+    y = R.mlp_forward(sd, torch.from_numpy(g["x"])).numpy()
+    assert y.shape == g["y"].shape == (24, 256)
+    assert np.abs(y - g["y"]).max() <= 1e-5
+    assert float(g["oracle_vs_reference_max_abs"]) < 1e-5
+    # key layout of MLP.state_dict() for 768 -> [512, 512] -> 256 (sylber_configs/sylber_resynthesis.yaml)
+    assert sd["mlp.0.weight"].shape == (512, 768) and sd["mlp.1.linear1.weight"].shape == (512, 512)
+    assert sd["mlp.3.norm.weight"].shape == (512,) and sd["mlp.4.weight"].shape == (256, 512)
+
+
+def test_km_indices_brute_force():
+    rng = np.random.default_rng(0)
+    c = rng.standard_normal((37, 48)).astype(np.float32)
+    x = rng.standard_normal((50, 48)).astype(np.float32)
+    idx, d2 = R.km_indices(x, c)
+    brute = np.array([np.argmin([np.sum((xi.astype(np.float64) - cj) ** 2) for cj in c]) for xi in x])
+    assert np.array_equal(idx, brute)
+    x[3] = c[11]
+    assert R.km_indices(x, c)[0][3] == 11
+    # normalisation (quantizer.py:104-105) maps every token onto the radius-6 sphere first
+    idxn, _ = R.km_indices(x * 100.0, c, normalize=True)
+    xs = x / np.linalg.norm(x, axis=-1, keepdims=True) * 6
+    assert np.array_equal(idxn, R.km_indices(xs.astype(np.float32), c)[0])
+
+
+def test_resynth_front_semantics():
+    from sylber_amd.synth_states import syllable_states
+    sd = synthetic_mlp_state_dict(1)
+    h = torch.from_numpy(np.stack([syllable_states(60, 3), syllable_states(60, 4)]))
+    inp, avg, segs = R.resynth_front(sd, h, 2.6, 0.8)
+    assert inp.shape == (2, 60, 256) and avg.shape == h.shape
+    norms = np.sqrt((h.numpy().astype(np.float64) ** 2).sum(-1))
+    assert np.all(inp.numpy()[norms < 2.59] == 0.0)
+    for b in range(2):
+        covered = np.zeros(60, bool)
+        for s, e in segs[b].reshape(-1, 2):
+            covered[s:e] = True
+            assert np.allclose(avg[b, s:e].numpy(), h[b, s:e].mean(0).numpy()[None], atol=1e-6)
+        assert np.all(avg[b].numpy()[~covered] == 0.0)
