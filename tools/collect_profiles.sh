@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): the bench lines, rocprofv3 kernel traces and PMC passes that profiles/ is built
+# from.  Everything lands in gpurun_out/; tools/rocprof_summary.py / tools/pmc_traffic.py turn it into profiles/.
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
+set -u
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/final
+rm -rf $OUT; mkdir -p $OUT
+python bench.py > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
+python bench.py --precision fp8 --no-cpu-baseline > $OUT/bench_fp8.json 2> $OUT/bench_fp8.err
+python bench.py --batch 8 --clip-seconds 60 --no-cpu-baseline > $OUT/bench_longform.json 2> $OUT/bench_longform.err
+python bench.py --no-overlap --no-cpu-baseline > $OUT/bench_sequential.json 2> $OUT/bench_sequential.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/trace_pipelined.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sequential -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-overlap > $OUT/trace_sequential.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fp8 -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --precision fp8 > $OUT/trace_fp8.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > $OUT/pmc_write.log 2>&1
+cd $ROOT
+mkdir -p $OUT/traffic
+cp $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) $OUT/traffic/FETCH_SIZE_counter_collection.csv
+cp $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1) $OUT/traffic/WRITE_SIZE_counter_collection.csv
+for t in pipelined sequential fp8; do cp $(find $OUT/trace_$t -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_$t.csv; done
+# keep the merge-back small: the raw traces are not needed
+rm -rf $OUT/trace_pipelined $OUT/trace_sequential $OUT/trace_fp8 $OUT/pmc_fetch $OUT/pmc_write
+ls -la $OUT $OUT/traffic
+tail -c 400 $OUT/bench_bf16.json

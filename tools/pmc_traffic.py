@@ -32,7 +32,7 @@ def main(src, dst):
     gemm = [r for r in rows if "gemm" in r[0]]
     n_gemm = sum(r[1] for r in gemm)
     tot = sum((r[2] + r[3]) * r[1] for r in gemm)
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1",
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap (tools/collect_profiles.sh)",
            "fetch_correction": 2.0, "gemm_family_bytes_per_launch": tot / n_gemm, "gemm_launches_profiled": n_gemm,
            "kernels": {r[0]: {"launches": r[1], "fetch_bytes_per_launch": r[2], "write_bytes_per_launch": r[3]} for r in rows}}
     json.dump(out, open(dst + ".json", "w"), indent=1)
