@@ -105,6 +105,9 @@ def main():
                     help="4-wave GEMM launches: 0 = one workgroup per tile, k = persistent k x 256 workgroups")
     ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
                     help="bf16 = BASELINE configs[1] (the headline); fp8 = configs[4]: FFN GEMMs on MXFP8 operands (not the headline)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="clip lengths U[2 s, clip-seconds] (seeded), padded to the batch maximum like sylber.py:93-118; value "
+                         "counts VALID audio only -> the padding overhead of the reference's batching contract (not the headline)")
     ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS,
                     help="clip length; 10 = BASELINE configs[1] (default), 60 with --batch 8 = configs[3] (long-form)")
     args = ap.parse_args()
@@ -146,6 +149,16 @@ def main():
     # inputs resident in HBM before the timed region: rank r holds clips [r*B, (r+1)*B) of the seeded job;
     # with the exchange enabled the root additionally holds the whole job and scatters it every step
     my_batch = noise_batch(B, clip_samples, seed=1000 + rank).to(dev)
+    lengths = None
+    valid_seconds = B * clip_seconds
+    if args.ragged:
+        import numpy as _np
+        rng = _np.random.default_rng(2000 + rank)
+        lengths = [int(x) for x in rng.integers(2 * 16000, clip_samples + 1, B)]
+        lengths[0] = clip_samples                              # the batch maximum stays the nominal clip length
+        for i, n in enumerate(lengths):
+            my_batch[i, n:] = 0.0                              # right zero padding (sylber.py:104-106)
+        valid_seconds = sum(lengths) / 16000.0
     root_batch = None
     if exchange and rank == 0:
         root_batch = torch.cat([noise_batch(B, clip_samples, seed=1000 + r) for r in range(world)], 0).to(dev)
@@ -171,7 +184,7 @@ def main():
         if exchange:
             return sharded.step(root_batch, None)
         if args.no_overlap:
-            hidden = enc.forward(my_batch, None)
+            hidden = enc.forward(my_batch, lengths)
             return (hidden,) + tuple(enc.segment(hidden, 2.6, 0.8))
         k = state["i"] % NPIPE
         state["i"] += 1
@@ -180,7 +193,7 @@ def main():
         with torch.cuda.stream(main):
             if seg_done[k] is not None:
                 main.wait_event(seg_done[k])      # the segmenter that last read this buffer set has finished
-            encs[k].forward(my_batch, None, out=hidden)
+            encs[k].forward(my_batch, lengths, out=hidden)
             ready = torch.cuda.Event()
             ready.record(main)
         with torch.cuda.stream(side):
@@ -209,7 +222,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_audio = world * B * clip_seconds * args.steps
+    total_audio = world * valid_seconds * args.steps           # (ragged: rank 0's draw stands for every rank)
     value = total_audio / elapsed
 
     # ---- per-kernel device time with HIP events on the launch stream (separate pass: event records
@@ -266,7 +279,9 @@ def main():
             "config": {"workload": "Segmenter forward (conv frontend + HuBERT-9L encoder + boundary detection + "
                                    "segment mean-pool), batch %d x %g s 16 kHz random waveforms per GPU, random-init "
                                    "sylber_base weights (BASELINE.json configs[1]%s)" % (B, clip_seconds, "; configs[2] sharding" if world > 1 else ""),
-                       "global_batch": world * B, "clip_seconds": clip_seconds, "frames_per_clip": T_frames,
+                       "global_batch": world * B, "clip_seconds": clip_seconds,
+                       "ragged": ("lengths U[2 s, %g s], %.1f valid s of %g padded s per batch" % (clip_seconds, valid_seconds, B * clip_seconds))
+                                 if args.ragged else None, "frames_per_clip": T_frames,
                        "parallelism": "utterance-sharded x%d, %s" % (world, "root scatter + gather over RCCL in every step" if exchange
                                                                       else "shards resident per rank, no data-path collective"),
                        "pipelining": "none" if (exchange or args.no_overlap) else

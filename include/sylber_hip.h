@@ -34,8 +34,8 @@ extern "C" {
 typedef struct sylber_ctx* sylber_t;
 
 /* compute precision of the encoder GEMMs */
-/* SYLBER_FP8 (BASELINE.json configs[4]): as SYLBER_BF16, but the q/k/v projection and the two FFN GEMMs of every
- * encoder layer (80 % of the encoder's GEMM FLOPs) run on OCP microscaling FP8 operands (e4m3 elements, one E8M0 power-of-two scale per 32 elements along K) through the
+/* SYLBER_FP8 (BASELINE.json configs[4]): as SYLBER_BF16, but the four projection GEMMs around the attention (q/k/v, out) and the two FFN
+ * GEMMs of every encoder layer (all of the encoder's weight GEMMs) run on OCP microscaling FP8 operands (e4m3 elements, one E8M0 power-of-two scale per 32 elements along K) through the
  * block-scaled gfx950 MFMA, fp32 accumulation; tolerance vs the bf16 mode is stated in tests/test_gpu_fp8.py */
 enum { SYLBER_BF16 = 0, SYLBER_FP32 = 1, SYLBER_FP8 = 2 };
 

@@ -28,6 +28,7 @@ struct LayerDev {
     bf16_t *wqkv, *wo, *w1, *w2;
     uint8_t *w1q = nullptr, *w1s = nullptr, *w2q = nullptr, *w2s = nullptr;   // SYLBER_FP8: MXFP8 FFN weights + E8M0 scales
     uint8_t *wqkvq = nullptr, *wqkvs = nullptr;                                // and the fused q/k/v projection
+    uint8_t *woq = nullptr, *wos = nullptr;                                    // and the attention out-projection
     float *bqkv, *bo, *b1, *b2, *ln1w, *ln1b, *ln2w, *ln2b;
 };
 
@@ -161,7 +162,7 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
         // FFN weights once more as MXFP8 (e4m3 + one E8M0 scale per 32 input features), quantised on the device
         // from the fp32 originals with the same kernel the activations' op-level entry point uses
         const size_t per_layer = (size_t)3072 * 768 + (size_t)3072 * 24 + (size_t)768 * 3072 + (size_t)768 * 96 +
-                                 (size_t)2304 * 768 + (size_t)2304 * 24;
+                                 (size_t)2304 * 768 + (size_t)2304 * 24 + (size_t)768 * 768 + (size_t)768 * 24;
         c->f8bytes = per_layer * w->num_layers;
         float* tmp = nullptr;
         if (hipMalloc((void**)&c->f8base, c->f8bytes) != hipSuccess || hipMalloc((void**)&tmp, (size_t)3072 * 768 * 4) != hipSuccess) {
@@ -174,6 +175,10 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
             uint8_t* q = (uint8_t*)c->f8base + per_layer * l;
             d.w1q = q; d.w1s = d.w1q + (size_t)3072 * 768; d.w2q = d.w1s + (size_t)3072 * 24; d.w2s = d.w2q + (size_t)768 * 3072;
             d.wqkvq = d.w2s + (size_t)768 * 96; d.wqkvs = d.wqkvq + (size_t)2304 * 768;
+            d.woq = d.wqkvs + (size_t)2304 * 24; d.wos = d.woq + (size_t)768 * 768;
+            bad |= hipMemcpy(tmp, w->layers[l].o_w, (size_t)768 * 768 * 4, hipMemcpyHostToDevice) != hipSuccess;
+            bad |= launch_mx_quant_rows(tmp, 768, d.woq, 768, d.wos, 768, 768, 768, nullptr);
+            bad |= hipDeviceSynchronize() != hipSuccess;
             {
                 const SylberLayerWeights& lw = w->layers[l];
                 bad |= hipMemcpy(tmp, lw.q_w, (size_t)768 * 768 * 4, hipMemcpyHostToDevice) != hipSuccess;
@@ -389,6 +394,7 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
     const bool f8 = c->precision == SYLBER_FP8;
     const long Mp = ((long)M + 255) & ~255L;            // row pitch of the activations' scale arrays
     uint8_t* h8 = (uint8_t*)hbf; uint8_t* h8s = h8 + (((size_t)M * 768 + 255) & ~(size_t)255);       // 24 Mp bytes
+    uint8_t* ctx8 = (uint8_t*)ctx; uint8_t* ctx8s = ctx8 + (((size_t)M * 768 + 255) & ~(size_t)255);     // 24 Mp bytes
     uint8_t* ffn8 = (uint8_t*)ffn; uint8_t* ffn8s = ffn8 + (((size_t)M * 3072 + 255) & ~(size_t)255);  // 96 Mp bytes
     auto run_ln = [&](const float* gam, const float* bet, bool last, bool to_fp8 = false) -> int {
         LnArgs a = {};
@@ -423,11 +429,20 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         g.W = d.wqkv + (size_t)1536 * 768; g.bias = d.bqkv + 1536; g.N = 768;
         RUN("gemm_v", launch_gemm_bf16(EPI_V, g, s));
         }
+        if (f8) {
+            RUN("attention", launch_attention_f8out(q, k, vt, valid, ctx8, ctx8s, Mp, B, p.T, p.Tp, p.Tpv, s));
+            GemmF8Args o = {};
+            o.g.M = M; o.g.N = 768; o.g.K = 768; o.g.bias = d.bo; o.g.out0 = pre; o.g.ld0 = 768; o.g.res = pre; o.g.ldres = 768;
+            o.g.ln_stats = stats; o.g.ln_gamma = res_g; o.g.ln_beta = res_b;
+            o.X8 = ctx8; o.ldx8 = 768; o.XS = ctx8s; o.xs_rows = Mp; o.W8 = d.woq; o.WS = d.wos; o.ws_rows = 768;
+            RUN("gemm_out", launch_gemm_mxfp8(EPI_F32_RESLN, o, s));
+        } else {
         RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, s));
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
         o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
         RUN("gemm_out", launch_gemm_bf16(EPI_F32_RESLN, o, s));
+        }
         RUN("layernorm", run_ln(d.ln1w, d.ln1b, false, f8));
         if (f8) {
             GemmF8Args f1 = {};

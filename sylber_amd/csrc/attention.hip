@@ -30,10 +30,11 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 // QW = 32-query sub-tiles per wave.  QW = 2 halves the LDS fragment reads and the LDS-DMA instructions per
 // MFMA (every K / V^T fragment feeds two MFMAs); the DMA issue is the most expensive instruction of the loop
 // (profiles/r01_mfma_ceiling.md).
-template <int QW>
+template <int QW, bool F8 = false>
 __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                 const bf16_t* __restrict__ Vt, const int* __restrict__ valid,
-                                                                bf16_t* __restrict__ ctx, int T, int Tp, int Tpv) {
+                                                                bf16_t* __restrict__ ctx, int T, int Tp, int Tpv,
+                                                                uint8_t* __restrict__ ctx_scale, long scale_rows) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -184,7 +185,33 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
         const float l_tot = l_run[qs] + __shfl_xor(l_run[qs], 32, 64);
         const float inv = 1.0f / l_tot;
         const int q = q0 + 32 * qs + ql;
-        if (q < T) {
+        if constexpr (F8) {
+            // SYLBER_FP8: the context leaves as MXFP8 for the out-projection GEMM.  A 32-wide d block of a head is one
+            // scale block: 16 values in this lane, 16 in lane ^ 32; the halves swap two runs so that each lane stores
+            // 16 contiguous bytes (a whole 32-byte sector per lane pair); the two scales of a (token, head) are the
+            // adjacent pair of the K-pair-major layout
+            uint8_t* dst8 = (uint8_t*)ctx + ((size_t)b * Tp + (q < T ? q : 0)) * SYL_HIDDEN + head * 64;
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                float amax = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(oacc[qs][ds][r] * inv));
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                const unsigned e = mx_e8m0(amax);
+                const float sc = inv * mx_inv_scale(e);
+                unsigned w[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    w[g] = pack_fp8x4(oacc[qs][ds][4 * g + 0] * sc, oacc[qs][ds][4 * g + 1] * sc, oacc[qs][ds][4 * g + 2] * sc, oacc[qs][ds][4 * g + 3] * sc);
+                const unsigned s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];
+                const unsigned g0 = (unsigned)__shfl_xor((int)s0, 32, 64), g1 = (unsigned)__shfl_xor((int)s1, 32, 64);
+                const uint4 out = h ? make_uint4(g0, w[2], g1, w[3]) : make_uint4(w[0], g0, w[1], g1);
+                if (q < T) {
+                    *(uint4*)(dst8 + 32 * ds + 16 * h) = out;
+                    if (h == 0) ctx_scale[mx_scale_index((long)b * Tp + q, 2 * head + ds, scale_rows)] = (uint8_t)e;
+                }
+            }
+        } else if (q < T) {
             bf16_t* dst = ctx + ((size_t)b * Tp + q) * SYL_HIDDEN + head * 64;
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds)
@@ -202,19 +229,31 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
 static int g_attn_qw = 0;
 void attention_force_qw(int qw) { g_attn_qw = qw; }
 
-int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T, int Tp,
-                     int Tpv, hipStream_t s) {
+static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, void* ctx, uint8_t* ctx_scale,
+                                long scale_rows, int B, int T, int Tp, int Tpv, hipStream_t s) {
     if (Tpv % 64 != 0 || Tpv < T) { syl_set_error("launch_attention", "Tpv must be a multiple of 64 and >= T"); return 1; }
     // 64 queries per wave when there are enough query blocks to fill the chip, else 32
     int qw = ((long)((T + 255) / 256) * SYL_HEADS * B >= 512) ? 2 : 1;
     if (g_attn_qw) qw = g_attn_qw;
-    if (qw == 2) {
-        dim3 grid((T + 255) / 256, SYL_HEADS, B);
-        hipLaunchKernelGGL(attention_bf16_kernel<2>, grid, dim3(256), AT_LDS, s, q, k, vt, valid, ctx, T, Tp, Tpv);
+    const dim3 grid(qw == 2 ? (T + 255) / 256 : (T + 127) / 128, SYL_HEADS, B);
+    if (ctx_scale) {
+        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, ctx_scale, scale_rows);
+        else hipLaunchKernelGGL((attention_bf16_kernel<1, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, ctx_scale, scale_rows);
     } else {
-        dim3 grid((T + 127) / 128, SYL_HEADS, B);
-        hipLaunchKernelGGL(attention_bf16_kernel<1>, grid, dim3(256), AT_LDS, s, q, k, vt, valid, ctx, T, Tp, Tpv);
+        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, nullptr, 0L);
+        else hipLaunchKernelGGL((attention_bf16_kernel<1, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, nullptr, 0L);
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T, int Tp,
+                     int Tpv, hipStream_t s) {
+    return launch_attention_any(q, k, vt, valid, ctx, nullptr, 0, B, T, Tp, Tpv, s);
+}
+
+// same attention, context written as MXFP8 ([B*Tp][768] e4m3 + K-pair-major E8M0 scales with row pitch scale_rows)
+int launch_attention_f8out(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, uint8_t* ctx8, uint8_t* ctx_scale,
+                           long scale_rows, int B, int T, int Tp, int Tpv, hipStream_t s) {
+    return launch_attention_any(q, k, vt, valid, ctx8, ctx_scale, scale_rows, B, T, Tp, Tpv, s);
 }

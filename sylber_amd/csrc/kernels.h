@@ -103,6 +103,8 @@ int launch_layernorm(const LnArgs& a, hipStream_t s);
 // ------------------------------------------------------------------------------------------------
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T,
                      int Tp, int Tpv, hipStream_t s);
+int launch_attention_f8out(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, uint8_t* ctx8, uint8_t* ctx_scale,
+                           long scale_rows, int B, int T, int Tp, int Tpv, hipStream_t s);   // context as MXFP8 (SYLBER_FP8)
 void attention_force_qw(int qw);   // 0 = automatic, 1 / 2 = 32 / 64 queries per wave
 int launch_attention_f32(const float* q, const float* k, const float* v, const int* valid, float* ctx, int B, int T,
                          int Tp, hipStream_t s);
