@@ -105,6 +105,7 @@ def main():
                     help="4-wave GEMM launches: 0 = one workgroup per tile, k = persistent k x 256 workgroups")
     ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
                     help="bf16 = BASELINE configs[1] (the headline); fp8 = configs[4]: FFN GEMMs on MXFP8 operands (not the headline)")
+    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph (small, launch-bound batches)")
     ap.add_argument("--ragged", action="store_true",
                     help="clip lengths U[2 s, clip-seconds] (seeded), padded to the batch maximum like sylber.py:93-118; value "
                          "counts VALID audio only -> the padding overhead of the reference's batching contract (not the headline)")
@@ -172,6 +173,9 @@ def main():
     T_frames = enc.num_frames(clip_samples)
     NPIPE = 1 if (exchange or args.no_overlap) else args.inflight
     encs = [enc] + [HubertEncoderHIP(sd, device=str(dev), precision=args.precision) for _ in range(NPIPE - 1)]
+    if args.graph:
+        for e_ in encs:
+            e_.set_graph_mode(True)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
     sides = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
     bufs = [(torch.empty(B, T_frames, 768, device=dev),
@@ -184,8 +188,8 @@ def main():
         if exchange:
             return sharded.step(root_batch, None)
         if args.no_overlap:
-            hidden = enc.forward(my_batch, lengths)
-            return (hidden,) + tuple(enc.segment(hidden, 2.6, 0.8))
+            hidden = enc.forward(my_batch, lengths, out=bufs[0][0])
+            return (hidden,) + tuple(enc.segment(hidden, 2.6, 0.8, out=bufs[0][1]))
         k = state["i"] % NPIPE
         state["i"] += 1
         hidden, seg_out = bufs[k]

@@ -150,6 +150,10 @@ int sylber_set_stop_stage(sylber_t h, int32_t stage);
  * names/ms arrays of capacity cap; returns the number of entries (<=cap) or <0 on error. */
 int sylber_set_profiling(sylber_t h, int32_t enable);
 int sylber_get_profile(sylber_t h, const char** names, float* ms, int32_t cap);
+/* graph mode (bf16 / fp8 handles): the second sylber_forward with the same (B, Lmax, wav_dev, hidden_dev) on a
+ * non-default stream captures its ~110 launches into a hipGraph and later calls replay it — for launch-bound small
+ * batches (one 3 s utterance: 1.5 ms eager).  Up to 8 shapes are cached per handle; disabling frees them. */
+int sylber_set_graph_mode(sylber_t h, int32_t enable);
 /* bytes of device workspace currently held by the handle */
 int64_t sylber_workspace_bytes(sylber_t h);
 

@@ -46,6 +46,7 @@ EXPORTS = {
                                c_void_p, c_void_p]),
     "sylber_set_stop_stage": (c_int, [c_void_p, c_int32]),
     "sylber_set_profiling": (c_int, [c_void_p, c_int32]),
+    "sylber_set_graph_mode": (c_int, [c_void_p, c_int32]),
     "sylber_get_profile": (c_int, [c_void_p, POINTER(c_char_p), POINTER(c_float), c_int32]),
     "sylber_workspace_bytes": (c_int64, [c_void_p]),
     "sylber_op_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -33,6 +33,7 @@ struct LayerDev {
 };
 
 struct ProfEntry { std::string name; hipEvent_t e0, e1; };
+struct GraphEntry { int B, Lmax, stop_stage; const void* in; void* out; hipGraphExec_t exec; unsigned long long stamp; };
 
 struct sylber_ctx {
     int device = 0, precision = 0, num_layers = 9;
@@ -51,6 +52,8 @@ struct sylber_ctx {
     int ws_B = 0, ws_Lmax = 0;
     float* seg_scratch = nullptr; size_t seg_scratch_floats = 0;
     int stop_stage = 0;
+    bool graph_mode = false;
+    std::vector<GraphEntry> graphs; unsigned long long graph_clock = 0;
     // profiling
     int profiling = 0;
     std::vector<ProfEntry> prof;
@@ -208,6 +211,7 @@ extern "C" void sylber_destroy(sylber_t c) {
     if (c->f8base) hipFree(c->f8base);
     if (c->ws) hipFree(c->ws);
     if (c->seg_scratch) hipFree(c->seg_scratch);
+    for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     delete c;
 }
@@ -326,16 +330,10 @@ extern "C" int sylber_get_profile(sylber_t c, const char** names, float* ms, int
 static int forward_f32(sylber_ctx* c, const float* wav_dev, const int32_t* lengths_host, int B, int Lmax, float* hidden_dev,
                        hipStream_t s);
 
-extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* lengths_host, int32_t B, int32_t Lmax,
-                              float* hidden_dev, void* stream) {
-    if (!c || !wav_dev || !hidden_dev) { syl_set_error("sylber_forward", "null argument"); return 1; }
-    if (c->precision == SYLBER_FP32) return forward_f32(c, wav_dev, lengths_host, B, Lmax, hidden_dev, (hipStream_t)stream);
-    if (B < 1 || Lmax < 400) { syl_set_error("sylber_forward", "need B >= 1 and at least 400 samples (one frame)"); return 1; }
-    hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipSetDevice(c->device));
-    Plan p;
-    make_plan(B, Lmax, p);
-    if (ensure_workspace(c, p, s)) return 1;
+// every kernel launch of the bf16 / fp8 forward, in stream order; nothing else (no allocation, copy or synchronisation),
+// so the sequence can be replayed from a captured hipGraph
+static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, float* hidden_dev, hipStream_t s) {
+    const int B = p.B, Lmax = p.Lmax;
     char* w = c->ws;
     bf16_t* bufA = (bf16_t*)(w + p.o_bufA); bf16_t* bufB = (bf16_t*)(w + p.o_bufB);
     bf16_t* ln512 = (bf16_t*)(w + p.o_ln512);
@@ -346,16 +344,6 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
     double* part = (double*)(w + p.o_part); float* ss = (float*)(w + p.o_ss); int* valid = (int*)(w + p.o_valid);
     const int M = B * p.Tp;
 
-    // valid frames per utterance (TP:664-689): conv-length formula of the number of valid samples
-    {
-        std::vector<int> v(B);
-        for (int i = 0; i < B; ++i) {
-            int n = lengths_host ? lengths_host[i] : Lmax;
-            if (n > Lmax || n < 400) { syl_set_error("sylber_forward", "lengths must be in [400, Lmax]"); return 1; }
-            v[i] = sylber_num_frames(n);
-        }
-        HIP_TRY(hipMemcpyAsync(valid, v.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
-    }
     // ---- conv layer 0 + GroupNorm + GELU
     RUN("conv0_stats", launch_conv0_stats(wav_dev, B, Lmax, p.L[0], part, p.nchunk, s));
     RUN("conv0_finalize", launch_conv0_finalize(part, p.nchunk, c->conv0_w, c->gn_w, c->gn_b, B, p.L[0], ss, s));
@@ -468,6 +456,78 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
         res_g = d.ln2w; res_b = d.ln2b;
         if (last) break;
     }
+    return 0;
+}
+
+
+// Graph mode (sylber_set_graph_mode): ~110 launches per forward are launch-latency bound for short / single
+// utterances (1.5 ms for one 3 s clip with 0.4 ms of kernel work).  The second call with the same
+// (B, Lmax, input, output) captures the launch sequence on the caller's stream into a hipGraph; later calls replay it.
+static void graphs_clear(sylber_ctx* c) {
+    for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
+extern "C" int sylber_set_graph_mode(sylber_t c, int32_t enable) {
+    if (!c) return 1;
+    c->graph_mode = enable != 0;
+    if (!enable) graphs_clear(c);
+    return 0;
+}
+
+extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* lengths_host, int32_t B, int32_t Lmax,
+                              float* hidden_dev, void* stream) {
+    if (!c || !wav_dev || !hidden_dev) { syl_set_error("sylber_forward", "null argument"); return 1; }
+    if (c->precision == SYLBER_FP32) return forward_f32(c, wav_dev, lengths_host, B, Lmax, hidden_dev, (hipStream_t)stream);
+    if (B < 1 || Lmax < 400) { syl_set_error("sylber_forward", "need B >= 1 and at least 400 samples (one frame)"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    Plan p;
+    make_plan(B, Lmax, p);
+    char* ws_before = c->ws;
+    if (ensure_workspace(c, p, s)) return 1;
+    if (c->ws != ws_before) graphs_clear(c);           // captured graphs hold workspace addresses
+    int* valid = (int*)(c->ws + p.o_valid);
+    // valid frames per utterance (TP:664-689): conv-length formula of the number of valid samples
+    {
+        std::vector<int> v(B);
+        for (int i = 0; i < B; ++i) {
+            int n = lengths_host ? lengths_host[i] : Lmax;
+            if (n > Lmax || n < 400) { syl_set_error("sylber_forward", "lengths must be in [400, Lmax]"); return 1; }
+            v[i] = sylber_num_frames(n);
+        }
+        HIP_TRY(hipMemcpyAsync(valid, v.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    if (!c->graph_mode || c->profiling || s == nullptr) return forward_launch(c, p, wav_dev, hidden_dev, s);
+    GraphEntry* e = nullptr;
+    for (auto& g : c->graphs)
+        if (g.B == B && g.Lmax == Lmax && g.stop_stage == c->stop_stage && g.in == wav_dev && g.out == hidden_dev) e = &g;
+    if (e && e->exec) { e->stamp = ++c->graph_clock; HIP_TRY(hipGraphLaunch(e->exec, s)); return 0; }
+    if (!e) {                                          // first sighting: run eagerly (also sets the kernels' attributes)
+        if (c->graphs.size() >= 8) {                   // evict the least recently used entry
+            size_t v = 0;
+            for (size_t i = 1; i < c->graphs.size(); ++i) if (c->graphs[i].stamp < c->graphs[v].stamp) v = i;
+            if (c->graphs[v].exec) hipGraphExecDestroy(c->graphs[v].exec);
+            c->graphs.erase(c->graphs.begin() + v);
+        }
+        c->graphs.push_back({B, Lmax, c->stop_stage, wav_dev, hidden_dev, nullptr, ++c->graph_clock});
+        return forward_launch(c, p, wav_dev, hidden_dev, s);
+    }
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = forward_launch(c, p, wav_dev, hidden_dev, s);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s, &graph);
+    if (rc != 0 || ec != hipSuccess || !graph) {
+        if (graph) hipGraphDestroy(graph);
+        if (rc == 0) syl_set_error("sylber_forward", "hipGraph capture failed");
+        return 1;
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (ei != hipSuccess) { syl_set_error("sylber_forward", "hipGraphInstantiate failed"); return 1; }
+    e->exec = exec; e->stamp = ++c->graph_clock;
+    HIP_TRY(hipGraphLaunch(exec, s));
     return 0;
 }
 

@@ -129,12 +129,27 @@ class HubertEncoderHIP:
         if lengths is not None:
             larr = (ctypes.c_int32 * B)(*[int(x) for x in lengths])
         self.lib.sylber_set_stop_stage(self.handle, int(stop_stage))
+        cur = torch.cuda.current_stream(wav.device)
+        use = cur
+        if getattr(self, "_graph_stream", None) is not None and cur.cuda_stream == 0:
+            # a hipGraph cannot be captured on the default stream: run on the handle's own stream, ordered both ways
+            use = self._graph_stream
+            use.wait_stream(cur)
         with torch.cuda.device(wav.device):
             st = self.lib.sylber_forward(self.handle, ctypes.c_void_p(wav.data_ptr()), larr, B, Lmax,
-                                         ctypes.c_void_p(out.data_ptr()), _stream_ptr(wav.device))
+                                         ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(use.cuda_stream))
+        if use is not cur:
+            cur.wait_stream(use)
         self.lib.sylber_set_stop_stage(self.handle, 0)
         _lib.check(st, "sylber_forward")
         return out
+
+    def set_graph_mode(self, enable: bool = True) -> None:
+        """Replay the forward's ~110 kernel launches from a captured hipGraph (per (B, Lmax, input, output buffers);
+        captured on the second call with the same key).  For launch-bound small batches; pass ``out=`` and reuse the
+        input buffer so that the key repeats."""
+        _lib.check(self.lib.sylber_set_graph_mode(self.handle, 1 if enable else 0), "sylber_set_graph_mode")
+        self._graph_stream = torch.cuda.Stream(device=self.device) if enable else None
 
     def segment(self, hidden: torch.Tensor, norm_threshold: float, merge_threshold: float, with_features: bool = True,
                 out=None):

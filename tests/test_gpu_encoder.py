@@ -118,3 +118,25 @@ def test_long_form_config(enc, sd):
     got = enc.forward(y.cuda().contiguous()).cpu().numpy()
     assert got.shape == ref.shape
     assert rel_rms(got, ref) < STAGE_TOL["hidden"]
+
+
+def test_graph_mode_replays_bitwise(sd):
+    """sylber_set_graph_mode: eager call, capturing call and replays give bit-identical hidden states, also after the
+    input buffer's CONTENTS change, for two shapes alternating, and with ragged lengths"""
+    from sylber_amd import HubertEncoderHIP
+    e = HubertEncoderHIP(sd)
+    ref = HubertEncoderHIP(sd)
+    e.set_graph_mode(True)
+    xa, xb = noise_batch(2, 24000, seed=41).cuda(), noise_batch(1, 16000, seed=42).cuda()
+    oa, ob = torch.empty(2, 74, 768, device="cuda"), torch.empty(1, 49, 768, device="cuda")
+    for it in range(5):
+        if it == 3:
+            xa.copy_(noise_batch(2, 24000, seed=43).cuda())          # same buffer, new audio
+        ha = e.forward(xa, [24000, 18000], out=oa).clone()
+        hb = e.forward(xb, None, out=ob).clone()
+        assert torch.equal(ha, ref.forward(xa, [24000, 18000]))
+        assert torch.equal(hb, ref.forward(xb, None))
+    # lengths are data, not part of the captured graph
+    assert torch.equal(e.forward(xa, [20000, 24000], out=oa), ref.forward(xa, [20000, 24000]))
+    e.set_graph_mode(False)
+    assert torch.equal(e.forward(xa, None, out=oa), ref.forward(xa, None))
