@@ -37,8 +37,15 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
                                                                 uint8_t* __restrict__ ctx_scale, long scale_rows) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (128 * QW) + wave * (32 * QW);
+    // 1-D launch, XCD-aware: workgroup i runs on XCD i % 8; xcd_remap hands every XCD a contiguous run of
+    // (utterance, head, query block) triples with the utterance slowest, i.e. the SAME utterances whose rows the
+    // q/k/v GEMM tiles of that XCD just wrote and whose context rows its out-projection tiles will read (both GEMMs
+    // split their row range into 8 contiguous chunks) -> producer and consumer share one 4 MB L2
+    const int nqb = (T + 128 * QW - 1) / (128 * QW);
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vid / (nqb * SYL_HEADS);
+    const int head = (vid / nqb) % SYL_HEADS;
+    const int q0 = (vid % nqb) * (128 * QW) + wave * (32 * QW);
     const int ql = lane & 31, h = lane >> 5;
     int nvalid = valid ? valid[b] : T;
     nvalid = nvalid < T ? nvalid : T;
@@ -235,7 +242,7 @@ static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* 
     // 64 queries per wave when there are enough query blocks to fill the chip, else 32
     int qw = ((long)((T + 255) / 256) * SYL_HEADS * B >= 512) ? 2 : 1;
     if (g_attn_qw) qw = g_attn_qw;
-    const dim3 grid(qw == 2 ? (T + 255) / 256 : (T + 127) / 128, SYL_HEADS, B);
+    const dim3 grid((qw == 2 ? (T + 255) / 256 : (T + 127) / 128) * SYL_HEADS * B);
     if (ctx_scale) {
         if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, ctx_scale, scale_rows);
         else hipLaunchKernelGGL((attention_bf16_kernel<1, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, ctx_scale, scale_rows);

@@ -184,7 +184,8 @@ template <int D, bool IN_BF16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     constexpr int V = D / 256;   // float4 groups per lane (2 for 512, 3 for 768)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + wave;
+    // XCD-aware row order: the rows an XCD normalises are the rows its GEMM tiles produced / will consume
+    const int m = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     if (m >= a.M) return;
     int orow = m;
     if (a.Tp > 0) {
