@@ -214,12 +214,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n):
+        if exchange:
+            # root scatter + gather inside every step, software-pipelined (dist.py run_stream): the gather of step i
+            # rides under the compute of step i+1
+            for _o in sharded.run_stream([root_batch] * n if rank == 0 else [None] * n, None, max_segments=160):
+                pass
+        else:
+            for _ in range(n):
+                step()
+
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -286,7 +294,7 @@ def main():
                        "global_batch": world * B, "clip_seconds": clip_seconds,
                        "ragged": ("lengths U[2 s, %g s], %.1f valid s of %g padded s per batch" % (clip_seconds, valid_seconds, B * clip_seconds))
                                  if args.ragged else None, "frames_per_clip": T_frames,
-                       "parallelism": "utterance-sharded x%d, %s" % (world, "root scatter + gather over RCCL in every step" if exchange
+                       "parallelism": "utterance-sharded x%d, %s" % (world, "root scatter + gather over RCCL in every step, gather(i) overlapped with compute(i+1)" if exchange
                                                                       else "shards resident per rank, no data-path collective"),
                        "pipelining": "none" if (exchange or args.no_overlap) else
                                      "%d batches in flight on independent handles/streams; segmenter on a side stream" % NPIPE,

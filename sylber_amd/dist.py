@@ -95,6 +95,99 @@ class ShardedSegmenter:
         hidden, seg, nseg, feats = self.compute(my_wav, my_lens)
         return self.gather(hidden, seg, nseg, feats, btot)
 
+    # ---- overlapped stream of batches --------------------------------------------------------------
+    def gather_async(self, hidden, seg, nseg, feats, btot: int, max_segments: int):
+        """Like ``gather`` but with asynchronous collectives and WITHOUT the host round trip that trims the pooled
+        features to the global max segment count: the first ``max_segments`` slots are exchanged instead (root
+        raises if an utterance has more).  Returns a zero-argument ``wait`` function."""
+        W = self.world
+        k = max(1, min(int(max_segments), seg.shape[1]))
+        parts = [hidden.contiguous(), seg[:, :k].contiguous(), nseg.contiguous(), feats[:, :k].contiguous()]
+        if W == 1:
+            def wait1():
+                if int(nseg[:btot].max()) > k:
+                    raise RuntimeError("an utterance has more than max_segments=%d segments" % k)
+                return tuple(t[:btot] for t in parts)
+            return wait1
+        outs, works = [], []
+        for t in parts:
+            o = [torch.empty_like(t) for _ in range(W)] if self.rank == 0 else None
+            works.append(dist.gather(t, o, dst=0, group=self.group, async_op=True))
+            outs.append(o)
+
+        def wait():
+            for wk in works:
+                wk.wait()
+            if self.rank != 0:
+                return None
+            res = tuple(torch.cat(o, 0)[:btot] for o in outs)
+            if int(res[2].max()) > k:
+                raise RuntimeError("an utterance has more than max_segments=%d segments" % k)
+            return res
+        _keep = parts                                      # the sources must outlive the collectives
+        wait.keep = _keep
+        return wait
+
+    def run_stream(self, batches_root, lengths_root=None, max_segments: int = 128):
+        """Generator over a sequence of root batches (``[Btot, Lmax]`` tensors on root, ``None`` elsewhere; every rank
+        must pass a sequence of the same length).  Software pipeline over ONE communicator, whose collectives
+        execute in issue order: the scatter of batch i+1 is issued BEFORE the compute of batch i, and the gather of
+        batch i after it, asynchronously — so gather(i) travels over xGMI while compute(i+1) runs, and scatter(i+2)
+        queues behind gather(i) without anybody waiting for it yet.  All shapes and lengths are broadcast ONCE up
+        front, so no step contains a host round trip.  Yields the gathered result of each batch in order (root:
+        tensors, other ranks: None)."""
+        batches = list(batches_root)
+        n = len(batches)
+        if n == 0:
+            return
+        W = self.world
+        # ---- one-off: (Btot, Lmax) of every batch and all lengths, to every rank
+        shapes = torch.zeros(n, 2, dtype=torch.int64, device=self.device)
+        if self.rank == 0:
+            for i, b in enumerate(batches):
+                shapes[i, 0], shapes[i, 1] = b.shape[0], b.shape[1]
+        if W > 1:
+            dist.broadcast(shapes, src=0, group=self.group)
+        shapes_h = shapes.tolist()
+        bmax = max(int(s_[0]) for s_ in shapes_h)
+        lens_all = torch.zeros(n, bmax, dtype=torch.int64, device=self.device)
+        if self.rank == 0:
+            for i, (bt, lm) in enumerate(shapes_h):
+                src = lengths_root[i] if (lengths_root is not None and lengths_root[i] is not None) else [lm] * bt
+                lens_all[i, :bt] = torch.as_tensor(list(src), dtype=torch.int64)
+        if W > 1:
+            dist.broadcast(lens_all, src=0, group=self.group)
+        lens_h = lens_all.tolist()
+
+        def scatter_known(i):
+            btot, lmax = int(shapes_h[i][0]), int(shapes_h[i][1])
+            bper = (btot + W - 1) // W
+            mine = (lens_h[i][:btot] + [lmax] * (bper * W - btot))[self.rank * bper:(self.rank + 1) * bper]
+            if W == 1:
+                return batches[i], mine, btot
+            my_wav = torch.empty(bper, lmax, dtype=torch.float32, device=self.device)
+            chunks = None
+            if self.rank == 0:
+                pad = bper * W - btot
+                full = batches[i] if pad == 0 else torch.cat(
+                    [batches[i], torch.zeros(pad, lmax, dtype=torch.float32, device=self.device)], 0)
+                chunks = list(full.contiguous().view(W, bper, lmax).unbind(0))
+            dist.scatter(my_wav, chunks, src=0, group=self.group)
+            return my_wav, mine, btot
+
+        nxt = scatter_known(0)
+        pending = None
+        for i in range(n):
+            my_wav, my_lens, btot = nxt
+            if i + 1 < n:
+                nxt = scatter_known(i + 1)                               # prefetch the next input
+            hidden, seg, nseg, feats = self.compute(my_wav, my_lens)
+            wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments)
+            if pending is not None:
+                yield pending()
+            pending = wait
+        yield pending()
+
     # ---- reference-shaped API on root ------------------------------------------------------------
     def __call__(self, wav: Optional[List[torch.Tensor]] = None, in_second: bool = True):
         """``wav``: list of [1, N] tensors on root (ignored elsewhere).  Root returns the same list of

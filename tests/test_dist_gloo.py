@@ -57,8 +57,30 @@ def _worker(rank, world, port, q):
     S = ShardedSegmenter(OracleEngine(sd), norm_threshold=2.6, merge_threshold=0.8)
     wavs = [syllable_wave(n, 60 + i) for i, n in enumerate(LENS)] if rank == 0 else None
     out = S(wavs, in_second=False)
+    # the overlapped stream of batches returns, batch by batch, exactly what the synchronous step returns
+    batches = lens = [None, None, None]
     if rank == 0:
+        sets = [LENS, LENS[1:4], LENS[::-1]]
+        lens = [list(ls) for ls in sets]
+        batches = []
+        for j, ls in enumerate(sets):
+            b = torch.zeros(len(ls), max(ls))
+            for i, n in enumerate(ls):
+                b[i, :n] = syllable_wave(n, 80 + 10 * j + i)[0]
+            batches.append(b)
+    sync = [S.step(b, l) for b, l in zip(batches, lens)]
+    streamed = list(S.run_stream(batches, lens, max_segments=64))
+    ok = True
+    if rank == 0:
+        for a, b in zip(sync, streamed):
+            k = b[1].shape[1]
+            ok &= torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+            n = int(a[2].max())
+            ok &= torch.equal(a[1][:, :n], b[1][:, :n]) and torch.equal(a[3][:, :n], b[3][:, :n]) and n <= k
         q.put([(o["segments"], o["segment_features"], o["hidden_states"]) for o in out])
+        q.put(bool(ok) and len(streamed) == 3)
+    else:
+        assert all(x is None for x in streamed)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -73,9 +95,11 @@ def test_two_rank_sharding_matches_single_process():
     for p in procs:
         p.start()
     got = q.get(timeout=300)
+    stream_ok = q.get(timeout=300)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    assert stream_ok, "run_stream (prefetched scatter + asynchronous gather) differs from the synchronous step"
     sd = synthetic_state_dict(0, num_layers=2)
     ref = SegmenterRef(sd, encoding_layer=2)([syllable_wave(n, 60 + i) for i, n in enumerate(LENS)], in_second=False)
     assert len(got) == len(ref) == len(LENS)
