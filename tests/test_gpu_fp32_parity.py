@@ -54,3 +54,30 @@ def test_e2e_segments_bit_identical_to_reference(S32, golden_dir):
         assert np.abs(o["hidden_states"] - g[f"batch{i}_hidden"]).max() < FP32_TOL
         assert np.array_equal(o["segments"], g[f"batch{i}_segments"])
         assert np.abs(o["segment_features"] - g[f"batch{i}_features"]).max() < FP32_TOL
+
+
+def test_sylber_segment_golden_bit_identical_segments(golden_dir):
+    """row N2 against the reference's own ``Sylber.segment`` output (tests/golden/sylber_segment.npz): in the fp32
+    parity mode the tensor-native ``Segmenter.segment`` returns bit-identical segment tables and the zero-padded
+    averaged features within fp32 accumulation noise"""
+    import os
+    import torch
+    from sylber_amd import Segmenter
+    from sylber_amd.synth import syllable_wave
+    from sylber_amd.weights import synthetic_state_dict
+    g = np.load(os.path.join(golden_dir, "sylber_segment.npz"))
+    lens = [int(x) for x in g["lens"]]
+    batch = torch.zeros(2, max(lens))
+    mask = torch.zeros(2, max(lens), dtype=torch.long)
+    for i, (n, s) in enumerate(zip(lens, g["seeds"])):
+        batch[i, :n] = syllable_wave(n, int(s))[0]
+        mask[i, :n] = 1
+    S = Segmenter(model_ckpt=synthetic_state_dict(0), precision="fp32")
+    feats, segments, avg_fts = S.segment(input_values=batch, attention_mask=mask, mergethreshold=0.8, normthreshold=2.6)
+    assert np.abs(feats[:, [0, -1]].cpu().numpy() - g["hidden_first_last"]).max() < 1e-4
+    for i in range(2):
+        assert np.array_equal(segments[i], g["segments%d" % i])
+    a = avg_fts.cpu().numpy()
+    assert a.shape == g["avg_fts"].shape
+    assert np.abs(a - g["avg_fts"]).max() < 1e-4
+    assert np.array_equal(a == 0.0, g["avg_fts"] == 0.0)

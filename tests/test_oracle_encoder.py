@@ -63,3 +63,28 @@ def test_e2e_matches_reference_goldens(sd, golden_dir):
     for i, r in enumerate(outs):
         assert np.abs(r["hidden_states"] - g[f"batch{i}_hidden"]).max() < FP32_TOL
         assert np.array_equal(r["segments"], g[f"batch{i}_segments"])
+
+
+def test_sylber_segment_golden_matches_oracle(golden_dir):
+    """row N2: the reference's own ``Sylber.segment`` (sylber.py:208-247) on a ragged two-clip batch
+    (tools/gen_golden_n2.py) vs the oracle path (hubert_ref forward + C get_segment + mean-pool)"""
+    import os
+    import numpy as np
+    import torch
+    from oracle import hubert_ref, segment_oracle
+    from sylber_amd.synth import syllable_wave
+    from sylber_amd.weights import synthetic_state_dict
+    g = np.load(os.path.join(golden_dir, "sylber_segment.npz"))
+    lens = [int(x) for x in g["lens"]]
+    batch = torch.zeros(2, max(lens))
+    for i, (n, s) in enumerate(zip(lens, g["seeds"])):
+        batch[i, :n] = syllable_wave(n, int(s))[0]
+    h = hubert_ref.forward(synthetic_state_dict(0), batch, lens)["hidden"].numpy()
+    assert np.abs(h[:, [0, -1]] - g["hidden_first_last"]).max() < 2e-5
+    for i in range(2):
+        seg = segment_oracle.get_segment(h[i], 2.6, 0.8)
+        assert np.array_equal(seg, g["segments%d" % i])
+        pooled = segment_oracle.mean_pool(h[i], seg)
+        # the reference pools with torch's mean here (sylber.py:235), numpy-order in Segmenter.__call__: last-ulp apart
+        assert np.abs(pooled - g["avg_fts"][i, : len(seg)]).max() < 2e-5
+        assert np.all(g["avg_fts"][i, len(seg):] == 0.0)                  # pad_sequence zero padding (:243)
