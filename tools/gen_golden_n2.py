@@ -39,6 +39,36 @@ def main():
     print("segments per clip:", [len(s) for s in segments], "avg_fts", tuple(avg_fts.shape))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "sylber_segment.npz"), **out)
     print("wrote tests/golden/sylber_segment.npz")
+    check_file_branch(ref, cfg_dir, sd)
+
+
+def check_file_branch(ref, cfg_dir, sd):
+    """The reference's FILE branch (sylber.py:79-87: torchaudio.load -> normalise -> batch) run for real on
+    samples/sample.wav and on a two-file list, with ``torchaudio.load`` provided by a stdlib ``wave`` reader of
+    16-bit PCM (int16 / 32768, what torchaudio.load returns); must reproduce the committed e2e golden, which was
+    generated through the tensor branch with the same normalisation ops."""
+    import tempfile
+    import wave
+    ta = sys.modules["torchaudio"]
+
+    def load(path):
+        with wave.open(str(path), "rb") as w:
+            assert w.getsampwidth() == 2
+            x = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+            return torch.from_numpy(x.reshape(-1, w.getnchannels()).T.copy()), w.getframerate()
+    ta.load = load
+    tmp = os.path.join(tempfile.gettempdir(), "sylber_synth_state.pt")
+    torch.save(sd, tmp)
+    S = ref.Segmenter(model_ckpt=tmp, speech_upstream=cfg_dir, device="cpu")
+    path = os.path.join(ref_shim.REFERENCE_ROOT, "samples", "sample.wav")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e.npz"))
+    out = S(wav_file=path, in_second=False)
+    assert np.array_equal(out["segments"], g["sample_segments"])
+    assert np.abs(out["hidden_states"] - g["sample_hidden"]).max() < 2e-5
+    outs = S(wav_file=[path, path], in_second=True)
+    assert isinstance(outs, list) and np.array_equal(outs[1]["segments"], g["sample_segments_sec"])
+    print("file branch of the reference reproduces the e2e golden: hidden max abs",
+          float(np.abs(out["hidden_states"] - g["sample_hidden"]).max()))
 
 
 if __name__ == "__main__":
