@@ -218,16 +218,25 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
                     if (h == 0) ctx_scale[mx_scale_index((long)b * Tp + q, 2 * head + ds, scale_rows)] = (uint8_t)e;
                 }
             }
-        } else if (q < T) {
-            bf16_t* dst = ctx + ((size_t)b * Tp + q) * SYL_HIDDEN + head * 64;
+        } else {
+            // the store tail is store-ISSUE bound (16 dwordx2 per lane): the lane halves swap one 4-feature run per pair
+            // of runs, so that each lane stores 8 consecutive features = 8 dwordx4 per lane, whole 32-byte sectors per
+            // lane pair (lane h = 0: d = 16p .. 16p+7, lane h = 1: d = 16p+8 .. 16p+15)
+            bf16_t* dst = ctx + ((size_t)b * Tp + (q < T ? q : 0)) * SYL_HIDDEN + head * 64;
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(oacc[qs][ds][4 * g + 0] * inv, oacc[qs][ds][4 * g + 1] * inv);
-                    pk.y = pack_bf16x2(oacc[qs][ds][4 * g + 2] * inv, oacc[qs][ds][4 * g + 3] * inv);
-                    *(uint2*)(dst + 32 * ds + 8 * g + 4 * h) = pk;
+                for (int pr = 0; pr < 2; ++pr) {
+                    uint2 ra, rb;
+                    ra.x = pack_bf16x2(oacc[qs][ds][8 * pr + 0] * inv, oacc[qs][ds][8 * pr + 1] * inv);
+                    ra.y = pack_bf16x2(oacc[qs][ds][8 * pr + 2] * inv, oacc[qs][ds][8 * pr + 3] * inv);
+                    rb.x = pack_bf16x2(oacc[qs][ds][8 * pr + 4] * inv, oacc[qs][ds][8 * pr + 5] * inv);
+                    rb.y = pack_bf16x2(oacc[qs][ds][8 * pr + 6] * inv, oacc[qs][ds][8 * pr + 7] * inv);
+                    const uint2 keep = h ? rb : ra, send = h ? ra : rb;
+                    uint2 got;
+                    got.x = (unsigned)__shfl_xor((int)send.x, 32, 64); got.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
+                    const uint4 out = h ? make_uint4(got.x, got.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, got.x, got.y);
+                    if (q < T) *(uint4*)(dst + 32 * ds + 16 * pr + 8 * h) = out;
                 }
         }
     }
