@@ -30,7 +30,8 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 #include "gemm_epilogue.h"
 
 static int g_gemm_wg_per_cu = 0;   // 0 = one workgroup per tile; k = persistent launch of k x 256 workgroups
-void gemm_set_wg_per_cu(int k) { g_gemm_wg_per_cu = k; }
+static int g_gemm8_persistent = 0; // 8-wave kernel: 0 = one workgroup per tile; 1 = 256 persistent workgroups
+void gemm_set_wg_per_cu(int k) { if (k >= 10) g_gemm8_persistent = k - 10; else g_gemm_wg_per_cu = k; }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -305,7 +306,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 // usual because the groups are staggered); fragment reads complete (lgkmcnt(0)) before the barrier that
 // lets the other group refill that slot.
 template <int FM, int FN, int WM, int WN, int EPI, int ACT>
-__global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
+__device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int tile_id, char* smem) {
     // K step 32 (64-byte LDS rows), 4-slot ring: the DMA of step s+3 is issued in step s and retired with
     // counted vmcnt, never 0 in the steady state.  (A 2-slot ring of 64-wide stages measured 5-12 % slower.)
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
@@ -315,7 +316,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     constexpr int NPW_HI = (NP + 7) / 8, NPW_LO = NP / 8;
     constexpr bool NATURAL = (EPI == EPI_V);
     static_assert(WM * WN == 8, "8 waves");
-    extern __shared__ __attribute__((aligned(256))) char smem[];
     const unsigned long long t_entry = ((EPI != EPI_PROJ) && (a.xpad_rows & 16)) ? __builtin_readcyclecounter() : 0ull;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
 
     const int tiles_n = (a.N + BN - 1) / BN;
     const int tiles_m = (a.M + BM - 1) / BM;
-    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int wg = xcd_remap(tile_id, tiles_m * tiles_n);
     const int m0 = (wg / tiles_n) * BM;
     const int n0 = (wg % tiles_n) * BN;
 
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     if (group == 0) __builtin_amdgcn_s_barrier();    // pairs with group 1's extra barrier
     const unsigned long long t_loop_end = now();
     if (timing && lane == 0 && a.out1 && wave < 4) {
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)tile_id * 4 + wave) * 8;
 #pragma unroll
         for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
         dbg[5] = t_loop - t_entry;
@@ -485,8 +485,28 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     }
     if (timing && lane == 0 && a.out1 && wave < 4) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)tile_id * 4 + wave) * 8;
         dbg[6] = __builtin_readcyclecounter() - t_loop_end;
+    }
+}
+
+
+// One launch = min(#tiles, 256 x per_cu) workgroups walking the tile list with stride gridDim.x (256 % 8 == 0, so a
+// workgroup's tiles all map to its own XCD's chunk).  Measured with rocprofv3 PMC (profiles/r01_mfma_util.md): the
+// one-tile-per-workgroup launch keeps the matrix pipe busy only 41 % of its resident cycles although the K loop alone
+// is at 81 % — every tile boundary costs a workgroup dispatch on a CU that holds nothing else.
+template <int FM, int FN, int WM, int WN, int EPI, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
+    const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gemm8_bf16_tile<FM, FN, WM, WN, EPI, ACT>(a, tile, smem);
+        if (tile + (int)gridDim.x < ntiles) {
+            // the ring is reused: this tile's epilogue staging reads and its stores' source data are done with LDS
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
 }
 
@@ -501,7 +521,9 @@ static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, a);
+    int grid = tiles;
+    if (g_gemm8_persistent > 0 && tiles > g_gemm8_persistent * 256) grid = g_gemm8_persistent * 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -16,7 +16,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sequential --
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fp8 -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --precision fp8 > $OUT/trace_fp8.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/pmc_mfma -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > $OUT/pmc_mfma.log 2>&1
 cd $ROOT
+cp $(find $OUT/pmc_mfma -name '*counter_collection.csv' | head -1) $OUT/mfma_counters.csv
+rm -rf $OUT/pmc_mfma
 mkdir -p $OUT/traffic
 cp $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) $OUT/traffic/FETCH_SIZE_counter_collection.csv
 cp $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1) $OUT/traffic/WRITE_SIZE_counter_collection.csv
