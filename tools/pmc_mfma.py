@@ -52,7 +52,8 @@ def main(src, dst):
                 "GRBM_GUI_ACTIVE advances at ~2.0 GHz over the same dispatch.  SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles, GRBM_GUI_ACTIVE",
                 "does not stop when the power manager withholds shader clocks: MfmaUtil above (41 % for the 8-wave kernel) x 2.0 / 1.3 ~ 60 % of",
                 "the shader cycles that actually ran.  I.e. roughly one third of the nominal cycles is lost to the power limit under this",
-                "MFMA + LDS + LDS-DMA mix (an MFMA-only loop on this box sustains 1.75-1.93 PF = 70-77 % of the 2.4 GHz peak,",
+                "MFMA + LDS + LDS-DMA mix (`tools/ubench/clock_calib.hip`: s_memtime IS the shader clock - 2.396 GHz on an idle chip, 2.2 GHz",
+                "under a dependent-MFMA load on every SIMD; an MFMA-only loop on this box sustains 1.75-1.93 PF = 70-77 % of the 2.4 GHz peak,",
                 "profiles/r01_mfma_ceiling.md), and the remaining gap to the 2.5 PF roofline is prologue / epilogue time at K = 768-1536."]
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out))
