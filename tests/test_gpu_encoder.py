@@ -140,3 +140,24 @@ def test_graph_mode_replays_bitwise(sd):
     assert torch.equal(e.forward(xa, [20000, 24000], out=oa), ref.forward(xa, [20000, 24000]))
     e.set_graph_mode(False)
     assert torch.equal(e.forward(xa, None, out=oa), ref.forward(xa, None))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_ragged_batches_vs_oracle(enc, sd, seed):
+    """random batch size, random lengths down to the one-frame minimum (400 samples), random batch maximum: every row
+    within the stage tolerance of the CPU oracle, padded frames included, and bitwise reproducible"""
+    rng = np.random.default_rng(100 + seed)
+    B = int(rng.integers(1, 6))
+    lmax = int(rng.integers(2000, 30000))
+    lens = [int(x) for x in rng.integers(400, lmax + 1, B)]
+    lens[int(rng.integers(0, B))] = lmax
+    x = noise_batch(B, lmax, seed=200 + seed)
+    for i, n in enumerate(lens):
+        x[i, n:] = 0.0
+    out = enc.forward(x.cuda(), lens)
+    assert torch.equal(out, enc.forward(x.cuda(), lens))
+    ref = hubert_ref.forward(sd, x, lens)["hidden"].numpy()
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    for i in range(B):
+        assert rel_rms(got[i], ref[i]) < STAGE_TOL["hidden"], (i, lens)
