@@ -271,6 +271,17 @@ def main():
                     "avg_launch_ms": round(gemm_ms / n_launch, 4), "flops_per_forward": gemm_fl,
                     "per_launch_tflops": {k: round(fl[k] / (kernels[k] * 1e-3) / 1e12, 1) for k in fl if kernels.get(k)}}
 
+    # the HBM-bound end of the path (north_star: "achieved HBM GB/s on the conv frontend"): conv0 + GroupNorm + GELU
+    # writes the channels-last bf16 activation once and reads the waveform once
+    frontend = None
+    if rank == 0 and kernels.get("conv0_gn_gelu"):
+        rows0 = ((T_frames + 3) // 4 * 4) * 64                 # R_0 = Tp * 2^6 rows per utterance (Tp = frames rounded up to 4)
+        fe_bytes = B * (rows0 * 512 * 2 + clip_samples * 4)
+        fe_gbs = fe_bytes / (kernels["conv0_gn_gelu"] * 1e-3) / 1e9
+        frontend = {"bound": "hbm", "kernel": "conv0_gn_gelu_kernel (Conv1d(1->512,k10,s5) + GroupNorm + GELU, bf16 channels-last out)",
+                    "achieved": round(fe_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(fe_gbs / 8000.0, 4),
+                    "algorithmic_bytes_per_launch": fe_bytes}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd)
@@ -299,7 +310,7 @@ def main():
                        "pipelining": "none" if (exchange or args.no_overlap) else
                                      "%d batches in flight on independent handles/streams; segmenter on a side stream" % NPIPE,
                        "gflop_per_clip": 124.65 if clip_samples == CLIP_SAMPLES else None},
-            "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_forward": kernels,
+            "roofline": roofline, "roofline_frontend": frontend, "cpu_baseline": cpu, "kernel_ms_per_forward": kernels,
             "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2), "segments_per_clip": seg_stats,
         }
         print(json.dumps(line), flush=True)
