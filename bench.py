@@ -126,7 +126,15 @@ def main():
         local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            except Exception as e:  # noqa: BLE001 - the default line has no data-path collective: keep it measurable
+                print("bench.py: RCCL initialisation failed (%s); control barrier / max-reduce fall back to gloo" % (e,),
+                      file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 1)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
