@@ -137,3 +137,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     } while (0)
 
 void syl_set_error(const char* what, const char* detail);
+
+// "has this kernel's dynamic-LDS attribute been raised on the CURRENT device yet" — function attributes are per device,
+// and a process may hold handles on several GPUs; one instance per launcher template instantiation
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool need() { int d = 0; (void)hipGetDevice(&d); d &= 63; if (done[d]) return false; done[d] = true; return true; }
+};

@@ -116,8 +116,8 @@ int launch_attention_f32(const float* q, const float* k, const float* v, const i
     if (k != q + SYL_HIDDEN || v != q + 2 * SYL_HIDDEN) { syl_set_error("launch_attention_f32", "expects a fused qkv buffer"); return 1; }
     const size_t lds = (size_t)4 * T * sizeof(float);
     if (lds > 64 * 1024) {
-        static bool set = false;
-        if (!set) { HIP_TRY(hipFuncSetAttribute((const void*)attention_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+        static PerDeviceOnce once;
+        if (once.need()) HIP_TRY(hipFuncSetAttribute((const void*)attention_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (lds > 160 * 1024) { syl_set_error("launch_attention_f32", "T too large for the fp32 parity kernel"); return 1; }
     }
     hipLaunchKernelGGL(attention_f32_kernel, dim3((T + 3) / 4, SYL_HEADS, B), dim3(256), lds, s, q, 3 * SYL_HIDDEN, valid, ctx, T, Tp);

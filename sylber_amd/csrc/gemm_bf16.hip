@@ -281,11 +281,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = NSTAGE * (BM + BN) * BK * 2;
     if (a.K % BK != 0) { syl_set_error("launch_gemm_bf16", "K must be a multiple of the K step"); return 1; }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
     auto kern = gemm_bf16_kernel<FM, FN, BK, NSTAGE, MINB, PRIO, EPI, ACT>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
     }
     int grid = tiles;
     if (g_gemm_wg_per_cu > 0 && tiles > g_gemm_wg_per_cu * 256) grid = g_gemm_wg_per_cu * 256;
@@ -515,11 +514,10 @@ static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDS = 4 * (BM + BN) * 64;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
     auto kern = gemm8_bf16_kernel<FM, FN, WM, WN, EPI, ACT>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
     }
     int grid = tiles;
     if (g_gemm8_persistent > 0 && tiles > g_gemm8_persistent * 256) grid = g_gemm8_persistent * 256;

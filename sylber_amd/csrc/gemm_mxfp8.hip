@@ -443,11 +443,10 @@ static int launch_f8_8(const GemmF8Args& a, hipStream_t s) {
     constexpr int LDS = 4 * ((BM + BN) * 64 + 1024);
     if ((a.xs_rows & 7) || (a.ws_rows & 7) || a.xs_rows < 8 || a.ws_rows < 8) { syl_set_error("launch_gemm_mxfp8", "scale pitches must be multiples of 8"); return 1; }
     const int tiles = ((a.g.M + BM - 1) / BM) * ((a.g.N + BN - 1) / BN);
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
     auto kern = gemm8_mxfp8_kernel<FM, FN, WM, WN, EPI, ACT>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
@@ -459,11 +458,10 @@ static int launch_f8(const GemmF8Args& a, hipStream_t s) {
     constexpr int BM = 64 * FM, BN = 64 * FN;
     constexpr int LDS = 2 * (BM + BN) * 128;
     const int tiles = ((a.g.M + BM - 1) / BM) * ((a.g.N + BN - 1) / BN);
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
     auto kern = gemm_mxfp8_kernel<FM, FN, EPI, ACT>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS, s, a);
     HIP_TRY(hipGetLastError());

@@ -120,11 +120,10 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
 int launch_posconv(const bf16_t* xpad, const bf16_t* wpk, const float* bias, const float* x_f32, float* out, int B, int Tp,
                    int act, hipStream_t s) {
     dim3 grid((Tp + PC_BM - 1) / PC_BM, SYL_POSG, B);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
-        attr_set = true;
     }
     if (act == 2) hipLaunchKernelGGL(posconv_bf16_kernel<2>, grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
     else hipLaunchKernelGGL(posconv_bf16_kernel<1>, grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);

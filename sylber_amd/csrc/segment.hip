@@ -281,11 +281,8 @@ int launch_segment(const float* hidden, int B, int T, int D, float norm_thr, flo
     if (D != SEG_D) { syl_set_error("launch_segment", "feature dim must be 768"); return 1; }
     const size_t lds = segment_lds_bytes(T);
     if (T < 1 || lds > 160 * 1024) { syl_set_error("launch_segment", "T must be in [1, 3940] (160 KiB of LDS per utterance)"); return 1; }
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        HIP_TRY(hipFuncSetAttribute((const void*)segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
-    }
+    static PerDeviceOnce once;                           // raise the limit to the full 160 KiB once per device
+    if (once.need()) HIP_TRY(hipFuncSetAttribute((const void*)segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(segment_kernel, dim3(B), dim3(256), lds, s, hidden, T, norm_thr, merge_thr, seg, nseg, feat);
     HIP_TRY(hipGetLastError());
     return 0;
