@@ -5,18 +5,21 @@
 // (TP:112-124, as implicit GEMM on channels-last activations: ldx = stride*512, K = taps*512), the
 // feature projection (TP:225-231), q/k/v/out projections (TP:318-342) and the FFN (TP:361-368).
 //
-// Structure: one 256-thread workgroup (4 waves as 2x2, ONE wave per SIMD) per output tile of
-// (64*FM) x (64*FN); a wave owns FM x FN v_mfma_f32_32x32x16_bf16 fragments (256x128: 128 fp32
-// accumulators/lane, 8 MFMAs per 6 ds_read_b128).  K step 64.  Both operands are staged HBM -> LDS
-// with global_load_lds_dwordx4 (no VGPR round trip) into a 3-slot ring: the loads of tile t+2 are
-// issued before the MFMAs of tile t and stay in flight ACROSS the per-tile barrier (raw s_barrier +
-// counted s_waitcnt vmcnt(N), never vmcnt(0) in the steady state).  The LDS image is lane-linear
-// per wave instruction (8 rows x 128 B), so the bank-conflict swizzle (16-B chunk ^= (row>>1)&7,
-// conflict-free for ds_read_b128's 16-lane groups on 128-B rows) is applied to the per-lane SOURCE
-// address and again on the fragment read.  Fragments of k-substep kk+1 are read while the MFMAs of
-// kk issue.  Tile shape is picked per launch to minimise the last partial round over 256 CUs
-// (e.g. 128x192 for M=16000,N=768: 500 tiles = 1.95 rounds).  Workgroup ids are remapped so that
-// each XCD owns a contiguous run of tiles (shared X panel in L2).
+// Two kernels share the staging scheme and the epilogues:
+//   * gemm_bf16_kernel: 256 threads (4 waves as 2x2), tile (64 FM) x (64 FN), K step 64 (128-byte LDS rows), 2-slot
+//     ring, TWO workgroups per CU (tiles 128x128 / 128x192): the second workgroup covers the first one's epilogue,
+//     barrier and LDS-DMA issue time.  Used for the N = 768 / 1536 launches (500 / 1000 tiles = 1 / 2 rounds).
+//   * gemm8_bf16_kernel (below): 512 threads, tile 256x256, K step 32, 4-slot ring, one workgroup per CU, the two
+//     wave groups staggered by one barrier.  Used for the big GEMMs (convs, FFN1).
+// Both operands are staged HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip); the loads of the next tile(s)
+// are issued between the MFMAs of the current one and stay in flight ACROSS the per-tile barrier (raw s_barrier +
+// counted s_waitcnt vmcnt(N), never vmcnt(0) in the steady state).  The LDS image is lane-linear per wave
+// instruction (8 rows x 128 B), so the bank-conflict swizzle (16-B chunk ^= (row>>1)&7, conflict-free for
+// ds_read_b128's 16-lane groups on 128-B rows; (row>>2)&3 on 64-B rows) is applied to the per-lane SOURCE address
+// and again on the fragment read.  Fragments of k-substep kk+1 are read while the MFMAs of kk issue.  Tile shape is
+// picked per launch by a measured cost model (rounds over 256 CUs x tile area / efficiency).  Workgroup ids are
+// remapped so that each XCD owns a contiguous run of tiles (shared X panel in L2; same row ownership as the
+// LayerNorm / attention launches between the GEMMs).
 #include "kernels.h"
 
 
