@@ -278,6 +278,18 @@ def main():
                                     "~160 MB per launch (8.3 GB of operands/outputs over 52 launches)",
                     "avg_launch_ms": round(gemm_ms / n_launch, 4), "flops_per_forward": gemm_fl,
                     "per_launch_tflops": {k: round(fl[k] / (kernels[k] * 1e-3) / 1e12, 1) for k in fl if kernels.get(k)}}
+        # the single dominant instantiation (40 % of the device time): the 8-wave 256x256 kernel with the GELU epilogue =
+        # conv1..conv5 + 9 x FFN1; its rocprofv3 row is "gemm8_bf16_kernel<4, 2, 2, 4, 0, 1>" (profiles/r01_kernel_stats_sequential.csv)
+        if clip_samples == CLIP_SAMPLES and B == BATCH_PER_GPU and args.precision == "bf16":
+            big = ["gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_ffn1"]
+            n_big = 5 + 9
+            ms_big = sum(kernels.get(k, 0.0) for k in big)
+            fl_big = sum(fl[k] for k in big)
+            if ms_big > 0:
+                roofline["dominant_instantiation"] = {
+                    "kernel": "gemm8_bf16_kernel<4, 2, 2, 4, 0, 1>", "launches_per_forward": n_big,
+                    "avg_launch_ms": round(ms_big / n_big, 4), "achieved": round(fl_big / (ms_big * 1e-3) / 1e12, 1),
+                    "frac": round(fl_big / (ms_big * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
     # the HBM-bound end of the path (north_star: "achieved HBM GB/s on the conv frontend"): conv0 + GroupNorm + GELU
     # writes the channels-last bf16 activation once and reads the waveform once
