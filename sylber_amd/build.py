@@ -48,7 +48,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+            errs = [ln for ln in r.stderr.splitlines() if "error" in ln]
+            raise RuntimeError("hipcc failed for %s:\n%s\n...\n%s" % (src, "\n".join(errs[:20]), r.stderr[-1500:]))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
