@@ -2,35 +2,87 @@
 """Throughput benchmark of the Segmenter hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 with no WORLD_SIZE in the environment re-executes itself under ``python -m torch.distributed.run``
+(one rank per GPU, rendezvous on 127.0.0.1) and fails loudly when fewer than N GPUs are visible; launched
+by an external ``torch.distributed.run`` it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
 A step = one pass of the hot path over one batch of synthetic input: waveform batch resident in HBM
 -> 7-layer conv frontend -> 9-layer HuBERT encoder -> boundary detection + segment mean-pool, outputs
 (hidden_states, segments, segment_features) left in HBM.  Workload = BASELINE.json configs[1]:
 32 x 10 s x 16 kHz random waveforms per GPU, synthetic seeded weights of the sylber_base geometry
-(no network for the real checkpoint), bf16 MFMA compute with fp32 accumulation/residual stream.
-Weak scaling: every rank processes its own resident 32-clip shard (cfg3 = 256 clips on 8 GPUs); the path
-shards over utterances with no collective inside it, so the timed steps contain none (only the closing
-barrier / max-reduce of the contract).  `--exchange` adds the root scatter of waveforms and the gather of all
-outputs over RCCL to every step (sylber_amd/dist.py).
+(no network for the real checkpoint), bf16 MFMA compute with fp32 accumulation / residual stream.
+
+N = 1: the shard is resident in HBM when the timed region starts.
+N > 1 (BASELINE configs[2], weak scaling, 32 clips per GPU): the job's N x 32 clips are resident on RANK 0 and every
+timed step contains the RCCL exchange of sylber_amd/dist.py::ShardedSegmenter.run_stream: root scatters the
+waveform blocks over xGMI, every rank encodes + segments its block, root gathers hidden states, segment tables,
+counts and pooled features; the gather of step i travels under the compute of step i+1.  The resident-shard
+figure (no data-path collective) is reported next to it as ``resident_shards``.  ``--no-exchange`` swaps the two.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 CLIP_SAMPLES = 160000
 CLIP_SECONDS = 10.0
 BATCH_PER_GPU = 32
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0               # same guide: 8 TB/s spec (6.3 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N>1: time resident shards (no data-path collective) as `value`; the exchange figure moves to `exchange`")
+    ap.add_argument("--no-overlap", action="store_true", help="one batch in flight, segmenter on the forward stream")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight (independent handles/streams)")
+    ap.add_argument("--precision", choices=["bf16", "fp8", "fp32"], default="bf16",
+                    help="bf16 = BASELINE configs[1] (the headline); fp8 = configs[4] (MXFP8 weight GEMMs); fp32 = the exact "
+                         "parity mode (f32 MFMA), reported so that its cost is a number")
+    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph (small, launch-bound batches)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="clip lengths U[2 s, clip-seconds] (seeded), padded to the batch maximum like sylber.py:93-118; value "
+                         "counts VALID audio only -> the padding overhead of the reference's batching contract (not the headline)")
+    ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS,
+                    help="clip length; 10 = BASELINE configs[1] (default), 60 with --batch 8 = configs[3] (long-form)")
+    ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
+    ap.add_argument("--agreement-clips", type=int, default=0,
+                    help="also report bf16-vs-fp32 segment agreement on this many synthetic clips (fp32 parity mode as truth)")
+    return ap.parse_args()
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible to PyTorch-ROCm; refusing to "
+                         "oversubscribe (one rank per GPU)\n" % (args.gpus, have))
+        sys.exit(2)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def gemm_flops_per_forward(B: int, n_samples: int = CLIP_SAMPLES) -> dict:
@@ -47,17 +99,32 @@ def gemm_flops_per_forward(B: int, n_samples: int = CLIP_SAMPLES) -> dict:
     for i in range(1, 7):
         f[f"gemm_conv{i}"] = 2.0 * L[i] * 512 * 512 * K[i] * B
     f["gemm_proj"] = 2.0 * T * 512 * 768 * B
-    f["gemm_qk"] = 9 * 2 * 2.0 * T * 768 * 768 * B
-    f["gemm_v"] = 9 * 2.0 * T * 768 * 768 * B
+    f["gemm_qkv"] = 9 * 3 * 2.0 * T * 768 * 768 * B
     f["gemm_out"] = 9 * 2.0 * T * 768 * 768 * B
     f["gemm_ffn1"] = 9 * 2.0 * T * 768 * 3072 * B
     f["gemm_ffn2"] = 9 * 2.0 * T * 768 * 3072 * B
     return f
 
 
+# launch names that share FLOPs with an entry of gemm_flops_per_forward (older / alternative launch splits)
+GEMM_ALIASES = {"gemm_qkv": ("gemm_qkv", "gemm_qk", "gemm_v")}
+
+
+def csrc_sha16() -> str:
+    """Identity of the kernel sources a committed PMC figure was collected with."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sylber_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(sd, seconds_budget=25.0):
     """The CPU restatement of the same path (oracle/: torch fp32 ops in the reference's order +
     C get_segment), timed on this box's host cores on a bounded sample of the same workload."""
+    import torch
     from oracle.segmenter_ref import SegmenterRef
     from sylber_amd.synth import noise_batch
     ref = SegmenterRef(sd)
@@ -91,53 +158,40 @@ def cpu_baseline(sd, seconds_budget=25.0):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="clips per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", action="store_true",
-                    help="N>1: include the root scatter of waveforms and the gather of all outputs (RCCL) in every step")
-    ap.add_argument("--no-overlap", action="store_true", help="run the segmenter on the forward stream (no pipelining)")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight (independent handles/streams)")
-    ap.add_argument("--gemm-wg-per-cu", type=int, default=0,
-                    help="4-wave GEMM launches: 0 = one workgroup per tile, k = persistent k x 256 workgroups")
-    ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
-                    help="bf16 = BASELINE configs[1] (the headline); fp8 = configs[4]: FFN GEMMs on MXFP8 operands (not the headline)")
-    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph (small, launch-bound batches)")
-    ap.add_argument("--ragged", action="store_true",
-                    help="clip lengths U[2 s, clip-seconds] (seeded), padded to the batch maximum like sylber.py:93-118; value "
-                         "counts VALID audio only -> the padding overhead of the reference's batching contract (not the headline)")
-    ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS,
-                    help="clip length; 10 = BASELINE configs[1] (default), 60 with --batch 8 = configs[3] (long-form)")
-    args = ap.parse_args()
+    args = parse_args()
+    maybe_spawn(args)
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if world != max(args.gpus, 1):
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
+    rccl_ranks = 1
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # SYLBER_DIST_BACKEND=gloo is a development aid: it lets the N>1 control flow (rendezvous, barriers,
-        # max-over-ranks) be exercised with several ranks sharing the one GPU of a development box
+        # SYLBER_DIST_BACKEND=gloo is a development aid only (several ranks sharing the one GPU of a development box);
+        # one rank per GPU is enforced otherwise
         backend = os.environ.get("SYLBER_DIST_BACKEND", "nccl")
-        local_rank %= max(1, torch.cuda.device_count())
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and ndev < world:
+            sys.stderr.write("bench.py: %d ranks but %d visible GPU(s)\n" % (world, ndev))
+            sys.exit(2)
+        local_rank %= max(1, ndev)
         torch.cuda.set_device(local_rank)
+        import datetime
         if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            except Exception as e:  # noqa: BLE001 - the default line has no data-path collective: keep it measurable
-                print("bench.py: RCCL initialisation failed (%s); control barrier / max-reduce fall back to gloo" % (e,),
-                      file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29511")) + 1)
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=300))
+            rccl_ranks = dist.get_world_size()
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
+            rccl_ranks = 0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -149,14 +203,18 @@ def main():
     clip_seconds = args.clip_seconds
     clip_samples = int(round(clip_seconds * 16000))
     sd = synthetic_state_dict(0)
-    enc = HubertEncoderHIP(sd, device=str(dev), precision=args.precision)
-    if args.gemm_wg_per_cu:
-        enc.lib.sylber_debug_force_gemm_cfg(-200 - args.gemm_wg_per_cu)
-    sharded = ShardedSegmenter(enc)
     B = args.batch
-    exchange = world > 1 and args.exchange
-    # inputs resident in HBM before the timed region: rank r holds clips [r*B, (r+1)*B) of the seeded job;
-    # with the exchange enabled the root additionally holds the whole job and scatters it every step
+    NPIPE = 1 if args.no_overlap else max(1, args.inflight)
+    encs = [HubertEncoderHIP(sd, device=str(dev), precision=args.precision) for _ in range(NPIPE)]
+    enc = encs[0]
+    if args.graph:
+        for e_ in encs:
+            e_.set_graph_mode(True)
+    T_frames = enc.num_frames(clip_samples)
+    on_cpu_group = world > 1 and dist.get_backend() != "nccl"
+
+    # inputs resident in HBM before the timed region: rank r holds clips [r*B, (r+1)*B) of the seeded job; for the
+    # exchange the root additionally holds the whole job (N x B clips) and scatters it every step
     my_batch = noise_batch(B, clip_samples, seed=1000 + rank).to(dev)
     lengths = None
     valid_seconds = B * clip_seconds
@@ -168,22 +226,39 @@ def main():
         for i, n in enumerate(lengths):
             my_batch[i, n:] = 0.0                              # right zero padding (sylber.py:104-106)
         valid_seconds = sum(lengths) / 16000.0
-    root_batch = None
-    if exchange and rank == 0:
-        root_batch = torch.cat([noise_batch(B, clip_samples, seed=1000 + r) for r in range(world)], 0).to(dev)
 
-    # Pipelining across steps (a serving loop keeps more than one batch in flight): NPIPE encoder handles, each
-    # with its own workspace and HIP stream, take the steps round-robin, so kernels of consecutive batches
-    # overlap on the chip — the one-round launches (500 tiles on 512 workgroup slots) leave their prologue /
-    # epilogue phases uncovered otherwise — and the boundary detection of batch i (one workgroup per utterance,
-    # 32 of 256 CUs) runs on a side stream.  Every step is still one full pass over one 32-clip batch; all work
-    # is complete before the closing device synchronize of the timed region.
-    T_frames = enc.num_frames(clip_samples)
-    NPIPE = 1 if (exchange or args.no_overlap) else args.inflight
-    encs = [enc] + [HubertEncoderHIP(sd, device=str(dev), precision=args.precision) for _ in range(NPIPE - 1)]
-    if args.graph:
-        for e_ in encs:
-            e_.set_graph_mode(True)
+    def barrier():
+        torch.cuda.synchronize(dev)               # device-wide: every stream of this rank has drained
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if on_cpu_group else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(run_steps):
+        """contract: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize, MAX over ranks.
+        run_steps(n) returns one timing-enabled event per step (recorded where the step's last kernel was issued)."""
+        run_steps(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        evs = run_steps(args.steps)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        # per-step time from the completion events: with P batches in flight completions arrive in bursts, so a step's
+        # time is the distance to the completion P steps later, divided by P
+        P = max(1, NPIPE)
+        gaps = [evs[i].elapsed_time(evs[i + P]) / P for i in range(len(evs) - P)] if evs and len(evs) > P else []
+        return elapsed, (statistics.median(gaps) if gaps else None)
+
+    # ---- resident shards: NPIPE encoder handles (own workspace + HIP stream) take the steps round-robin, so kernels
+    # of consecutive batches overlap on the chip; boundary detection of batch i (one workgroup per utterance) runs on a
+    # side stream.  Every step is one full pass over one B-clip batch; all work is complete before the closing
+    # device synchronize of the timed region.
     streams = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
     sides = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
     bufs = [(torch.empty(B, T_frames, 768, device=dev),
@@ -192,56 +267,69 @@ def main():
     seg_done = [None] * NPIPE
     state = {"i": 0}
 
-    def step():
-        if exchange:
-            return sharded.step(root_batch, None)
-        if args.no_overlap:
-            hidden = enc.forward(my_batch, lengths, out=bufs[0][0])
-            return (hidden,) + tuple(enc.segment(hidden, 2.6, 0.8, out=bufs[0][1]))
-        k = state["i"] % NPIPE
-        state["i"] += 1
-        hidden, seg_out = bufs[k]
-        main, side = streams[k], sides[k]
-        with torch.cuda.stream(main):
-            if seg_done[k] is not None:
-                main.wait_event(seg_done[k])      # the segmenter that last read this buffer set has finished
-            encs[k].forward(my_batch, lengths, out=hidden)
-            ready = torch.cuda.Event()
-            ready.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        seg_done[k] = ev
-        return (hidden,) + seg_out
+    def resident_steps(n):
+        evs = []
+        for _ in range(n):
+            k = state["i"] % NPIPE
+            state["i"] += 1
+            hidden, seg_out = bufs[k]
+            main_s, side = streams[k], sides[k]
+            with torch.cuda.stream(main_s):
+                if seg_done[k] is not None:
+                    main_s.wait_event(seg_done[k])      # the segmenter that last read this buffer set has finished
+                encs[k].forward(my_batch, lengths, out=hidden)
+                if args.no_overlap:
+                    encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(main_s)
+                    evs.append(ev)
+                    continue
+                ready = torch.cuda.Event()
+                ready.record(main_s)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(side)
+            seg_done[k] = ev
+            evs.append(ev)
+        return evs
 
-    def barrier():
-        torch.cuda.synchronize(dev)               # device-wide: every stream of this rank has drained
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+    # ---- exchange (N > 1 default): root scatter + gather over RCCL inside every step
+    sharded = ShardedSegmenter(encs)
+    root_batch = None
+    if world > 1 and rank == 0:
+        root_batch = torch.cat([noise_batch(B, clip_samples, seed=1000 + r) for r in range(world)], 0).to(dev)
 
-    def run_steps(n):
-        if exchange:
-            # root scatter + gather inside every step, software-pipelined (dist.py run_stream): the gather of step i
-            # rides under the compute of step i+1
-            for _o in sharded.run_stream([root_batch] * n if rank == 0 else [None] * n, None, max_segments=160):
-                pass
-        else:
-            for _ in range(n):
-                step()
+    def exchange_steps(n):
+        evs = []
+        src = [root_batch] * n if rank == 0 else [None] * n
+        for _o in sharded.run_stream(src, None, max_segments=min(T_frames, 192)):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(dev))
+            evs.append(ev)
+        return evs
 
-    run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    exchange_first = world > 1 and not args.no_exchange
+    secondary = None
+    exchange_error = None
+    if exchange_first:
+        try:
+            elapsed, med_ms = timed(exchange_steps)
+        except Exception as e:  # noqa: BLE001 - keep a measurable line; the failure is reported in the line itself
+            exchange_error = "%s: %s" % (type(e).__name__, e)
+            exchange_first = False
+    if exchange_first:
+        r_elapsed, r_med = timed(resident_steps)
+        secondary = ("resident_shards", r_elapsed, r_med)
+    else:
+        elapsed, med_ms = timed(resident_steps)
+        if world > 1 and exchange_error is None:
+            try:
+                x_elapsed, x_med = timed(exchange_steps)
+                secondary = ("exchange", x_elapsed, x_med)
+            except Exception as e:  # noqa: BLE001
+                exchange_error = "%s: %s" % (type(e).__name__, e)
     total_audio = world * valid_seconds * args.steps           # (ragged: rank 0's draw stands for every rank)
     value = total_audio / elapsed
 
@@ -249,7 +337,8 @@ def main():
     # perturb the launch stream slightly, so they are kept out of the throughput timing above)
     roofline = None
     kernels = {}
-    if rank == 0:
+    frontend = None
+    if rank == 0 and args.precision != "fp32":
         enc.set_profiling(True)
         nprof = max(3, min(args.steps, 10))
         for _ in range(nprof):
@@ -260,26 +349,38 @@ def main():
         enc.set_profiling(False)
         kernels = {k: round(v / nprof, 4) for k, v in prof.items()}      # ms per forward
         fl = gemm_flops_per_forward(B, clip_samples)
-        gemm_ms = sum(kernels.get(k, 0.0) for k in fl)
+        ms_of = {k: sum(kernels.get(a, 0.0) for a in GEMM_ALIASES.get(k, (k,))) for k in fl}
+        gemm_ms = sum(ms_of.values())
         gemm_fl = sum(fl.values())
-        n_launch = 6 + 1 + 9 * 5
+        n_launch = sum(1 for k in kernels if k.startswith("gemm_conv") or k == "gemm_proj") + 9 * sum(
+            1 for k in ("gemm_qkv", "gemm_qk", "gemm_v", "gemm_out", "gemm_ffn1", "gemm_ffn2") if k in kernels)
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath) and B == BATCH_PER_GPU and clip_samples == CLIP_SAMPLES:
-            # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
-            # (FETCH_SIZE x2 + WRITE_SIZE, separate passes; tools/pmc_traffic.py) -- PMC cannot be read live
-            traffic = round(json.load(open(tpath))["gemm_family_bytes_per_launch"])
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all %d launches per forward: 6 implicit-GEMM convs, "
-                    "projection, 9 x {qk, v, out, ffn1, ffn2})" % n_launch,
+        traffic, traffic_note = None, "no PMC pass committed for these kernel sources"
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+        if os.path.exists(tpath) and B == BATCH_PER_GPU and clip_samples == CLIP_SAMPLES and args.precision == "bf16":
+            # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 +
+            # WRITE_SIZE, separate passes; tools/pmc_traffic.py).  PMC cannot be read live, so the figure is only
+            # repeated when the kernel sources are the ones it was collected with.
+            tj = json.load(open(tpath))
+            if tj.get("csrc_sha16") == csrc_sha16():
+                traffic = round(tj["gemm_family_bytes_per_launch"])
+                traffic_note = "HBM bytes per launch, rocprofv3 PMC (profiles/r02_hbm_traffic.md), same kernel sources"
+            else:
+                traffic_note = "profiles/r02_hbm_traffic.json was collected with other kernel sources (csrc sha %s != %s)" % (
+                    tj.get("csrc_sha16"), csrc_sha16())
+        roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (all %d launches per forward: 6 implicit-GEMM convs, "
+                    "projection, 9 x {qkv, out, ffn1, ffn2})" % n_launch,
                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch, rocprofv3 PMC (profiles/r01_hbm_traffic.md); algorithmic minimum "
-                                    "~160 MB per launch (8.3 GB of operands/outputs over 52 launches)",
-                    "avg_launch_ms": round(gemm_ms / n_launch, 4), "flops_per_forward": gemm_fl,
-                    "per_launch_tflops": {k: round(fl[k] / (kernels[k] * 1e-3) / 1e12, 1) for k in fl if kernels.get(k)}}
-        # the single dominant instantiation (40 % of the device time): the 8-wave 256x256 kernel with the GELU epilogue =
-        # conv1..conv5 + 9 x FFN1; its rocprofv3 row is "gemm8_bf16_kernel<4, 2, 2, 4, 0, 1>" (profiles/r01_kernel_stats_sequential.csv)
+                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                    "avg_launch_ms": round(gemm_ms / max(n_launch, 1), 4), "flops_per_forward": gemm_fl,
+                    "per_launch_tflops": {k: round(fl[k] / (ms_of[k] * 1e-3) / 1e12, 1) for k in fl if ms_of[k] > 0}}
+        enc_keys = ["gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2"]
+        enc_ms = sum(ms_of[k] for k in enc_keys)
+        if enc_ms > 0:
+            enc_tf = sum(fl[k] for k in enc_keys) / (enc_ms * 1e-3) / 1e12
+            roofline["encoder_gemms"] = {"achieved": round(enc_tf, 1), "frac": round(enc_tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                                         "ms_per_forward": round(enc_ms, 4)}
+        # the single dominant instantiation: the 8-wave 256x256 kernel with the GELU epilogue = conv1..conv5 + 9 x FFN1
         if clip_samples == CLIP_SAMPLES and B == BATCH_PER_GPU and args.precision == "bf16":
             big = ["gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_ffn1"]
             n_big = 5 + 9
@@ -290,21 +391,46 @@ def main():
                     "kernel": "gemm8_bf16_kernel<4, 2, 2, 4, 0, 1>", "launches_per_forward": n_big,
                     "avg_launch_ms": round(ms_big / n_big, 4), "achieved": round(fl_big / (ms_big * 1e-3) / 1e12, 1),
                     "frac": round(fl_big / (ms_big * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+        # the HBM-bound end of the path (north_star: "achieved HBM GB/s on the conv frontend"): conv0 + GroupNorm + GELU
+        # writes the channels-last bf16 activation once and reads the waveform once
+        if kernels.get("conv0_gn_gelu"):
+            rows0 = enc.padded_frames(clip_samples) * 64       # R_0 = Tp * 2^6 rows per utterance
+            fe_bytes = B * (rows0 * 512 * 2 + clip_samples * 4)
+            fe_gbs = fe_bytes / (kernels["conv0_gn_gelu"] * 1e-3) / 1e9
+            frontend = {"bound": "hbm", "kernel": "conv0_gn_gelu_kernel (Conv1d(1->512,k10,s5) + GroupNorm + GELU, bf16 channels-last out)",
+                        "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fe_gbs / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": fe_bytes}
 
-    # the HBM-bound end of the path (north_star: "achieved HBM GB/s on the conv frontend"): conv0 + GroupNorm + GELU
-    # writes the channels-last bf16 activation once and reads the waveform once
-    frontend = None
-    if rank == 0 and kernels.get("conv0_gn_gelu"):
-        rows0 = ((T_frames + 3) // 4 * 4) * 64                 # R_0 = Tp * 2^6 rows per utterance (Tp = frames rounded up to 4)
-        fe_bytes = B * (rows0 * 512 * 2 + clip_samples * 4)
-        fe_gbs = fe_bytes / (kernels["conv0_gn_gelu"] * 1e-3) / 1e9
-        frontend = {"bound": "hbm", "kernel": "conv0_gn_gelu_kernel (Conv1d(1->512,k10,s5) + GroupNorm + GELU, bf16 channels-last out)",
-                    "achieved": round(fe_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(fe_gbs / 8000.0, 4),
-                    "algorithmic_bytes_per_launch": fe_bytes}
+    # ---- API level, PCIe inclusive (never `value`): Segmenter.__call__ on host tensors -> numpy dicts
+    api = None
+    if rank == 0 and world == 1 and not args.no_api:
+        from sylber_amd import Segmenter
+        seg_api = Segmenter(model_ckpt=sd, device=str(dev), precision=args.precision)
+        host_wavs = [w[None, :].clone() for w in noise_batch(B, clip_samples, seed=1000)]
+        seg_api(wav=host_wavs, in_second=True)
+        torch.cuda.synchronize(dev)
+        n_api = 5
+        t_api = []
+        for _ in range(n_api):
+            t0 = time.perf_counter()
+            seg_api(wav=host_wavs, in_second=True)
+            t_api.append(time.perf_counter() - t0)
+        if os.environ.get("SYLBER_BENCH_DEBUG"):
+            sys.stderr.write("api call times (ms): %s\n" % [round(x * 1e3, 1) for x in t_api])
+        dt = statistics.median(t_api)
+        api = {"value": round(B * clip_seconds / dt, 1), "unit": "audio-sec/s", "ms_per_call": round(dt * 1e3, 2),
+               "what": "Segmenter.__call__(wav=[%d host tensors]) -> list of numpy dicts: one batched H2D, forward + "
+                       "segmentation, D2H of hidden states / segments / features, per-utterance slicing" % B}
+        del seg_api
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd)
+
+    agreement = None
+    if rank == 0 and world == 1 and args.agreement_clips > 0 and args.precision != "fp32":
+        from sylber_amd.agreement import segment_agreement
+        agreement = segment_agreement(sd, enc, args.agreement_clips, device=str(dev))
 
     seg_stats = None
     if rank == 0:
@@ -313,26 +439,41 @@ def main():
         nn_ = nseg_t.float()
         seg_stats = {"mean": round(float(nn_.mean()), 1), "min": int(nn_.min()), "max": int(nn_.max())}
     if rank == 0:
+        dtype = {"bf16": "bf16", "fp8": "bf16 + mxfp8 (e4m3, E8M0 block scales) weight GEMMs", "fp32": "f32"}[args.precision]
+        ex_txt = "root scatter + gather over RCCL in every step (run_stream: gather(i) overlapped with compute(i+1))"
+        res_txt = "shards resident per rank, no data-path collective"
         line = {
             "metric": "audio-sec/s encoded (sylber_base, 16 kHz, batched 10 s clips)",
             "value": round(value, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16 + mxfp8 (e4m3, E8M0 block scales) FFN GEMMs",
-            "data": "synthetic",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "ms_per_step_median": None if med_ms is None else round(med_ms, 3),
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "Segmenter forward (conv frontend + HuBERT-9L encoder + boundary detection + "
                                    "segment mean-pool), batch %d x %g s 16 kHz random waveforms per GPU, random-init "
                                    "sylber_base weights (BASELINE.json configs[1]%s)" % (B, clip_seconds, "; configs[2] sharding" if world > 1 else ""),
                        "global_batch": world * B, "clip_seconds": clip_seconds,
                        "ragged": ("lengths U[2 s, %g s], %.1f valid s of %g padded s per batch" % (clip_seconds, valid_seconds, B * clip_seconds))
                                  if args.ragged else None, "frames_per_clip": T_frames,
-                       "parallelism": "utterance-sharded x%d, %s" % (world, "root scatter + gather over RCCL in every step, gather(i) overlapped with compute(i+1)" if exchange
-                                                                      else "shards resident per rank, no data-path collective"),
-                       "pipelining": "none" if (exchange or args.no_overlap) else
-                                     "%d batches in flight on independent handles/streams; segmenter on a side stream" % NPIPE,
+                       "parallelism": "utterance-sharded x%d, %s" % (world, ex_txt if exchange_first else res_txt),
+                       "rccl_ranks": rccl_ranks,
+                       "pipelining": "%d batch(es) in flight on independent handles/streams%s" % (
+                           NPIPE, "" if (exchange_first or args.no_overlap) else "; segmenter on a side stream"),
                        "gflop_per_clip": 124.65 if clip_samples == CLIP_SAMPLES else None},
-            "roofline": roofline, "roofline_frontend": frontend, "cpu_baseline": cpu, "kernel_ms_per_forward": kernels,
+            "roofline": roofline, "roofline_frontend": frontend, "cpu_baseline": cpu, "api_level": api,
+            "kernel_ms_per_forward": kernels,
             "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2), "segments_per_clip": seg_stats,
         }
+        if secondary is not None:
+            name, s_el, s_med = secondary
+            line[name] = {"value": round(total_audio / s_el, 1), "unit": "audio-sec/s",
+                          "ms_per_step": round(1e3 * s_el / args.steps, 3),
+                          "ms_per_step_median": None if s_med is None else round(s_med, 3),
+                          "parallelism": res_txt if name == "resident_shards" else ex_txt}
+        if exchange_error is not None:
+            line["exchange_error"] = exchange_error
+        if agreement is not None:
+            line["segment_agreement"] = agreement
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -66,6 +66,9 @@ typedef struct {
 
 /* number of 50 Hz frames the 7-layer conv stack yields for n_samples (TP:664-677) */
 int32_t sylber_num_frames(int32_t n_samples);
+/* frame pitch per utterance of the library's internal activation buffers for a batch padded to n_samples (>= the
+ * frame count, a multiple of 32); informational: workspace sizing and roofline byte counts */
+int32_t sylber_padded_frames(int32_t n_samples);
 
 /* copies + packs the weights onto `device` (bf16 MFMA layouts, conv taps interleaved) */
 int sylber_create(const SylberWeights* w, int device, int precision, sylber_t* out);
@@ -81,6 +84,9 @@ const char* sylber_last_error(void);
  */
 int sylber_forward(sylber_t h, const float* wav_dev, const int32_t* lengths_host, int32_t B, int32_t Lmax,
                    float* hidden_dev, void* stream);
+/* lengths_host is read before the call returns (the frame counts travel to the device as kernel arguments: no
+ * pageable copy, no host synchronisation).  A handle is single-stream: it owns ONE workspace, so two forwards of the
+ * same handle must be ordered on the same stream; use one handle per in-flight batch to overlap batches. */
 
 /* (2)+(3) boundary detection + segment mean-pool, one workgroup per utterance, bit-exact w.r.t. the
  * reference's numpy float32 evaluation order.
@@ -141,6 +147,15 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
                      int32_t B, int32_t T, int32_t S, float norm_thr, float* avg_hidden_dev, float* cond_dev, float* workspace_dev,
                      void* stream);
 
+/* ---- per-handle options ------------------------------------------------------------------------ */
+/* Tuning / test overrides, scoped to ONE handle (nothing process-global); value < 0 or 0 restores the automatic choice.
+ *   SYLBER_OPT_GEMM_TILE               tile configuration id of the bf16 GEMM launches (csrc/gemm_bf16.hip launch_t:
+ *                                      0 = 256x128, 3 = 128x128, 4 = 128x192, 10 = 256x256 8-wave, 11 = 256x192 8-wave)
+ *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   32 or 64
+ *   SYLBER_OPT_GEMM_PERSISTENT         k > 0: GEMM launches of k x 256 persistent workgroups walking the tile list */
+enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3 };
+int sylber_set_option(sylber_t h, int32_t key, int32_t value);
+
 /* ---- introspection used by parity tests and the benchmark ------------------------------------ */
 /* run sylber_forward only up to a stage: 0 = all, 1 = conv stack, 2 = +projection/pos-conv/LN,
  * 3 + l = through encoder layer l.  The stage output is written to hidden_dev in place of the final
@@ -158,9 +173,12 @@ int sylber_set_graph_mode(sylber_t h, int32_t enable);
 int64_t sylber_workspace_bytes(sylber_t h);
 
 /* ---- single-op entry points (unit parity tests; same kernels the forward path launches) ------ */
-/* C[M,N] (fp32) = A[M,K] (fp32, cast to bf16) x W[N,K]^T (fp32, cast to bf16) + bias[N] (nullable); act: 0 none, 1 gelu */
+/* C[M,N] (fp32) = A[M,K] (fp32, cast to bf16) x W[N,K]^T (fp32, cast to bf16) + bias[N] (nullable); act: 0 none,
+ * 1 gelu (the bf16 path's polynomial), 2 gelu (erf); precision: SYLBER_BF16 or SYLBER_FP8 (K % 128 == 0);
+ * tile: -1 = automatic, else the tile configuration id to run (parity tests sweep every configuration), + 1000 k for a
+ * persistent launch of k x 256 workgroups */
 int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, float* c_dev, int32_t M,
-                     int32_t N, int32_t K, int32_t act, int32_t precision, void* stream);   /* precision: SYLBER_BF16 or SYLBER_FP8 (K % 128 == 0) */
+                     int32_t N, int32_t K, int32_t act, int32_t precision, int32_t tile, void* stream);
 /* MXFP8 quantiser used by SYLBER_FP8: x [R,K] fp32 -> data [R,K] e4m3 + E8M0 scales, one per 32 elements along K,
  * stored K-pair-major [K/64, R, 2] (K % 64 == 0; the layout the GEMM's scale fetch wants); the block scale is the
  * smallest power of two 2^e with amax <= 448 * 2^e, elements are x / 2^e rounded to nearest even */
@@ -168,16 +186,10 @@ int sylber_op_mx_quantize(const float* x_dev, int32_t R, int32_t K, uint8_t* dat
 /* y = LayerNorm(x [+ res]) over the last dim D (512 or 768), eps 1e-5 */
 int sylber_op_layernorm(const float* x_dev, const float* res_dev, const float* g_dev, const float* b_dev,
                         float* y_dev, int32_t M, int32_t D, void* stream);
-/* softmax(q k^T / 8 + key mask) v ; q,k,v,o: [B,T,768] fp32 (12 heads x 64); valid_dev [B] int32 */
+/* softmax(q k^T / 8 + key mask) v ; q,k,v,o: [B,T,768] fp32 (12 heads x 64); valid_dev [B] int32;
+ * queries_per_wave: 0 = automatic, 32 or 64 */
 int sylber_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const int32_t* valid_dev,
-                        float* o_dev, int32_t B, int32_t T, int32_t precision, void* stream);
-
-/* development aid: average ms of one launch of the bf16 GEMM kernel (M x N x K, activation row stride
- * ldx) on pseudo-random operands; epi/act as in csrc/kernels.h, cfg -1 = automatic tile shape */
-/* development aid: force a GEMM tile configuration for every following launch (-1 = automatic) */
-void sylber_debug_force_gemm_cfg(int32_t cfg);
-int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
-                            int32_t iters, float* ms_out);
+                        float* o_dev, int32_t B, int32_t T, int32_t precision, int32_t queries_per_wave, void* stream);
 
 #ifdef __cplusplus
 }

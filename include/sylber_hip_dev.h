@@ -1,0 +1,20 @@
+/*
+ * sylber_hip_dev.h -- development aids exported by libsylber_hip.so that are NOT part of the drop-in C-ABI
+ * (include/sylber_hip.h): micro-benchmarks used by tools/.  Nothing on the product path or in the parity tests
+ * needs them, and they keep no process-global state.
+ */
+#ifndef SYLBER_HIP_DEV_H
+#define SYLBER_HIP_DEV_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* average ms of one launch of the bf16 GEMM kernel (M x N x K, activation row stride ldx) on pseudo-random
+ * operands; epi / act as in csrc/kernels.h; cfg: -1 = automatic tile shape, else persist * 1000 + tile id;
+ * cfg in [100, 200): the MXFP8 GEMM with tile configuration cfg - 100 */
+int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
+                            int32_t iters, float* ms_out);
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYLBER_HIP_DEV_H */

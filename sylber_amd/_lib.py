@@ -38,6 +38,8 @@ class SylberWeights(ctypes.Structure):
 
 EXPORTS = {
     "sylber_num_frames": (c_int32, [c_int32]),
+    "sylber_padded_frames": (c_int32, [c_int32]),
+    "sylber_set_option": (c_int, [c_void_p, c_int32, c_int32]),
     "sylber_create": (c_int, [POINTER(SylberWeights), c_int, c_int, POINTER(c_void_p)]),
     "sylber_destroy": (None, [c_void_p]),
     "sylber_last_error": (c_char_p, []),
@@ -50,11 +52,9 @@ EXPORTS = {
     "sylber_get_profile": (c_int, [c_void_p, POINTER(c_char_p), POINTER(c_float), c_int32]),
     "sylber_workspace_bytes": (c_int64, [c_void_p]),
     "sylber_op_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                 c_void_p]),
+                                 c_int32, c_void_p]),
     "sylber_op_mx_quantize": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "sylber_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
-    "sylber_debug_force_gemm_cfg": (None, [c_int32]),
-    "sylber_debug_gemm_bench": (c_int, [c_int32] * 8 + [POINTER(c_float)]),
     "sylber_ingest_num_frames": (c_int64, [c_int64, c_int32]),
     "sylber_ingest_workspace_bytes": (c_int64, [c_int32]),
     "sylber_ingest": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
@@ -67,8 +67,13 @@ EXPORTS = {
     "sylber_condition": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
     "sylber_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
-                                    c_void_p]),
+                                    c_int32, c_void_p]),
 }
+# include/sylber_hip_dev.h: development aids (tools/ only)
+DEV_EXPORTS = {
+    "sylber_debug_gemm_bench": (c_int, [c_int32] * 8 + [POINTER(c_float)]),
+}
+OPT_GEMM_TILE, OPT_ATTN_QUERIES_PER_WAVE, OPT_GEMM_PERSISTENT = 1, 2, 3
 
 _LIB = None
 
@@ -85,7 +90,7 @@ def load() -> ctypes.CDLL:
                 "libsylber_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `python sylber_amd/build.py`; there is no CPU fallback on the product path." % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in EXPORTS.items():
+        for name, (res, args) in list(EXPORTS.items()) + list(DEV_EXPORTS.items()):
             fn = getattr(lib, name)      # AttributeError if the ABI drifted from include/sylber_hip.h
             fn.restype = res
             fn.argtypes = args

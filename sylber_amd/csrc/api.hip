@@ -10,11 +10,26 @@
 #include <vector>
 
 #include "../../include/sylber_hip.h"
+#include "../../include/sylber_hip_dev.h"
 #include "kernels.h"
 
 static thread_local char g_err[512] = "";
 void syl_set_error(const char* what, const char* detail) { snprintf(g_err, sizeof(g_err), "%s: %s", what, detail); }
 extern "C" const char* sylber_last_error(void) { return g_err; }
+
+// every entry point runs on the handle's GPU and leaves the caller's current device as it found it (a process may
+// hold handles on several GPUs; sylber_destroy runs from garbage collectors at arbitrary times)
+struct DeviceGuard {
+    int prev = -1; bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { int cur = -1; if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev); }
+};
+#define GUARD_DEVICE(dev)                                                                             \
+    DeviceGuard _dg(dev);                                                                             \
+    if (!_dg.ok) { syl_set_error("hipSetDevice", "cannot select the handle's device"); return 1; }
 
 static const int CK[7] = {10, 3, 3, 3, 3, 2, 2};
 static const int CS[7] = {5, 2, 2, 2, 2, 2, 2};
@@ -23,6 +38,21 @@ extern "C" int32_t sylber_num_frames(int32_t n) {
     for (int i = 0; i < 7; ++i) n = (n - CK[i]) / CS[i] + 1;
     return n;
 }
+
+// frame pitch per utterance of the internal activation buffers: enough rows for every conv layer's valid outputs at
+// its 2^(6-i) rows-per-frame pitch, rounded up to 32 (a 32-row MFMA block then never straddles two utterances, and
+// 32 x 10 s = 16384 rows is a whole number of 256-row tiles)
+static int padded_frames(int Lmax) {
+    int n = Lmax, tp = 0;
+    for (int i = 0; i < 7; ++i) {
+        n = (n - CK[i]) / CS[i] + 1;
+        const int f = 1 << (6 - i);
+        const int need = (n + f - 1) / f;
+        tp = need > tp ? need : tp;
+    }
+    return (tp + 31) & ~31;
+}
+extern "C" int32_t sylber_padded_frames(int32_t n_samples) { return n_samples < 400 ? 0 : padded_frames(n_samples); }
 
 struct LayerDev {
     bf16_t *wqkv, *wo, *w1, *w2;
@@ -52,6 +82,7 @@ struct sylber_ctx {
     int ws_B = 0, ws_Lmax = 0;
     float* seg_scratch = nullptr; size_t seg_scratch_floats = 0;
     int stop_stage = 0;
+    int opt_gemm_cfg = 0, opt_attn_qw = 0, opt_gemm_persist = 0;   // sylber_set_option (0 = automatic)
     bool graph_mode = false;
     std::vector<GraphEntry> graphs; unsigned long long graph_clock = 0;
     // profiling
@@ -79,7 +110,7 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
     if (w->num_layers < 1 || w->num_layers > SYLBER_MAX_LAYERS) { syl_set_error("sylber_create", "num_layers out of range"); return 1; }
     if (precision != SYLBER_BF16 && precision != SYLBER_FP32 && precision != SYLBER_FP8) { syl_set_error("sylber_create", "unknown precision"); return 1; }
     const bool f32 = precision == SYLBER_FP32;
-    HIP_TRY(hipSetDevice(device));
+    GUARD_DEVICE(device);
     sylber_ctx* c = new sylber_ctx();
     c->device = device; c->precision = precision; c->num_layers = w->num_layers;
     Packer P;
@@ -206,7 +237,7 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
 
 extern "C" void sylber_destroy(sylber_t c) {
     if (!c) return;
-    hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     if (c->wbase) hipFree(c->wbase);
     if (c->f8base) hipFree(c->f8base);
     if (c->ws) hipFree(c->ws);
@@ -217,6 +248,17 @@ extern "C" void sylber_destroy(sylber_t c) {
 }
 
 extern "C" int sylber_set_stop_stage(sylber_t c, int32_t stage) { if (!c) return 1; c->stop_stage = stage; return 0; }
+extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
+    if (!c) { syl_set_error("sylber_set_option", "null handle"); return 1; }
+    switch (key) {
+        case SYLBER_OPT_GEMM_TILE: c->opt_gemm_cfg = value < 0 ? 0 : value + 1; break;     // stored as id + 1, 0 = automatic
+        case SYLBER_OPT_ATTN_QUERIES_PER_WAVE: c->opt_attn_qw = value == 32 ? 1 : (value == 64 ? 2 : 0); break;
+        case SYLBER_OPT_GEMM_PERSISTENT: c->opt_gemm_persist = value > 0 ? value : 0; break;
+        default: syl_set_error("sylber_set_option", "unknown option key"); return 1;
+    }
+    if (c->graph_mode) { for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec); c->graphs.clear(); }   // captured launches are stale
+    return 0;
+}
 // enabling (or re-enabling) profiling resets the accumulated per-kernel times
 extern "C" int sylber_set_profiling(sylber_t c, int32_t enable) {
     if (!c) return 1;
@@ -234,6 +276,7 @@ struct Plan {
     size_t o_bufA, o_bufB, o_ln512, o_xf32, o_xpad, o_pre, o_stats, o_hbf16, o_q, o_k, o_vt, o_ctx, o_ffn, o_part, o_ss, o_valid,
         total;
     int nchunk;
+    bool zero_all = false;        // fp32 parity plan: its own offsets, zero everything on a layout change
 };
 
 static void make_plan(int B, int Lmax, Plan& p) {
@@ -241,9 +284,7 @@ static void make_plan(int B, int Lmax, Plan& p) {
     int n = Lmax;
     for (int i = 0; i < 7; ++i) { n = (n - CK[i]) / CS[i] + 1; p.L[i] = n; }
     p.T = p.L[6];
-    int tp = 0;
-    for (int i = 0; i < 7; ++i) { const int f = 1 << (6 - i); const int need = (p.L[i] + f - 1) / f; tp = need > tp ? need : tp; }
-    p.Tp = (tp + 3) & ~3;
+    p.Tp = padded_frames(Lmax);
     p.Tpv = (p.Tp + 63) & ~63;
     for (int i = 0; i < 7; ++i) p.R[i] = p.Tp << (6 - i);
     size_t off = 0;
@@ -279,10 +320,45 @@ static int ensure_workspace(sylber_ctx* c, const Plan& p, hipStream_t s) {
         c->ws_B = 0;
     }
     if (c->ws_B != p.B || c->ws_Lmax != p.Lmax) {
-        // layout changed: padded regions (pos-conv halo, V^T tail, slack rows) must read as zeros
-        HIP_TRY(hipMemsetAsync(c->ws, 0, p.total, s));
+        // layout changed: the regions that are read but never (fully) written must read as zeros -- the pos-conv
+        // input's halo rows, the V^T key tail [Tp, Tpv) and the slack rows behind the GEMM operands (which only ever
+        // feed rows beyond M, but must stay finite).  Everything else is written before it is read, so a ragged
+        // serving loop (new Lmax per call) pays ~60 MB of memset instead of the whole 2 GB workspace.
+        const size_t M = (size_t)p.B * p.Tp;
+        if (p.zero_all) HIP_TRY(hipMemsetAsync(c->ws, 0, p.total, s));
+        else {
+            HIP_TRY(hipMemsetAsync(c->ws + p.o_xpad, 0, (size_t)p.B * (p.Tp + 128) * 768 * 2, s));
+            HIP_TRY(hipMemsetAsync(c->ws + p.o_vt, 0, (size_t)p.B * 12 * 64 * p.Tpv * 2, s));
+            HIP_TRY(hipMemsetAsync(c->ws + p.o_bufA + (size_t)p.B * p.R[0] * 512 * 2, 0, 8 * 512 * 2, s));
+            HIP_TRY(hipMemsetAsync(c->ws + p.o_bufB + (size_t)p.B * p.R[1] * 512 * 2, 0, 8 * 512 * 2, s));
+            HIP_TRY(hipMemsetAsync(c->ws + p.o_hbf16 + M * 768 * 2, 0, 128 * 768 * 2, s));
+            HIP_TRY(hipMemsetAsync(c->ws + p.o_ctx + M * 768 * 2, 0, 128 * 768 * 2, s));
+            HIP_TRY(hipMemsetAsync(c->ws + p.o_ffn + M * 3072 * 2, 0, (size_t)128 * 3072 * 2, s));
+        }
         c->ws_B = p.B; c->ws_Lmax = p.Lmax;
     }
+    return 0;
+}
+
+// valid frames per utterance -> device, without a host staging buffer: the values travel as kernel arguments (64 per
+// launch), so there is no pageable hipMemcpyAsync (an implicit host synchronisation) and nothing whose lifetime
+// the caller has to think about
+struct ValidPack { int v[64]; };
+__global__ void set_valid_kernel(int* __restrict__ dst, ValidPack p, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
+}
+static int upload_valid(int* valid_dev, const int32_t* lengths_host, int B, int Lmax, hipStream_t s) {
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        ValidPack pk;
+        const int n = B - b0 < 64 ? B - b0 : 64;
+        for (int i = 0; i < n; ++i) {
+            const int len = lengths_host ? lengths_host[b0 + i] : Lmax;
+            if (len > Lmax || len < 400) { syl_set_error("sylber_forward", "lengths must be in [400, Lmax]"); return 1; }
+            pk.v[i] = sylber_num_frames(len);
+        }
+        hipLaunchKernelGGL(set_valid_kernel, dim3(1), dim3(64), 0, s, valid_dev + b0, pk, n);
+    }
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -353,8 +429,8 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     for (int i = 1; i < 7; ++i) {
         GemmArgs a = {};
         a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w[i];
-        a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = 1;
-        a.out0 = dst; a.ld0 = 512;
+        a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = ACT_GELU_FAST;
+        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist;
         static const char* nm[7] = {"", "gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_conv6"};
         RUN(nm[i], launch_gemm_bf16(EPI_BF16, a, s));
         bf16_t* t = src; src = dst; dst = t;
@@ -401,34 +477,33 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     for (int l = 0; l < c->num_layers; ++l) {
         const LayerDev& d = c->L[l];
         const bool last = (l == c->num_layers - 1) || (c->stop_stage == 3 + l);
+        // one launch for q, k and v (N = 2304): the q / k thirds leave head-major, the v third transposed (EPI_QK)
         if (f8) {
             GemmF8Args g = {};
-            g.g.M = M; g.g.N = 1536; g.g.K = 768; g.g.bias = d.bqkv; g.g.out0 = q; g.g.out1 = k; g.g.out2 = vt;
+            g.g.M = M; g.g.N = 2304; g.g.K = 768; g.g.bias = d.bqkv; g.g.out0 = q; g.g.out1 = k; g.g.out2 = vt;
             g.g.Tp = p.Tp; g.g.Tpv = p.Tpv; g.g.T = p.T;
             g.X8 = h8; g.ldx8 = 768; g.XS = h8s; g.xs_rows = Mp; g.W8 = d.wqkvq; g.WS = d.wqkvs; g.ws_rows = 2304;
-            RUN("gemm_qk", launch_gemm_mxfp8(EPI_QK, g, s));
-            g.W8 = d.wqkvq + (size_t)1536 * 768; g.WS = d.wqkvs + (size_t)1536 * 2; g.g.bias = d.bqkv + 1536; g.g.N = 768;
-            RUN("gemm_v", launch_gemm_mxfp8(EPI_V, g, s));
+            RUN("gemm_qkv", launch_gemm_mxfp8(EPI_QK, g, s));
         } else {
-        GemmArgs g = {};
-        g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 1536; g.K = 768; g.bias = d.bqkv;
-        g.out0 = q; g.out1 = k; g.out2 = vt; g.Tp = p.Tp; g.Tpv = p.Tpv; g.T = p.T;
-        RUN("gemm_qk", launch_gemm_bf16(EPI_QK, g, s));
-        g.W = d.wqkv + (size_t)1536 * 768; g.bias = d.bqkv + 1536; g.N = 768;
-        RUN("gemm_v", launch_gemm_bf16(EPI_V, g, s));
+            GemmArgs g = {};
+            g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 2304; g.K = 768; g.bias = d.bqkv;
+            g.out0 = q; g.out1 = k; g.out2 = vt; g.Tp = p.Tp; g.Tpv = p.Tpv; g.T = p.T;
+            g.tune_cfg = c->opt_gemm_cfg; g.tune_persist = c->opt_gemm_persist;
+            RUN("gemm_qkv", launch_gemm_bf16(EPI_QK, g, s));
         }
         if (f8) {
-            RUN("attention", launch_attention_f8out(q, k, vt, valid, ctx8, ctx8s, Mp, B, p.T, p.Tp, p.Tpv, s));
+            RUN("attention", launch_attention_f8out(q, k, vt, valid, ctx8, ctx8s, Mp, B, p.T, p.Tp, p.Tpv, c->opt_attn_qw, s));
             GemmF8Args o = {};
             o.g.M = M; o.g.N = 768; o.g.K = 768; o.g.bias = d.bo; o.g.out0 = pre; o.g.ld0 = 768; o.g.res = pre; o.g.ldres = 768;
             o.g.ln_stats = stats; o.g.ln_gamma = res_g; o.g.ln_beta = res_b;
             o.X8 = ctx8; o.ldx8 = 768; o.XS = ctx8s; o.xs_rows = Mp; o.W8 = d.woq; o.WS = d.wos; o.ws_rows = 768;
             RUN("gemm_out", launch_gemm_mxfp8(EPI_F32_RESLN, o, s));
         } else {
-        RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, s));
+        RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, c->opt_attn_qw, s));
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
         o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
+        o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist;
         RUN("gemm_out", launch_gemm_bf16(EPI_F32_RESLN, o, s));
         }
         RUN("layernorm", run_ln(d.ln1w, d.ln1b, false, f8));
@@ -445,11 +520,12 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         } else {
         GemmArgs f1 = {};
         f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = 1;
-        f1.out0 = ffn; f1.ld0 = 3072;
+        f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist;
         RUN("gemm_ffn1", launch_gemm_bf16(EPI_BF16, f1, s));
         GemmArgs f2 = {};
         f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
         f2.out0 = pre; f2.ld0 = 768; f2.res = pre; f2.ldres = 768; f2.ln_stats = stats; f2.ln_gamma = d.ln1w; f2.ln_beta = d.ln1b;
+        f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist;
         RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RESLN, f2, s));
         }
         RUN("layernorm", run_ln(d.ln2w, d.ln2b, last, f8));
@@ -478,10 +554,10 @@ extern "C" int sylber_set_graph_mode(sylber_t c, int32_t enable) {
 extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* lengths_host, int32_t B, int32_t Lmax,
                               float* hidden_dev, void* stream) {
     if (!c || !wav_dev || !hidden_dev) { syl_set_error("sylber_forward", "null argument"); return 1; }
-    if (c->precision == SYLBER_FP32) return forward_f32(c, wav_dev, lengths_host, B, Lmax, hidden_dev, (hipStream_t)stream);
+    if (c->precision == SYLBER_FP32) { GUARD_DEVICE(c->device); return forward_f32(c, wav_dev, lengths_host, B, Lmax, hidden_dev, (hipStream_t)stream); }
     if (B < 1 || Lmax < 400) { syl_set_error("sylber_forward", "need B >= 1 and at least 400 samples (one frame)"); return 1; }
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipSetDevice(c->device));
+    GUARD_DEVICE(c->device);
     Plan p;
     make_plan(B, Lmax, p);
     char* ws_before = c->ws;
@@ -489,15 +565,7 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
     if (c->ws != ws_before) graphs_clear(c);           // captured graphs hold workspace addresses
     int* valid = (int*)(c->ws + p.o_valid);
     // valid frames per utterance (TP:664-689): conv-length formula of the number of valid samples
-    {
-        std::vector<int> v(B);
-        for (int i = 0; i < B; ++i) {
-            int n = lengths_host ? lengths_host[i] : Lmax;
-            if (n > Lmax || n < 400) { syl_set_error("sylber_forward", "lengths must be in [400, Lmax]"); return 1; }
-            v[i] = sylber_num_frames(n);
-        }
-        HIP_TRY(hipMemcpyAsync(valid, v.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
-    }
+    if (upload_valid(valid, lengths_host, B, Lmax, s)) return 1;
     if (!c->graph_mode || c->profiling || s == nullptr) return forward_launch(c, p, wav_dev, hidden_dev, s);
     GraphEntry* e = nullptr;
     for (auto& g : c->graphs)
@@ -536,7 +604,6 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
 static int forward_f32(sylber_ctx* c, const float* wav_dev, const int32_t* lengths_host, int B, int Lmax, float* hidden_dev,
                        hipStream_t s) {
     if (B < 1 || Lmax < 400) { syl_set_error("sylber_forward", "need B >= 1 and at least 400 samples (one frame)"); return 1; }
-    HIP_TRY(hipSetDevice(c->device));
     Plan p;
     make_plan(B, Lmax, p);
     const size_t M = (size_t)B * p.Tp;
@@ -547,22 +614,14 @@ static int forward_f32(sylber_ctx* c, const float* wav_dev, const int32_t* lengt
     const size_t o_pre = take(M * 768 * 4), o_h = take(M * 768 * 4), o_qkv = take(M * 2304 * 4), o_ctx = take(M * 768 * 4);
     const size_t o_ffn = take(M * 3072 * 4), o_part = take((size_t)B * p.nchunk * 65 * 8), o_ss = take((size_t)B * 512 * 2 * 4);
     const size_t o_valid = take((size_t)B * 4);
-    Plan q = p; q.total = off;
+    Plan q = p; q.total = off; q.zero_all = true;
     if (ensure_workspace(c, q, s)) return 1;
     char* w = c->ws;
     float* bufA = (float*)(w + o_a); float* bufB = (float*)(w + o_b); float* ln512 = (float*)(w + o_ln);
     float* xf = (float*)(w + o_x); float* xpad = (float*)(w + o_xpad); float* pre = (float*)(w + o_pre); float* h = (float*)(w + o_h);
     float* qkv = (float*)(w + o_qkv); float* ctx = (float*)(w + o_ctx); float* ffn = (float*)(w + o_ffn);
     double* part = (double*)(w + o_part); float* ss = (float*)(w + o_ss); int* valid = (int*)(w + o_valid);
-    {
-        std::vector<int> v(B);
-        for (int i = 0; i < B; ++i) {
-            int n = lengths_host ? lengths_host[i] : Lmax;
-            if (n > Lmax || n < 400) { syl_set_error("sylber_forward", "lengths must be in [400, Lmax]"); return 1; }
-            v[i] = sylber_num_frames(n);
-        }
-        HIP_TRY(hipMemcpyAsync(valid, v.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
-    }
+    if (upload_valid(valid, lengths_host, B, Lmax, s)) return 1;
     RUN("conv0_stats", launch_conv0_stats(wav_dev, B, Lmax, p.L[0], part, p.nchunk, s));
     RUN("conv0_finalize", launch_conv0_finalize(part, p.nchunk, c->conv0_w, c->gn_w, c->gn_b, B, p.L[0], ss, s));
     RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 1, s));
@@ -631,7 +690,7 @@ extern "C" int sylber_segment(sylber_t c, const float* hidden_dev, int32_t B, in
                               float merge_thr, int64_t* seg_dev, int32_t* nseg_dev, float* feat_dev, void* stream) {
     if (!c || !hidden_dev || !seg_dev || !nseg_dev) { syl_set_error("sylber_segment", "null argument"); return 1; }
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipSetDevice(c->device));
+    GUARD_DEVICE(c->device);
     ProfScope ps(c, s, "segment");
     return launch_segment(hidden_dev, B, T, D, norm_thr, merge_thr, seg_dev, nseg_dev, feat_dev, c->seg_scratch, s);
 }
@@ -645,7 +704,7 @@ struct TmpBuf {
 };
 
 extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, float* c_dev, int32_t M,
-                                int32_t N, int32_t K, int32_t act, int32_t precision, void* stream) {
+                                int32_t N, int32_t K, int32_t act, int32_t precision, int32_t tile, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (precision == SYLBER_FP8) {
         // both operands quantised to MXFP8 on the device, contraction on the block-scaled fp8 MFMA
@@ -660,6 +719,7 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
         if (launch_mx_quant_rows(w_dev, K, (uint8_t*)w8.p, K, (uint8_t*)wsc.p, Np, N, K, s)) return 1;
         GemmF8Args g = {};
         g.g.M = M; g.g.N = N; g.g.K = K; g.g.bias = bias_dev; g.g.act = act; g.g.out0 = c_dev; g.g.ld0 = N;
+        g.g.tune_cfg = tile < 0 ? 0 : tile + 1;
         g.X8 = (uint8_t*)a8.p; g.ldx8 = K; g.XS = (uint8_t*)as.p; g.xs_rows = Mp; g.W8 = (uint8_t*)w8.p; g.WS = (uint8_t*)wsc.p; g.ws_rows = Np;
         if (launch_gemm_mxfp8(EPI_F32, g, s)) return 1;
         HIP_TRY(hipStreamSynchronize(s));
@@ -672,7 +732,7 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
     if (launch_f32_to_bf16(w_dev, (bf16_t*)wb.p, (size_t)N * K, s)) return 1;
     GemmArgs g = {};
     g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev; g.act = act;
-    g.out0 = c_dev; g.ld0 = N;
+    g.out0 = c_dev; g.ld0 = N; g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 1000 ? tile / 1000 : 0;
     if (launch_gemm_bf16(EPI_F32, g, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -707,17 +767,18 @@ __global__ void pack_qkv_kernel(const float* __restrict__ q, const float* __rest
 }
 
 extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const int32_t* valid_dev,
-                                   float* o_dev, int32_t B, int32_t T, int32_t precision, void* stream) {
+                                   float* o_dev, int32_t B, int32_t T, int32_t precision, int32_t queries_per_wave, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (precision != SYLBER_BF16) { syl_set_error("sylber_op_attention", "only bf16"); return 1; }
-    const int Tp = (T + 3) & ~3, Tpv = (Tp + 63) & ~63;
+    const int Tp = (T + 31) & ~31, Tpv = (Tp + 63) & ~63;
+    const int qw = queries_per_wave == 32 ? 1 : (queries_per_wave == 64 ? 2 : 0);
     TmpBuf qb, kb, vb, cb;
     const size_t n = (size_t)B * Tp * 768;
     if (qb.alloc(n * 2) || kb.alloc(n * 2) || vb.alloc((size_t)B * 768 * Tpv * 2) || cb.alloc(n * 2)) { syl_set_error("sylber_op_attention", "alloc"); return 1; }
     HIP_TRY(hipMemsetAsync(qb.p, 0, n * 2, s)); HIP_TRY(hipMemsetAsync(kb.p, 0, n * 2, s));
     HIP_TRY(hipMemsetAsync(vb.p, 0, (size_t)B * 768 * Tpv * 2, s)); HIP_TRY(hipMemsetAsync(cb.p, 0, n * 2, s));
     hipLaunchKernelGGL(pack_qkv_kernel, dim3(T, B), dim3(256), 0, s, q_dev, k_dev, v_dev, (bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, T, Tp, Tpv);
-    if (launch_attention((bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, valid_dev, (bf16_t*)cb.p, B, T, Tp, Tpv, s)) return 1;
+    if (launch_attention((bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, valid_dev, (bf16_t*)cb.p, B, T, Tp, Tpv, qw, s)) return 1;
     if (launch_bf16_to_f32_rows((bf16_t*)cb.p, 768, o_dev, B, Tp, T, 768, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -725,14 +786,6 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
 
 
 // ------------------------------------------------------------------------------------------------
-extern "C" void sylber_debug_force_gemm_cfg(int32_t cfg) {
-    // cfg >= 0: GEMM tile configuration; -1: automatic; -101 / -102: attention with 32 / 64 queries per wave; -100: automatic
-    if (cfg <= -300) gemm_mxfp8_force_cfg(-cfg - 301);         // -300: MXFP8 GEMM tile automatic; -301 - k: force tile config k (0..3)
-    else if (cfg <= -200) gemm_set_wg_per_cu(-cfg - 200);     // -200: one workgroup per tile; -201 / -202: persistent, 1 / 2 per CU
-    else if (cfg <= -100) attention_force_qw(-cfg - 100);
-    else gemm_force_cfg(cfg);
-}
-
 // GEMM micro-benchmark (development aid): times `iters` launches of the bf16 GEMM on pseudo-random
 // operands with HIP events.  cfg: -1 auto, 0 = 256x128, 1 = 128x192, 2 = 128x128 tiles.
 __global__ void fill_random_bf16(bf16_t* p, size_t n, unsigned seed) {
@@ -772,7 +825,7 @@ static int gemm_bench_f8(int M, int N, int K, int epi, int act, int cfg, int ite
     g.X8 = (uint8_t*)xb.p; g.ldx8 = K; g.XS = (uint8_t*)xs.p; g.xs_rows = Mp; g.W8 = (uint8_t*)wb.p; g.WS = (uint8_t*)wsb.p; g.ws_rows = Np;
     g.out_scale = (uint8_t*)os.p; g.os_rows = Mp;
     const int e = epi == 0 ? EPI_MXFP8 : (epi == 6 ? EPI_F32_RESLN : EPI_F32);
-    gemm_mxfp8_force_cfg(cfg);
+    g.g.tune_cfg = cfg < 0 ? 0 : cfg + 1;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     int rc = 0;
@@ -781,7 +834,6 @@ static int gemm_bench_f8(int M, int N, int K, int epi, int act, int cfg, int ite
     for (int i = 0; i < iters && !rc; ++i) rc = launch_gemm_mxfp8(e, g, 0);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
-    gemm_mxfp8_force_cfg(-1);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / iters;
@@ -803,41 +855,31 @@ extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t 
     GemmArgs g = {};
     g.X = (bf16_t*)xb.p; g.ldx = ldx; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = (float*)bb.p; g.act = act;
     g.out0 = ob.p; g.ld0 = N; g.res = (float*)rb.p; g.ldres = N;
-    g.xpad_rows = cfg >= 1000 ? (cfg / 1000) : 0;     // ablation flags ride on cfg = flags*1000 + cfg
-    cfg = cfg % 1000;
-    TmpBuf dbg;
-    const size_t ndbg = (size_t)((M + 127) / 128) * ((N + 127) / 128) * 4 * 8 + 64;
-    if (g.xpad_rows & 16) {
-        if (dbg.alloc(ndbg * 8)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }
-        HIP_TRY(hipMemset(dbg.p, 0, ndbg * 8));
-        g.out1 = dbg.p;
+    TmpBuf lnb;
+    if (epi == EPI_F32_RESLN) {
+        if (lnb.alloc((size_t)M * 8 + (size_t)N * 8)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }
+        HIP_TRY(hipMemset(lnb.p, 0, (size_t)M * 8 + (size_t)N * 8));
+        g.ln_stats = (float*)lnb.p; g.ln_gamma = (float*)lnb.p + (size_t)M * 2; g.ln_beta = g.ln_gamma + N;
     }
+    g.Tp = 512; g.Tpv = 512; g.T = 499;               // EPI_QK: rows = (utterance, frame) at this pitch
+    TmpBuf qkb;
+    if (epi == EPI_QK) {
+        if (qkb.alloc((size_t)(M + 512) * 768 * 2 * 3)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }
+        g.out0 = qkb.p; g.out1 = (char*)qkb.p + (size_t)(M + 512) * 768 * 2; g.out2 = (char*)qkb.p + (size_t)(M + 512) * 768 * 4;
+    }
+    g.tune_cfg = cfg < 0 ? 0 : (cfg % 1000) + 1;
+    g.tune_persist = cfg >= 1000 ? cfg / 1000 : 0;    // cfg = persist * 1000 + tile
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    gemm_force_cfg(cfg);
     int rc = 0;
     for (int i = 0; i < 3 && !rc; ++i) rc = launch_gemm_bf16(epi, g, 0);
     hipEventRecord(e0, 0);
     for (int i = 0; i < iters && !rc; ++i) rc = launch_gemm_bf16(epi, g, 0);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
-    gemm_force_cfg(-1);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
-    if (g.xpad_rows & 16) {
-        std::vector<unsigned long long> h(ndbg);
-        hipMemcpy(h.data(), dbg.p, ndbg * 8, hipMemcpyDeviceToHost);
-        double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        size_t nw = 0;
-        for (size_t w = 0; w + 8 <= ndbg; w += 8) { if (!h[w]) continue; for (int i = 0; i < 8; ++i) tot[i] += (double)h[w + i]; ++nw; }
-        const double steps = (double)(K / (cfg >= 10 ? 32 : 64)) * (nw ? nw : 1);
-        printf("timing (ticks per step, mean over %zu waves; cfg<10: kk0..2 | waits | barrier | frag0+DMA | last mfma; cfg>=10: "
-               "reads+DMA issue | waits | barrier | mfma | barrier): %.0f | %.0f | %.0f | %.0f | %.0f\n", nw, tot[0] / steps, tot[1] / steps, tot[2] / steps, tot[3] / steps, tot[4] / steps);
-        printf("   per workgroup: prologue %.0f | K loop %.0f | epilogue %.0f cycles\n", tot[5] / (nw ? nw : 1),
-               (tot[0] + tot[1] + tot[2] + tot[3] + tot[4]) / (nw ? nw : 1), tot[6] / (nw ? nw : 1));
-        fflush(stdout);
-    }
     return rc;
 }

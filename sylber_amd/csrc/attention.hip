@@ -242,15 +242,12 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
     }
 }
 
-static int g_attn_qw = 0;
-void attention_force_qw(int qw) { g_attn_qw = qw; }
-
 static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, void* ctx, uint8_t* ctx_scale,
-                                long scale_rows, int B, int T, int Tp, int Tpv, hipStream_t s) {
+                                long scale_rows, int B, int T, int Tp, int Tpv, int force_qw, hipStream_t s) {
     if (Tpv % 64 != 0 || Tpv < T) { syl_set_error("launch_attention", "Tpv must be a multiple of 64 and >= T"); return 1; }
     // 64 queries per wave when there are enough query blocks to fill the chip, else 32
     int qw = ((long)((T + 255) / 256) * SYL_HEADS * B >= 512) ? 2 : 1;
-    if (g_attn_qw) qw = g_attn_qw;
+    if (force_qw == 1 || force_qw == 2) qw = force_qw;
     const dim3 grid((qw == 2 ? (T + 255) / 256 : (T + 127) / 128) * SYL_HEADS * B);
     if (ctx_scale) {
         if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, ctx_scale, scale_rows);
@@ -264,12 +261,12 @@ static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* 
 }
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T, int Tp,
-                     int Tpv, hipStream_t s) {
-    return launch_attention_any(q, k, vt, valid, ctx, nullptr, 0, B, T, Tp, Tpv, s);
+                     int Tpv, int qw, hipStream_t s) {
+    return launch_attention_any(q, k, vt, valid, ctx, nullptr, 0, B, T, Tp, Tpv, qw, s);
 }
 
 // same attention, context written as MXFP8 ([B*Tp][768] e4m3 + K-pair-major E8M0 scales with row pitch scale_rows)
 int launch_attention_f8out(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, uint8_t* ctx8, uint8_t* ctx_scale,
-                           long scale_rows, int B, int T, int Tp, int Tpv, hipStream_t s) {
-    return launch_attention_any(q, k, vt, valid, ctx8, ctx_scale, scale_rows, B, T, Tp, Tpv, s);
+                           long scale_rows, int B, int T, int Tp, int Tpv, int qw, hipStream_t s) {
+    return launch_attention_any(q, k, vt, valid, ctx8, ctx_scale, scale_rows, B, T, Tp, Tpv, qw, s);
 }

@@ -32,10 +32,6 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 #include "gemm_epilogue.h"
 
-static int g_gemm_wg_per_cu = 0;   // 0 = one workgroup per tile; k = persistent launch of k x 256 workgroups
-static int g_gemm8_persistent = 0; // 8-wave kernel: 0 = one workgroup per tile; 1 = 256 persistent workgroups
-void gemm_set_wg_per_cu(int k) { if (k >= 10) g_gemm8_persistent = k - 10; else g_gemm_wg_per_cu = k; }
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -50,8 +46,6 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     constexpr int NP = (BM + BN) / RPP;      // 1-KiB pieces per stage
     constexpr int NPW = NP / 4;              // pieces per wave
     static_assert(NP % 4 == 0, "tile must split evenly over 4 waves");
-    constexpr bool NATURAL = (EPI == EPI_V); // A = activations: lane owns a feature column, runs of 4 tokens
-    const unsigned long long t_entry = ((EPI != EPI_PROJ) && (a.xpad_rows & 16)) ? __builtin_readcyclecounter() : 0ull;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -114,10 +108,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn) {
-                if constexpr (NATURAL)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[buf][fm], wf[buf][fn], acc[fm][fn], 0, 0, 0);
-                else
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][fn], xf[buf][fm], acc[fm][fn], 0, 0, 0);
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][fn], xf[buf][fm], acc[fm][fn], 0, 0, 0);
             }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
@@ -131,10 +122,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             const int fm = i / FN, fn = i % FN;
-            if constexpr (NATURAL)
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[buf][fm], wf[buf][fn], acc[fm][fn], 0, 0, 0);
-            else
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][fn], xf[buf][fm], acc[fm][fn], 0, 0, 0);
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][fn], xf[buf][fm], acc[fm][fn], 0, 0, 0);
             // pieces are spread evenly: piece p0 + j goes after MFMA number ceil((j+1)*NM/np) - 1
 #pragma unroll
             for (int p = 0; p < NPW; ++p) {
@@ -162,14 +150,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     __builtin_amdgcn_s_barrier();
     read_frags(smem, 0, 0);
     int slot = 0;
-    const bool timing = (EPI != EPI_PROJ) && (a.xpad_rows & 16);
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
-    auto now = [&]() -> unsigned long long { return timing ? __builtin_readcyclecounter() : 0ull; };
-    const unsigned long long t_loop = now();
     for (int t = 0; t < nt; ++t) {
         const char* sb = smem + slot * STAGE;
         const int nslot = slot == NSTAGE - 1 ? 0 : slot + 1;
-        const unsigned long long t0 = now();
         // 2-slot ring: the DMA of tile t+1 (into the slot tile t-1 left at the previous barrier) was started
         // under the last MFMA group of tile t-1 (pieces [0, D0)) and continues under groups 0 and 1 here
         constexpr int D0 = (NPW * 2 + 4) / 5, D1 = D0 + (NPW - D0 + 1) / 2;   // e.g. NPW = 10 -> 4 | 3 | 3
@@ -184,8 +167,6 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
             else mfmas(kk & 1);
         }
         SCHED_FENCE();
-        const unsigned long long t1 = now();
-        unsigned long long t2 = t1, t3 = t1, t4 = t1;
         if (t + 1 < nt) {
             // every ds_read of tile t has been issued; once they have landed (lgkmcnt(0)) and my pieces of
             // tile t+1 have landed (counted vmcnt: tile t+2 stays in flight), meet the other waves.  After
@@ -196,50 +177,19 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
             if (NSTAGE > 3 && t + 3 < nt) wait_vmcnt<2 * NPW>();
             else if (NSTAGE > 2 && t + 2 < nt) wait_vmcnt<NPW>();
             else wait_vmcnt<0>();
-            t2 = now();
             __builtin_amdgcn_s_barrier();
-            t3 = now();
             SCHED_FENCE();
             read_frags(smem + nslot * STAGE, 0, 0);
             if constexpr (NSTAGE != 2) { if (t + NSTAGE < nt) stage(t + NSTAGE, slot); }
             SCHED_FENCE();
-            t4 = now();
         }
         if constexpr (NSTAGE == 2) mfmas_dma((KK - 1) & 1, t + 2, slot, 0, D0, (t + 1 < nt) && (t + 2 < nt));
         else mfmas((KK - 1) & 1);
         slot = nslot;
-        if (timing) {
-            const unsigned long long t5 = now();
-            tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += t5 - t4;
-        }
-    }
-    const unsigned long long t_loop_end = now();
-    if (timing && lane == 0 && a.out1) {
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)tile_id * 4 + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
-        dbg[5] = t_loop - t_entry;
     }
 
     // ---- epilogue
-    if (EPI != EPI_PROJ && (a.xpad_rows & 8)) {      // development ablation: no stores
-        float sum = 0.f;
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sum += acc[fm][fn][r];
-        if (sum == 123.456f) ((float*)a.out0)[0] = sum;
-        return;
-    }
-    if constexpr (NATURAL) {
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                epilogue_v_natural(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN + fn * 32 + frow, lane);
-    } else if constexpr (EPI == EPI_QK || EPI == EPI_PROJ) {
+    if constexpr (EPI == EPI_QK || EPI == EPI_PROJ) {
         // measured A/B (MI355X): the LDS-staged, line-coalesced epilogue wins for the scattered head-major /
         // dual-output epilogues (+7 % qk, +40 % proj) and is neutral-to-slightly-negative for the others
         static_assert(4 * StagedEpi<FN, EPI>::BYTES <= NSTAGE * STAGE, "epilogue staging must fit the ring");
@@ -254,11 +204,6 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
                 epilogue_swapped<EPI, ACT>(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
-    }
-    if (timing && lane == 0 && a.out1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)tile_id * 4 + wave) * 8;
-        dbg[6] = __builtin_readcyclecounter() - t_loop_end;
     }
 }
 
@@ -290,7 +235,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
     int grid = tiles;
-    if (g_gemm_wg_per_cu > 0 && tiles > g_gemm_wg_per_cu * 256) grid = g_gemm_wg_per_cu * 256;
+    if (a.tune_persist > 0 && tiles > a.tune_persist * 256) grid = a.tune_persist * 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -316,9 +261,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     constexpr int XT = BM * RB, WT = BN * RB, STAGE = XT + WT;
     constexpr int NP = (BM + BN) / 16;               // 1-KiB pieces (16 rows x 64 B) per step
     constexpr int NPW_HI = (NP + 7) / 8, NPW_LO = NP / 8;
-    constexpr bool NATURAL = (EPI == EPI_V);
     static_assert(WM * WN == 8, "8 waves");
-    const unsigned long long t_entry = ((EPI != EPI_PROJ) && (a.xpad_rows & 16)) ? __builtin_readcyclecounter() : 0ull;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int group = wave >> 2;                     // waves w and w+4 share a SIMD
@@ -375,10 +318,6 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nt = a.K / 32;
-    const int abl = (EPI == EPI_PROJ) ? 0 : a.xpad_rows;     // development ablations (micro-benchmark only)
-    const bool timing = abl & 16;
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0};
-    auto now = [&]() -> unsigned long long { return timing ? __builtin_readcyclecounter() : 0ull; };
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     if (nt > 2) stage(2, 2);
@@ -387,26 +326,21 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     __builtin_amdgcn_s_barrier();
     if (group == 1) __builtin_amdgcn_s_barrier();    // stagger: group 1 runs one barrier behind
     int slot = 0;
-    const unsigned long long t_loop = now();
     for (int s = 0; s < nt; ++s) {
         const char* sb = smem + slot * STAGE;
         bf16x8_t xf[2][FM], wf[2][FN];
         // ---- A: fragments of step s, DMA of step s+3, retire step s+1
-        const unsigned long long t0 = now();
         SCHED_FENCE();
-        if (!(abl & 2) || s == 0) {
 #pragma unroll
-            for (int f = 0; f < FM; ++f) {
-                xf[0][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff0);
-                xf[1][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff1);
-            }
-#pragma unroll
-            for (int f = 0; f < FN; ++f) {
-                wf[0][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff0);
-                wf[1][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff1);
-            }
+        for (int f = 0; f < FM; ++f) {
+            xf[0][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff0);
+            xf[1][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff1);
         }
-        const unsigned long long t1 = now();
+#pragma unroll
+        for (int f = 0; f < FN; ++f) {
+            wf[0][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff0);
+            wf[1][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff1);
+        }
         {
             // step s+3's DMA is issued in phase B below (between the MFMAs), so at this point the steps
             // issued after step s+1 are at most {s+2}
@@ -415,9 +349,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SCHED_FENCE();
-        const unsigned long long t2 = now();
         __builtin_amdgcn_s_barrier();
-        const unsigned long long t3 = now();
         SCHED_FENCE();
         // ---- B: MFMAs of step s
         // The LDS-DMA of step s+3 is spread between the MFMAs (one 1-KiB piece per quarter of the MFMAs):
@@ -425,17 +357,14 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         // issued in a burst in phase A it made A the longer phase (measured 623 vs 517 cycles).  Here it
         // issues under MFMAs that are already executing.  Target slot = slot of step s-1: every wave has
         // left A(s-1) at least two program barriers ago.
-        const bool dma = (s + 3 < nt) && !(abl & 1);
+        const bool dma = s + 3 < nt;
         char* dbase = smem + ((slot + 3) & 3) * STAGE;
         constexpr int NMF = 2 * FM * FN;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < NMF; ++i) {
             const int kk = i / (FM * FN), fm = (i / FN) % FM, fn = i % FN;
-            if constexpr (NATURAL)
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[kk][fm], wf[kk][fn], acc[fm][fn], 0, 0, 0);
-            else
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][fn], xf[kk][fm], acc[fm][fn], 0, 0, 0);
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][fn], xf[kk][fm], acc[fm][fn], 0, 0, 0);
             // after MFMA number (q+1)*NMF/NPW_HI - 1 issue piece q
             if ((i + 1) % (NMF / NPW_HI) == 0) {
                 const int q = (i + 1) / (NMF / NPW_HI) - 1;
@@ -446,30 +375,12 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         }
         __builtin_amdgcn_s_setprio(0);
         SCHED_FENCE();
-        const unsigned long long t4 = now();
         __builtin_amdgcn_s_barrier();
-        if (timing) {
-            const unsigned long long t5 = now();
-            tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += t5 - t4;
-        }
         slot = (slot + 1) & 3;
     }
     if (group == 0) __builtin_amdgcn_s_barrier();    // pairs with group 1's extra barrier
-    const unsigned long long t_loop_end = now();
-    if (timing && lane == 0 && a.out1 && wave < 4) {
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)tile_id * 4 + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) dbg[i] = tacc[i];
-        dbg[5] = t_loop - t_entry;
-    }
 
-    if constexpr (NATURAL) {
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                epilogue_v_natural(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN + fn * 32 + frow, lane);
-    } else if (EPI == EPI_QK || EPI == EPI_PROJ || EPI == EPI_BF16 || (abl & 32)) {
+    if constexpr (EPI == EPI_QK || EPI == EPI_PROJ || EPI == EPI_BF16) {
         // measured A/B (MI355X, instrumented): in this one-workgroup-per-CU kernel the LDS-staged, line-coalesced
         // epilogue cuts the bf16 epilogue from 29.8 k to 19.4 k cycles per 256x256 tile (FFN1 +7-9 %, convs neutral)
         static_assert(8 * StagedEpi<FN, EPI>::BYTES <= 4 * STAGE, "epilogue staging must fit the ring");
@@ -484,11 +395,6 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
                 epilogue_swapped<EPI, ACT>(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
-    }
-    if (timing && lane == 0 && a.out1 && wave < 4) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long* dbg = (unsigned long long*)a.out1 + ((size_t)tile_id * 4 + wave) * 8;
-        dbg[6] = __builtin_readcyclecounter() - t_loop_end;
     }
 }
 
@@ -523,7 +429,7 @@ static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
     int grid = tiles;
-    if (g_gemm8_persistent > 0 && tiles > g_gemm8_persistent * 256) grid = g_gemm8_persistent * 256;
+    if (a.tune_persist > 0 && tiles > 256) grid = 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -535,9 +441,6 @@ static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
 //   cfg 10 256x256, 8 waves staggered, 1 WG/CU best for the big GEMMs (conv1-5, FFN1): +20-25 %
 // Two co-resident workgroups (cfg 3/4) cover each other's epilogue / barrier / DMA-issue time; the big
 // tile (cfg 10) instead halves the per-FLOP L1/TA traffic.  Cost = rounds x (tile area per CU) / eff.
-static int g_force_cfg = -1;
-void gemm_force_cfg(int cfg) { g_force_cfg = cfg; }
-
 template <int EPI, int ACT>
 static int launch_t(const GemmArgs& a, hipStream_t s) {
     struct Cfg { int id, bm, bn, per_cu; double eff; };
@@ -552,7 +455,7 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
     int cfg = cfgs[best].id;
-    if (g_force_cfg >= 0) cfg = g_force_cfg;
+    if (a.tune_cfg > 0) cfg = a.tune_cfg - 1;            // per-call override (sylber_set_option / parity tests)
     switch (cfg) {
         case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
         case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT>(a, s);   // 128x128, 2 WG/CU
@@ -577,7 +480,6 @@ int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s) {
         case EPI_F32_RES: return launch_t<EPI_F32_RES, 0>(a, s);
         case EPI_F32_RESLN: return launch_t<EPI_F32_RESLN, 0>(a, s);
         case EPI_QK: return launch_t<EPI_QK, 0>(a, s);
-        case EPI_V: return launch_t<EPI_V, 0>(a, s);
         case EPI_PROJ: return launch_t<EPI_PROJ, 0>(a, s);
     }
     syl_set_error("launch_gemm_bf16", "unknown epilogue");

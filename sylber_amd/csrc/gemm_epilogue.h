@@ -71,30 +71,6 @@ __device__ __forceinline__ void epilogue_swapped(const GemmArgs& a, const f32x16
     }
 }
 
-// V projection (its own launch, EPI_V), NATURAL orientation: lane owns feature n (column l&31) and 16
-// tokens m = mb + (r&3) + 8*(r>>2) + 4*(l>>5): four runs of 4 consecutive tokens -> 8-byte stores
-// into the key-contiguous Vt[b][head][d][t] image the attention kernel reads as MFMA A-operand.
-__device__ __forceinline__ void epilogue_v_natural(const GemmArgs& a, const f32x16_t& acc, int mb, int n, int lane) {
-    if (n >= a.N) return;
-    const int h = lane >> 5;
-    const float bias = a.bias ? a.bias[n] : 0.f;
-    const int nn = n;                            // the V launch has its own weight/bias slice: N = 768
-    const int head = nn >> 6, d = nn & 63;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int m = mb + 8 * g + 4 * h;       // multiple of 4; Tp % 4 == 0 so the run stays in one utterance
-        if (m >= a.M) continue;
-        const int b = m / a.Tp, t = m - b * a.Tp;
-        // key axis stored with bits 2 and 3 swapped: a 16-B chunk then holds exactly the 8 keys one
-        // half-wave contributes to a 16-key P.V MFMA (see attention.hip)
-        const int pos = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
-        uint2 pk;
-        pk.x = pack_bf16x2(acc[4 * g + 0] + bias, acc[4 * g + 1] + bias);
-        pk.y = pack_bf16x2(acc[4 * g + 2] + bias, acc[4 * g + 3] + bias);
-        *(uint2*)((bf16_t*)a.out2 + (((size_t)b * SYL_HEADS + head) * 64 + d) * a.Tpv + pos) = pk;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Coalesced epilogue through LDS (swapped orientation).  Straight from the MFMA layout a lane owns ONE
 // output row and runs of 4 columns, so a store instruction would touch 32 rows with 16-32 bytes each
@@ -113,10 +89,52 @@ struct StagedEpi {
     static constexpr int BYTES = 32 * RS;           // private LDS bytes per wave
 };
 
+// V third of the fused q/k/v projection (EPI_QK, columns n >= 1536), swapped orientation like q and k: the lane
+// owns token mrow0 + (lane & 31) and 16 features per fragment, but V^T wants [b][feature][key] with the key axis
+// contiguous (and bits 2/3 of the key index swapped, see attention.hip).  The wave transposes its 32 tokens x 32 FN
+// features through its private LDS region (ds_write_b16 at [feature][pos(token)], 64-byte rows) and stores 16-byte
+// chunks = 8 keys of one feature row; a 32-token block never straddles utterances because Tp % 32 == 0.
+template <int FN>
+__device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x16_t (&acc)[FN], int mrow0, int ncol0, char* lds,
+                                                   int lane) {
+    const int ml = lane & 31, h = lane >> 5;
+    const int pos = (ml & ~12) | ((ml & 4) << 1) | ((ml & 8) >> 1);
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = 32 * fn + 8 * g + 4 * h;
+            const int n = ncol0 + nl;
+            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias && n < a.N) bb = *(const float4*)(a.bias + n);
+            *(bf16_t*)(lds + (nl + 0) * 64 + pos * 2) = f2bf_dev(acc[fn][4 * g + 0] + bb.x);
+            *(bf16_t*)(lds + (nl + 1) * 64 + pos * 2) = f2bf_dev(acc[fn][4 * g + 1] + bb.y);
+            *(bf16_t*)(lds + (nl + 2) * 64 + pos * 2) = f2bf_dev(acc[fn][4 * g + 2] + bb.z);
+            *(bf16_t*)(lds + (nl + 3) * 64 + pos * 2) = f2bf_dev(acc[fn][4 * g + 3] + bb.w);
+        }
+    if (mrow0 >= a.M) return;
+    const int b = mrow0 / a.Tp, t0 = mrow0 - b * a.Tp;
+#pragma unroll
+    for (int it = 0; it < FN * 2; ++it) {
+        const int idx = it * 64 + lane;
+        const int f = idx >> 2, c = idx & 3;
+        const int n = ncol0 + f;
+        if (n >= a.N) continue;
+        const uint4 raw = *(const uint4*)(lds + f * 64 + c * 16);
+        *(uint4*)((bf16_t*)a.out2 + ((size_t)b * SYL_HIDDEN + (n - 2 * SYL_HIDDEN)) * a.Tpv + t0 + 8 * c) = raw;
+    }
+}
+
 template <int FN, int EPI, int ACT>
 __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_t (&acc)[FN], int mrow0, int ncol0, char* lds,
                                                 int lane) {
     using S = StagedEpi<FN, EPI>;
+    if constexpr (EPI == EPI_QK) {
+        // one launch for q, k and v (N = 2304): the V third leaves through the transposing epilogue (wave-uniform:
+        // every wave's column range lies inside one third, 768 being a multiple of every wave width in use)
+        static_assert(FN * 32 * 64 <= S::BYTES, "V^T staging must fit the wave's region");
+        if (ncol0 >= 2 * SYL_HIDDEN) { epilogue_vt_rows32<FN>(a, acc, mrow0, ncol0, lds, lane); return; }
+    }
     const int ml = lane & 31, h = lane >> 5;
     const int m = mrow0 + ml;
     // ---- in: MFMA layout -> row-major LDS

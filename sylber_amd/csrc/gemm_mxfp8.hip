@@ -277,7 +277,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_mxfp8_kernel(const GemmF8Args a)
     constexpr int NP = NPT + 1;                      // + the scale piece
     constexpr int NPW_HI = (NP + 7) / 8, NPW_LO = NP / 8;
     constexpr int NMF = FM * FN;
-    constexpr bool NATURAL = (EPI == EPI_V);         // A = activations: lane owns a feature column, runs of 4 tokens
     static_assert(WM * WN == 8, "8 waves");
     static_assert(BM <= 256 && BN <= 256, "one scale piece covers 256 + 256 rows");
     extern __shared__ __attribute__((aligned(256))) char smem[];
@@ -388,10 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_mxfp8_kernel(const GemmF8Args a)
 #pragma unroll
         for (int i = 0; i < NMF; ++i) {
             const int fm = i / FN, fn = i % FN;
-            if constexpr (NATURAL)
-                acc[fm][fn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[fm], wf[fn], acc[fm][fn], 0, 0, 0, xsc[fm], 0, wsc[fn]);
-            else
-                acc[fm][fn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[fn], xf[fm], acc[fm][fn], 0, 0, 0, wsc[fn], 0, xsc[fm]);
+            acc[fm][fn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[fn], xf[fm], acc[fm][fn], 0, 0, 0, wsc[fn], 0, xsc[fm]);
 #pragma unroll
             for (int q = 0; q < NPW_HI; ++q) {
                 if (((q + 1) * NMF + NPW_HI - 1) / NPW_HI - 1 == i) {
@@ -415,12 +411,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_mxfp8_kernel(const GemmF8Args a)
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
             epilogue_mxfp8_rows32<FN, ACT>(a, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
-    } else if constexpr (NATURAL) {
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                epilogue_v_natural(a.g, acc[fm][fn], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN + fn * 32 + frow, lane);
     } else if constexpr (EPI == EPI_QK) {
         static_assert(8 * StagedEpi<FN, EPI>::BYTES <= 4 * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();
@@ -470,13 +460,10 @@ static int launch_f8(const GemmF8Args& a, hipStream_t s) {
 
 // tile configurations: 0 = 128x192 (4 waves, 2 workgroups/CU), 1 = 128x128 (same), 2 = 256x256 (8 waves), 3 = 256x192
 // (8 waves); -1 = automatic: the 8-wave tile whose launch needs the fewest rounds over 256 CUs
-static int g_f8_cfg = -1;
-void gemm_mxfp8_force_cfg(int cfg) { g_f8_cfg = cfg; }
-
 template <int EPI, int ACT>
 static int launch_f8_t(const GemmF8Args& a, hipStream_t s) {
-    int cfg = g_f8_cfg;
-    if constexpr (EPI == EPI_QK || EPI == EPI_V) { if (cfg == 0 || cfg == 1) cfg = -1; }   // 8-wave kernels only
+    int cfg = a.g.tune_cfg > 0 ? a.g.tune_cfg - 1 : -1;
+    if constexpr (EPI == EPI_QK) { if (cfg == 0 || cfg == 1) cfg = -1; }   // 8-wave kernels only
     if (cfg < 0) {
         const long t2 = (long)((a.g.M + 255) / 256) * ((a.g.N + 255) / 256), t3 = (long)((a.g.M + 255) / 256) * ((a.g.N + 191) / 192);
         const double c2 = (double)((t2 + 255) / 256) * 256 * 256, c3 = (double)((t3 + 255) / 256) * 256 * 192;
@@ -484,7 +471,7 @@ static int launch_f8_t(const GemmF8Args& a, hipStream_t s) {
     }
     if (cfg == 2) return launch_f8_8<4, 2, 2, 4, EPI, ACT>(a, s);
     if (cfg == 3) return launch_f8_8<2, 3, 4, 2, EPI, ACT>(a, s);
-    if constexpr (EPI != EPI_QK && EPI != EPI_V) {
+    if constexpr (EPI != EPI_QK) {
         if (cfg == 1) return launch_f8<2, 2, EPI, ACT>(a, s);
         return launch_f8<2, 3, EPI, ACT>(a, s);
     }
@@ -506,7 +493,6 @@ int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s) {
             return launch_f8_t<EPI_F32, 0>(a, s);
         case EPI_F32_RESLN: return launch_f8_t<EPI_F32_RESLN, 0>(a, s);
         case EPI_QK: return launch_f8_t<EPI_QK, 0>(a, s);
-        case EPI_V: return launch_f8_t<EPI_V, 0>(a, s);
     }
     syl_set_error("launch_gemm_mxfp8", "unsupported epilogue");
     return 1;

@@ -7,13 +7,15 @@
 // X rows may overlap (ldx < K): the strided 1-D convolutions are run as this GEMM on a channels-last
 // activation buffer with ldx = stride*512, K = taps*512 (implicit GEMM, no im2col).
 // ------------------------------------------------------------------------------------------------
+enum GemmAct { ACT_NONE = 0, ACT_GELU_FAST = 1, ACT_GELU_ERF = 2 };   // GemmArgs::act (bf16 / MXFP8 GEMMs)
 enum GemmEpi {
     EPI_BF16 = 0,       // out0 bf16 [M][ld0] = act(acc + bias)
     EPI_F32 = 1,        // out0 f32  [M][ld0] = act(acc + bias)
     EPI_F32_RES = 2,    // out0 f32  [M][ld0] = acc + bias + res[m][n]
-    EPI_QK = 3,         // N = 1536: q (x0.125) -> out0, k -> out1, both [B,H,Tp,64] bf16
+    EPI_QK = 3,         // fused q/k/v projection: columns [0,768) q (x0.125) -> out0, [768,1536) k -> out1, both
+                        // [B,H,Tp,64] bf16; columns [1536,2304) (N = 2304 only; needs Tp % 32 == 0) v -> out2 = Vt
+                        // [B,H,64,Tpv] bf16 with the key axis bit-swapped, transposed through LDS
     EPI_PROJ = 4,       // feature projection: zero padded frames; out0 f32 [M][768]; out1 bf16 xpad
-    EPI_V = 5,          // N = 768: v -> out2 = Vt [B,H,64,Tpv] bf16 (key axis bit-swapped), natural orientation
     EPI_MXFP8 = 7,      // MXFP8 GEMM only: out0 e4m3 [M][ld0] + out_scale e8m0 [M][N/32] = mx(act(acc + bias))
     EPI_F32_RESLN = 6,  // out0 f32 = acc + bias + LN(res[m][n]) with LN = (x - mean[m]) * rstd[m] * gamma[n] + beta[n]
                         // (the residual IS a LayerNorm output that is never materialised in fp32; out0 may alias res)
@@ -24,7 +26,7 @@ struct GemmArgs {
     const bf16_t* W;              // [N][K] row-major
     int M, N, K;
     const float* bias;            // [N] or nullptr
-    int act;                      // 0 none, 1 gelu(fast), 2 gelu(erf)
+    int act;                      // GemmAct
     void* out0; long ld0;
     void* out1; void* out2;
     const float* res; long ldres;
@@ -33,6 +35,8 @@ struct GemmArgs {
     int xpad_rows;                // rows per utterance of the zero-padded pos-conv input (EPI_PROJ)
     const float* ln_stats;        // [M][2] (mean, rstd) of the rows of `res` (EPI_F32_RESLN)
     const float* ln_gamma; const float* ln_beta;
+    int tune_cfg;                 // 0 = tile shape chosen by the cost model; k > 0 forces tile configuration k - 1
+    int tune_persist;             // > 0: persistent launch (that many workgroups per CU walk the tile list)
 };
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
@@ -49,18 +53,16 @@ struct GemmF8Args {
     const uint8_t* WS; long ws_rows;
     uint8_t* out_scale; long os_rows;  // EPI_MXFP8: scales of the output, pitch os_rows
 };
-int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s);   // epi: EPI_MXFP8, EPI_F32, EPI_F32_RESLN, EPI_QK, EPI_V
-void gemm_mxfp8_force_cfg(int cfg);
+int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s);   // epi: EPI_MXFP8, EPI_F32, EPI_F32_RESLN, EPI_QK, EPI_V (g.tune_cfg as above)
 int launch_mx_quant_rows(const float* in, long ld_in, uint8_t* out, long ld_out, uint8_t* sc, long sc_rows, int R, int K, hipStream_t s);
-void gemm_force_cfg(int cfg);   // -1 = automatic tile-shape choice
-void gemm_set_wg_per_cu(int k); // 4-wave GEMM: 0 = one workgroup per tile, k = persistent launch of k x 256 workgroups
 
 // fp32 parity-mode GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), same epilogues on fp32 tensors
+enum GemmActF32 { ACTF_NONE = 0, ACTF_GELU_ERF = 1, ACTF_RELU = 2 };
 struct GemmArgsF32 {
     const float* X; long ldx;
     const float* W;
     int M, N, K;
-    const float* bias; int act;       // act: 0 none, 1 erf-GELU, 2 ReLU
+    const float* bias; int act;       // GemmActF32 (NOT GemmAct: the parity path has erf-GELU and the conditioner's ReLU)
     float* out0; long ld0;
     const float* res; long ldres;
     int Tp, T; const int* valid;      // feature projection: zero frames t >= min(valid[b], T) (Tp > 0 enables row -> (b,t))
@@ -101,11 +103,11 @@ int launch_layernorm(const LnArgs& a, hipStream_t s);
 // flash attention: softmax(q k^T + key mask) v, 12 heads x 64, q pre-scaled by 1/8
 //   q,k: [B,H,Tp,64] bf16; vt: [B,H,64,Tpv] bf16; ctx out: [B*Tp][768] bf16
 // ------------------------------------------------------------------------------------------------
+// qw: 0 = automatic, 1 / 2 = 32 / 64 queries per wave
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T,
-                     int Tp, int Tpv, hipStream_t s);
+                     int Tp, int Tpv, int qw, hipStream_t s);
 int launch_attention_f8out(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, uint8_t* ctx8, uint8_t* ctx_scale,
-                           long scale_rows, int B, int T, int Tp, int Tpv, hipStream_t s);   // context as MXFP8 (SYLBER_FP8)
-void attention_force_qw(int qw);   // 0 = automatic, 1 / 2 = 32 / 64 queries per wave
+                           long scale_rows, int B, int T, int Tp, int Tpv, int qw, hipStream_t s);   // context as MXFP8 (SYLBER_FP8)
 int launch_attention_f32(const float* q, const float* k, const float* v, const int* valid, float* ctx, int B, int T,
                          int Tp, hipStream_t s);
 

@@ -24,16 +24,21 @@ FRAME_RATE = 50
 
 class ShardedSegmenter:
     """``engine`` is a per-rank object with ``device``, ``num_frames(n)``, ``forward(wav, lengths)`` and
-    ``segment(hidden, norm_thr, merge_thr)`` (sylber_amd.HubertEncoderHIP on the GPU)."""
+    ``segment(hidden, norm_thr, merge_thr)`` (sylber_amd.HubertEncoderHIP on the GPU).  A LIST of engines (independent
+    handles = independent workspaces) lets ``run_stream`` keep that many shards in flight on this rank, each on its
+    own HIP stream: the memory-bound phases of one batch then run under the MFMA phases of the other."""
 
     def __init__(self, engine, norm_threshold: float = 2.6, merge_threshold: float = 0.8, group=None):
-        self.engine = engine
+        self.engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
+        self.engine = self.engines[0]
         self.norm_threshold = norm_threshold
         self.merge_threshold = merge_threshold
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.device = engine.device
+        self.device = self.engine.device
+        self._cuda = torch.device(self.device).type == "cuda"
+        self._streams = [torch.cuda.Stream(device=self.device) for _ in self.engines] if self._cuda else None
 
     # ---- device-level step (what bench.py times) -------------------------------------------------
     def scatter(self, batch_root: Optional[torch.Tensor], lengths_root: Optional[Sequence[int]]):
@@ -67,10 +72,11 @@ class ShardedSegmenter:
             dist.scatter(my_wav, wav_chunks, src=0, group=self.group)
         return my_wav, my_lens, btot, bper
 
-    def compute(self, my_wav: torch.Tensor, my_lens):
+    def compute(self, my_wav: torch.Tensor, my_lens, k: int = 0):
         lens = [int(x) for x in (my_lens.tolist() if torch.is_tensor(my_lens) else my_lens)]
-        hidden = self.engine.forward(my_wav, lens)
-        seg, nseg, feats = self.engine.segment(hidden, self.norm_threshold, self.merge_threshold)
+        eng = self.engines[k]
+        hidden = eng.forward(my_wav, lens)
+        seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold)
         return hidden, seg, nseg, feats
 
     def gather(self, hidden, seg, nseg, feats, btot: int):
@@ -104,7 +110,14 @@ class ShardedSegmenter:
         k = max(1, min(int(max_segments), seg.shape[1]))
         parts = [hidden.contiguous(), seg[:, :k].contiguous(), nseg.contiguous(), feats[:, :k].contiguous()]
         if W == 1:
+            done = None
+            if self._cuda:
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.device))
+
             def wait1():
+                if done is not None:
+                    torch.cuda.current_stream(self.device).wait_event(done)
                 if int(nseg[:btot].max()) > k:
                     raise RuntimeError("an utterance has more than max_segments=%d segments" % k)
                 return tuple(t[:btot] for t in parts)
@@ -175,18 +188,38 @@ class ShardedSegmenter:
             dist.scatter(my_wav, chunks, src=0, group=self.group)
             return my_wav, mine, btot
 
-        nxt = scatter_known(0)
+        # step i runs on engine / stream i % E.  Collectives take their stream dependencies from the stream that is
+        # current when they are issued, so scatter(i+1) is issued under the stream that will consume it and gather(i)
+        # under the stream that produced its operands.
+        import contextlib
+        E = len(self.engines)
+
+        def on(k):
+            return torch.cuda.stream(self._streams[k]) if self._cuda else contextlib.nullcontext()
+
+        if self._cuda:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self._streams:
+                st.wait_stream(cur)                                      # the root batches were produced on `cur`
+        with on(0):
+            nxt = scatter_known(0)
         pending = None
         for i in range(n):
+            k = i % E
             my_wav, my_lens, btot = nxt
             if i + 1 < n:
-                nxt = scatter_known(i + 1)                               # prefetch the next input
-            hidden, seg, nseg, feats = self.compute(my_wav, my_lens)
-            wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments)
+                with on((i + 1) % E):
+                    nxt = scatter_known(i + 1)                           # prefetch the next input
+            with on(k):
+                hidden, seg, nseg, feats = self.compute(my_wav, my_lens, k)
+                wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments)
             if pending is not None:
                 yield pending()
             pending = wait
         yield pending()
+        if self._cuda:
+            for st in self._streams:
+                torch.cuda.current_stream(self.device).wait_stream(st)
 
     # ---- reference-shaped API on root ------------------------------------------------------------
     def __call__(self, wav: Optional[List[torch.Tensor]] = None, in_second: bool = True):

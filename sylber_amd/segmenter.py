@@ -103,7 +103,7 @@ class HubertEncoderHIP:
         h = ctypes.c_void_p()
         prec = {"bf16": 0, "fp32": 1, "fp8": 2}[precision]
         _lib.check(self.lib.sylber_create(ctypes.byref(w), self.device.index or 0, prec, ctypes.byref(h)),
-                   "sylber_create")
+                   "sylber_create")                 # (the library restores the caller's current device itself)
         self.handle = h
         del keep
 
@@ -115,6 +115,14 @@ class HubertEncoderHIP:
 
     def num_frames(self, n_samples: int) -> int:
         return int(self.lib.sylber_num_frames(int(n_samples)))
+
+    def padded_frames(self, n_samples: int) -> int:
+        """frame pitch per utterance of the library's activation buffers (>= num_frames, multiple of 32)"""
+        return int(self.lib.sylber_padded_frames(int(n_samples)))
+
+    def set_option(self, key: int, value: int) -> None:
+        """per-handle tuning / test override (include/sylber_hip.h SYLBER_OPT_*; value < 0 = automatic)"""
+        _lib.check(self.lib.sylber_set_option(self.handle, int(key), int(value)), "sylber_set_option")
 
     def forward(self, wav: torch.Tensor, lengths: Optional[Sequence[int]] = None, stop_stage: int = 0,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -246,11 +254,33 @@ class Segmenter:
                 lengths.append(int(w.shape[1]))
         lmax = max(lengths)
         dev = self.speech_model.device
-        batch = torch.zeros(len(rows), lmax, dtype=torch.float32, device=dev)
-        for i, r in enumerate(rows):
-            batch[i, : lengths[i]] = r.to(dev, torch.float32, non_blocking=True)
+        if all(not r.is_cuda for r in rows):
+            # host inputs: pad on the host into ONE pinned staging buffer and cross PCIe once (a row-by-row copy
+            # loop costs a host round trip per utterance)
+            stage = self._pinned("wav", (len(rows), lmax), torch.float32)
+            for i, r in enumerate(rows):
+                stage[i, : lengths[i]] = r
+                stage[i, lengths[i]:] = 0.0
+            batch = torch.empty(len(rows), lmax, dtype=torch.float32, device=dev)
+            batch.copy_(stage, non_blocking=True)
+        else:
+            batch = torch.zeros(len(rows), lmax, dtype=torch.float32, device=dev)
+            for i, r in enumerate(rows):
+                batch[i, : lengths[i]] = r.to(dev, torch.float32, non_blocking=True)
         hidden = self.speech_model.forward(batch, lengths)
         return hidden, lengths
+
+    def _pinned(self, name: str, shape, dtype) -> torch.Tensor:
+        """grow-only pinned host staging buffers (allocating pinned memory per call costs more than the copy)"""
+        pool = self.__dict__.setdefault("_pin_pool", {})
+        n = 1
+        for d in shape:
+            n *= int(d)
+        buf = pool.get(name)
+        if buf is None or buf.numel() < n or buf.dtype != dtype:
+            buf = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            pool[name] = buf
+        return buf[:n].view(*shape)
 
     def segment(self, input_values=None, features=None, attention_mask=None, mergethreshold=None, normthreshold=None,
                 **kwargs):
@@ -281,11 +311,21 @@ class Segmenter:
         batch_wavs, is_batch = self._collect(wav_file, wav)
         hidden, _ = self.encode_batch(batch_wavs)
         seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold)
+        # D2H: the hidden states (the bulk) leave asynchronously into pinned memory while the host waits for the
+        # segment counts; segments / features are then trimmed to the batch's largest count and follow the same way
+        hid_pin = self._pinned("hidden", tuple(hidden.shape), torch.float32)
+        hid_pin.copy_(hidden, non_blocking=True)
         nseg_h = nseg.cpu().numpy()
         nmax = int(nseg_h.max()) if len(nseg_h) else 0
-        hidden_h = hidden.cpu().numpy()
-        seg_h = seg[:, :max(nmax, 1)].cpu().numpy()
-        feats_h = feats[:, :max(nmax, 1)].cpu().numpy()
+        k = max(nmax, 1)
+        seg_pin = self._pinned("seg", (seg.shape[0], k, 2), torch.int64)
+        feat_pin = self._pinned("feat", (feats.shape[0], k, feats.shape[2]), torch.float32)
+        seg_pin.copy_(seg[:, :k], non_blocking=True)
+        feat_pin.copy_(feats[:, :k], non_blocking=True)
+        torch.cuda.current_stream(hidden.device).synchronize()
+        hidden_h = hid_pin.numpy().copy()                  # the caller owns its arrays; the staging buffers are reused
+        seg_h = seg_pin.numpy().copy()
+        feats_h = feat_pin.numpy().copy()
         outputs = []
         for i in range(hidden_h.shape[0]):
             n = int(nseg_h[i])

@@ -24,6 +24,19 @@ def test_header_symbols_are_exported(lib):
         assert hasattr(lib, name), name
     from sylber_amd import _lib
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    # development aids live in their own header and are not part of the drop-in ABI
+    dev = open(os.path.join(ROOT, "include", "sylber_hip_dev.h")).read()
+    dev_declared = set(re.findall(r"\b(sylber_[a-z0-9_]+)\s*\(", dev))
+    assert dev_declared == set(_lib.DEV_EXPORTS) and not (dev_declared & declared)
+    for name in sorted(dev_declared):
+        assert hasattr(lib, name), name
+
+
+def test_no_process_global_tuning_state():
+    """tuning overrides are per handle (sylber_set_option) or per call: the old process-global force switches are gone"""
+    for f in ("gemm_bf16.hip", "gemm_mxfp8.hip", "attention.hip", "api.hip"):
+        src = open(os.path.join(ROOT, "sylber_amd", "csrc", f)).read()
+        assert "force_cfg" not in src and "g_force" not in src and "xpad_rows &" not in src, f
 
 
 def test_num_frames_matches_conv_formula(lib):

@@ -34,7 +34,7 @@ def test_linear(lib, M, N, K, act):
     b = torch.randn(N, generator=g)
     ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
     c = torch.full((M, N), float("nan"), device="cuda")
-    _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, act, 0, None), "op_linear")
+    _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, act, 0, -1, None), "op_linear")
     ref = _bf(a) @ _bf(w).T + b
     if act:
         ref = torch.nn.functional.gelu(ref)
@@ -63,7 +63,6 @@ def test_layernorm(lib, D):
                                        (6, 499, None)])
 def test_attention(lib, B, T, valid, qw):
     from sylber_amd import _lib
-    lib.sylber_debug_force_gemm_cfg(-100 - qw)      # 32 / 64 queries per wave
     g = torch.Generator().manual_seed(B * 1000 + T)
     q = torch.randn(B, T, 768, generator=g)
     k = torch.randn(B, T, 768, generator=g)
@@ -73,10 +72,7 @@ def test_attention(lib, B, T, valid, qw):
     vd = torch.tensor(valid, dtype=torch.int32).cuda() if valid else None
     o = torch.full((B, T, 768), float("nan"), device="cuda")
     qd, kd, vdev = q.cuda(), k.cuda(), v.cuda()
-    try:
-        _lib.check(lib.sylber_op_attention(_p(qd), _p(kd), _p(vdev), _p(vd), _p(o), B, T, 0, None), "op_attention")
-    finally:
-        lib.sylber_debug_force_gemm_cfg(-100)
+    _lib.check(lib.sylber_op_attention(_p(qd), _p(kd), _p(vdev), _p(vd), _p(o), B, T, 0, 32 * qw, None), "op_attention")
     qh = _bf(q * 0.125).view(B, T, 12, 64).transpose(1, 2)
     kh = _bf(k).view(B, T, 12, 64).transpose(1, 2)
     vh = _bf(v).view(B, T, 12, 64).transpose(1, 2)
@@ -102,11 +98,7 @@ def test_linear_every_tile_config(lib, cfg):
         b = torch.randn(N, generator=g)
         ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
         c = torch.full((M, N), float("nan"), device="cuda")
-        lib.sylber_debug_force_gemm_cfg(cfg)
-        try:
-            _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 1, 0, None), "op_linear")
-        finally:
-            lib.sylber_debug_force_gemm_cfg(-1)
+        _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 1, 0, cfg, None), "op_linear")
         ref = torch.nn.functional.gelu(_bf(a) @ _bf(w).T + b)
         assert (c.cpu() - ref).abs().max().item() < 2e-3, (cfg, M, N, K)
 
@@ -125,14 +117,10 @@ def test_attention_full_batch_no_race(lib):
     ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).transpose(1, 2).reshape(B, T, 768)
     for qw in (1, 2):
         outs = []
-        lib.sylber_debug_force_gemm_cfg(-100 - qw)
-        try:
-            for _ in range(3):
-                o = torch.full((B, T, 768), float("nan"), device="cuda")
-                _lib.check(lib.sylber_op_attention(_p(qd), _p(kd), _p(vdev), None, _p(o), B, T, 0, None), "op_attention")
-                outs.append(o.cpu())
-        finally:
-            lib.sylber_debug_force_gemm_cfg(-100)
+        for _ in range(3):
+            o = torch.full((B, T, 768), float("nan"), device="cuda")
+            _lib.check(lib.sylber_op_attention(_p(qd), _p(kd), _p(vdev), None, _p(o), B, T, 0, 32 * qw, None), "op_attention")
+            outs.append(o.cpu())
         assert (outs[0] - ref).abs().max().item() < 3e-2, qw
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), qw
 
@@ -146,10 +134,6 @@ def test_linear_persistent_grid(lib, per_cu):
     a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
     ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
     c = torch.full((M, N), float("nan"), device="cuda")
-    lib.sylber_debug_force_gemm_cfg(-200 - per_cu)
-    try:
-        _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 0, 0, None), "op_linear")
-    finally:
-        lib.sylber_debug_force_gemm_cfg(-200)
+    _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 0, 0, 1000 * per_cu + 4, None), "op_linear")
     ref = _bf(a) @ _bf(w).T + b
     assert (c.cpu() - ref).abs().max().item() < 2e-3

@@ -9,7 +9,7 @@ def run(a, w):
     M, K = a.shape; N = w.shape[0]
     ad, wd = torch.from_numpy(a).cuda(), torch.from_numpy(w).cuda()
     out = torch.empty(M, N, device="cuda")
-    _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), None, _p(out), M, N, K, 0, 2, None), "lin")
+    _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), None, _p(out), M, N, K, 0, 2, -1, None), "lin")
     return out.cpu().numpy().astype(np.float64)
 rng = np.random.default_rng(0)
 for name, M, N, K, spread in [("narrow", 256, 256, 128, 0), ("narrowK1024", 256, 256, 1024, 0), ("wide", 256, 256, 128, 2), ("ints", 256, 256, 128, -1)]:

@@ -6,16 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sylber_amd import _lib
 
 lib = _lib.load()
-B, Tp = 32, 500
+B, Tp = 32, 512
 M = B * Tp
 SHAPES = [  # name, M, N, K, ldx, epi, act
-    ("conv1", B * 16000, 512, 1536, 1024, 0, 1),
-    ("conv3", B * 4000, 512, 1536, 1024, 0, 1),
-    ("conv6", B * 500, 512, 1024, 1024, 0, 1),
-    ("qk", M, 1536, 768, 768, 1, 0),
-    ("v/out", M, 768, 768, 768, 2, 0),
+    ("conv1", B * Tp * 32, 512, 1536, 1024, 0, 1),
+    ("conv3", B * Tp * 8, 512, 1536, 1024, 0, 1),
+    ("conv6", B * Tp, 512, 1024, 1024, 0, 1),
+    ("qkv", M, 2304, 768, 768, 3, 0),
+    ("out", M, 768, 768, 768, 6, 0),
     ("ffn1", M, 3072, 768, 768, 0, 1),
-    ("ffn2", M, 768, 3072, 3072, 2, 0),
+    ("ffn2", M, 768, 3072, 3072, 6, 0),
     ("sq4096", 4096, 4096, 4096, 4096, 0, 0),
 ]
 cfgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1, 3, 4, 10, 11]
