@@ -298,11 +298,21 @@ static void make_plan(int B, int Lmax, Plan& p) {
     p.o_pre = take(M * 768 * 4);
     p.o_stats = take(M * 2 * 4);
     p.o_hbf16 = take((M + 128) * 768 * 2);
+    // q, k, V^T and the attention context are dead by the time FFN1 writes its intermediate, and that is dead before the
+    // next layer's q/k/v projection: the FFN intermediate ALIASES them, which keeps a layer's working set
+    // (residual stream + bf16 copy + this region + weights = ~190 MB at 32 x 10 s) inside the 256 MB Infinity Cache
+    const size_t attn_begin = off;
     p.o_q = take(M * 768 * 2);
     p.o_k = take(M * 768 * 2);
     p.o_vt = take((size_t)B * 12 * 64 * p.Tpv * 2);
     p.o_ctx = take((M + 128) * 768 * 2);
-    p.o_ffn = take((M + 128) * 3072 * 2);
+    static const bool no_alias = getenv("SYLBER_NO_ALIAS") != nullptr;      // A/B switch (development)
+    if (no_alias) p.o_ffn = take((M + 128) * 3072 * 2);
+    else {
+        p.o_ffn = attn_begin;
+        const size_t need = (M + 128) * 3072 * 2;
+        if (off - attn_begin < need) take(need - (off - attn_begin));
+    }
     p.nchunk = (p.L[0] + 2047) / 2048;
     p.o_part = take((size_t)B * p.nchunk * 65 * 8);
     p.o_ss = take((size_t)B * 512 * 2 * 4);

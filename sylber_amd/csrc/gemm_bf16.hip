@@ -20,8 +20,9 @@
 // picked per launch by a measured cost model (rounds over 256 CUs x tile area / efficiency).  Workgroup ids are
 // remapped so that each XCD owns a contiguous run of tiles (shared X panel in L2; same row ownership as the
 // LayerNorm / attention launches between the GEMMs).
-#include "kernels.h"
+#include <stdlib.h>
 
+#include "kernels.h"
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* glb_vptr;
@@ -195,15 +196,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
         static_assert(4 * StagedEpi<FN, EPI>::BYTES <= NSTAGE * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();                 // every wave is done reading operand tiles
         char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-            epilogue_rows32<FN, EPI, ACT>(a, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
+        epilogue_staged<FM, FN, EPI, ACT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
     } else {
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                epilogue_swapped<EPI, ACT>(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+        epilogue_direct<FM, FN, EPI, ACT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
     }
 }
 
@@ -386,15 +381,9 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         static_assert(8 * StagedEpi<FN, EPI>::BYTES <= 4 * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();                 // every wave is done reading operand tiles
         char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-            epilogue_rows32<FN, EPI, ACT>(a, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
+        epilogue_staged<FM, FN, EPI, ACT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
     } else {
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                epilogue_swapped<EPI, ACT>(a, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+        epilogue_direct<FM, FN, EPI, ACT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
     }
 }
 
@@ -408,6 +397,16 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    // Multi-round launches: the workgroups of the first round start in four phases `tune_stagger` shader cycles
+    // apart (all four phases on every XCD).  Tiles take equal time, so without this every CU reaches its epilogue
+    // at the same moment and 256 x 128 KB of stores hit HBM as one burst (~3.7 TB/s, ~11 k cycles per tile during
+    // which the matrix pipes idle); staggered, a quarter of the CUs store while the others run their K loops, and the
+    // later rounds inherit the phases because a CU's next workgroup starts when its previous one retires.
+    if (a.tune_stagger > 0 && blockIdx.x < 256 && ntiles > 256) {
+        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned)a.tune_stagger;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gemm8_bf16_tile<FM, FN, WM, WN, EPI, ACT>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) {
@@ -430,7 +429,10 @@ static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
     }
     int grid = tiles;
     if (a.tune_persist > 0 && tiles > 256) grid = 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a);
+    GemmArgs b = a;
+    static const int env_stagger = getenv("SYLBER_GEMM_STAGGER") ? atoi(getenv("SYLBER_GEMM_STAGGER")) : 0;
+    if (b.tune_stagger == 0) b.tune_stagger = env_stagger;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, b);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -70,7 +70,8 @@ struct StagedF8 {
 };
 
 template <int FN, int ACT>
-__device__ __forceinline__ void epilogue_mxfp8_rows32(const GemmF8Args& a, const f32x16_t (&acc)[FN], int mrow0, int ncol0, char* lds, int lane) {
+__device__ __forceinline__ void epilogue_mxfp8_rows32(const GemmF8Args& a, const f32x16_t (&acc)[FN], const float4 (&bias)[FN][4], int mrow0,
+                                                      int ncol0, char* lds, int lane) {
     using S = StagedF8<FN>;
     const int ml = lane & 31, h = lane >> 5;
     const int m = mrow0 + ml;
@@ -80,9 +81,7 @@ __device__ __forceinline__ void epilogue_mxfp8_rows32(const GemmF8Args& a, const
         float amax = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int n = ncol0 + 32 * fn + 8 * g + 4 * h;
-            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.g.bias && n < a.g.N) bb = *(const float4*)(a.g.bias + n);
+            const float4 bb = bias[fn][g];
             v[4 * g + 0] = acc[fn][4 * g + 0] + bb.x; v[4 * g + 1] = acc[fn][4 * g + 1] + bb.y;
             v[4 * g + 2] = acc[fn][4 * g + 2] + bb.z; v[4 * g + 3] = acc[fn][4 * g + 3] + bb.w;
             apply_act4<ACT>(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
@@ -246,15 +245,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const GemmF8Args a) 
         static_assert(4 * StagedF8<FN>::BYTES <= 2 * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();
         char* my = smem + wave * StagedF8<FN>::BYTES;
+        float4 bias4[FN][4];
+        load_colvec<FN>(a.g.bias, n0 + wn * 32 * FN, lane >> 5, a.g.N, bias4);
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
-            epilogue_mxfp8_rows32<FN, ACT>(a, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
+            epilogue_mxfp8_rows32<FN, ACT>(a, acc[fm], bias4, m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
     } else {
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                epilogue_swapped<EPI, ACT>(a.g, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+        epilogue_direct<FM, FN, EPI, ACT>(a.g, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
     }
 }
 
@@ -408,22 +405,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_mxfp8_kernel(const GemmF8Args a)
         static_assert(8 * StagedF8<FN>::BYTES <= 4 * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();
         char* my = smem + wave * StagedF8<FN>::BYTES;
+        float4 bias4[FN][4];
+        load_colvec<FN>(a.g.bias, n0 + wn * 32 * FN, lane >> 5, a.g.N, bias4);
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
-            epilogue_mxfp8_rows32<FN, ACT>(a, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
+            epilogue_mxfp8_rows32<FN, ACT>(a, acc[fm], bias4, m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
     } else if constexpr (EPI == EPI_QK) {
         static_assert(8 * StagedEpi<FN, EPI>::BYTES <= 4 * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();
         char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-            epilogue_rows32<FN, EPI, ACT>(a.g, acc[fm], m0 + wm * 32 * FM + fm * 32, n0 + wn * 32 * FN, my, lane);
+        epilogue_staged<FM, FN, EPI, ACT>(a.g, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
     } else {
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                epilogue_swapped<EPI, ACT>(a.g, acc[fm][fn], m0 + wm * 32 * FM + fm * 32 + frow, n0 + wn * 32 * FN + fn * 32, lane);
+        epilogue_direct<FM, FN, EPI, ACT>(a.g, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
     }
 }
 

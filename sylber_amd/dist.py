@@ -28,7 +28,8 @@ class ShardedSegmenter:
     handles = independent workspaces) lets ``run_stream`` keep that many shards in flight on this rank, each on its
     own HIP stream: the memory-bound phases of one batch then run under the MFMA phases of the other."""
 
-    def __init__(self, engine, norm_threshold: float = 2.6, merge_threshold: float = 0.8, group=None):
+    def __init__(self, engine, norm_threshold: float = 2.6, merge_threshold: float = 0.8, group=None,
+                 always_collective: bool = False):
         self.engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
         self.engine = self.engines[0]
         self.norm_threshold = norm_threshold
@@ -37,6 +38,9 @@ class ShardedSegmenter:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = self.engine.device
+        # a one-rank group normally short-cuts the exchange; `always_collective` sends it through the communicator
+        # anyway (scatter / gather to self) so that the RCCL code path can be exercised on a one-GPU box
+        self._coll = self.world > 1 or (always_collective and dist.is_initialized())
         self._cuda = torch.device(self.device).type == "cuda"
         self._streams = [torch.cuda.Stream(device=self.device) for _ in self.engines] if self._cuda else None
 
@@ -48,14 +52,14 @@ class ShardedSegmenter:
         meta = torch.zeros(2, dtype=torch.int64, device=self.device)
         if self.rank == 0:
             meta[0], meta[1] = batch_root.shape[0], batch_root.shape[1]
-        if W > 1:
+        if self._coll:
             dist.broadcast(meta, src=0, group=self.group)
         btot, lmax = int(meta[0]), int(meta[1])
         bper = (btot + W - 1) // W
         lens = torch.full((bper * W,), lmax, dtype=torch.int32, device=self.device)
         if self.rank == 0 and lengths_root is not None:
             lens[:btot] = torch.as_tensor(list(lengths_root), dtype=torch.int32)
-        if W == 1:
+        if not self._coll:
             my_wav, my_lens = batch_root, lens
         else:
             my_lens = torch.empty(bper, dtype=torch.int32, device=self.device)
@@ -82,7 +86,7 @@ class ShardedSegmenter:
     def gather(self, hidden, seg, nseg, feats, btot: int):
         """Root receives [Btot, ...] tensors; other ranks receive None."""
         W = self.world
-        if W == 1:
+        if not self._coll:
             return hidden[:btot], seg[:btot], nseg[:btot], feats[:btot]
 
         def g(t):
@@ -109,7 +113,7 @@ class ShardedSegmenter:
         W = self.world
         k = max(1, min(int(max_segments), seg.shape[1]))
         parts = [hidden.contiguous(), seg[:, :k].contiguous(), nseg.contiguous(), feats[:, :k].contiguous()]
-        if W == 1:
+        if not self._coll:
             done = None
             if self._cuda:
                 done = torch.cuda.Event()
@@ -159,7 +163,7 @@ class ShardedSegmenter:
         if self.rank == 0:
             for i, b in enumerate(batches):
                 shapes[i, 0], shapes[i, 1] = b.shape[0], b.shape[1]
-        if W > 1:
+        if self._coll:
             dist.broadcast(shapes, src=0, group=self.group)
         shapes_h = shapes.tolist()
         bmax = max(int(s_[0]) for s_ in shapes_h)
@@ -168,7 +172,7 @@ class ShardedSegmenter:
             for i, (bt, lm) in enumerate(shapes_h):
                 src = lengths_root[i] if (lengths_root is not None and lengths_root[i] is not None) else [lm] * bt
                 lens_all[i, :bt] = torch.as_tensor(list(src), dtype=torch.int64)
-        if W > 1:
+        if self._coll:
             dist.broadcast(lens_all, src=0, group=self.group)
         lens_h = lens_all.tolist()
 
@@ -176,7 +180,7 @@ class ShardedSegmenter:
             btot, lmax = int(shapes_h[i][0]), int(shapes_h[i][1])
             bper = (btot + W - 1) // W
             mine = (lens_h[i][:btot] + [lmax] * (bper * W - btot))[self.rank * bper:(self.rank + 1) * bper]
-            if W == 1:
+            if not self._coll:
                 return batches[i], mine, btot
             my_wav = torch.empty(bper, lmax, dtype=torch.float32, device=self.device)
             chunks = None

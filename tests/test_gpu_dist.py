@@ -1,0 +1,93 @@
+"""GPU tier: ``ShardedSegmenter`` driving the HIP engine (world_size 1 on the one-GPU box) — the N > 1 control flow of
+bench.py / sylber_amd/dist.py with the real kernels: ``step``, the pipelined ``run_stream`` (two handles in flight) and the
+reference-shaped ``__call__`` agree BITWISE with the single-process ``Segmenter``; the same again with every exchange
+forced through a one-rank RCCL communicator (scatter / gather / broadcast to self), which is the only RCCL
+coverage a one-GPU box allows; and ``bench.py --gpus 2`` refuses to run on one GPU instead of reporting n_gpus: 1."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from sylber_amd.synth import syllable_wave
+from sylber_amd.weights import synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LENS = [24000, 16000, 31000, 9000, 20000]
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synthetic_state_dict(0)
+
+
+def _batches(lens_sets):
+    out = []
+    for j, ls in enumerate(lens_sets):
+        b = torch.zeros(len(ls), max(ls))
+        for i, n in enumerate(ls):
+            b[i, :n] = syllable_wave(n, 40 + 10 * j + i)[0]
+        out.append(b.cuda())
+    return out
+
+
+def _check_against_segmenter(S, sd):
+    from sylber_amd import Segmenter
+    wavs = [syllable_wave(n, 60 + i) for i, n in enumerate(LENS)]
+    ref = Segmenter(model_ckpt=sd)(wav=wavs, in_second=False)
+    got = S(wavs, in_second=False)
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g["hidden_states"], r["hidden_states"])
+        assert g["segments"].shape == r["segments"].shape and np.array_equal(g["segments"], r["segments"])
+        assert np.array_equal(g["segment_features"], r["segment_features"], equal_nan=True)
+    # step() and the pipelined stream (two handles in flight) return the same tensors batch by batch
+    sets = [LENS, LENS[1:4], LENS[::-1], LENS[:2]]
+    batches = _batches(sets)
+    sync = [S.step(b, ls) for b, ls in zip(batches, sets)]
+    streamed = list(S.run_stream(batches, sets, max_segments=96))
+    torch.cuda.synchronize()
+    assert len(streamed) == len(sync)
+    for a, b in zip(sync, streamed):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+        for i, n in enumerate(a[2].tolist()):           # rows beyond an utterance's own count are uninitialised
+            assert torch.equal(a[1][i, :n], b[1][i, :n]) and torch.equal(a[3][i, :n], b[3][i, :n])
+
+
+def test_sharded_hip_engine_world1(sd):
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.dist import ShardedSegmenter
+    S = ShardedSegmenter([HubertEncoderHIP(sd), HubertEncoderHIP(sd)])
+    _check_against_segmenter(S, sd)
+
+
+def test_sharded_hip_engine_through_rccl_one_rank(sd):
+    import torch.distributed as dist
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.dist import ShardedSegmenter
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        S = ShardedSegmenter([HubertEncoderHIP(sd), HubertEncoderHIP(sd)], always_collective=True)
+        assert S._coll
+        _check_against_segmenter(S, sd)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "GPU" in r.stderr and '"n_gpus"' not in r.stdout
