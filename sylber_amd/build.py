@@ -16,7 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsylber_hip.so")
 SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip"]
 EXTRA = {"segment.hip": ["-ffp-contract=off"]}
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# -fno-slp-vectorize: NO packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the library.  Measured on
+# MI355X / ROCm 7.2 (profiles/r02_packed_f32_hazard.md): a wave running dependent packed-fp32 chains returns wrong values
+# in lanes 48-63 of the LOW half of a result when MFMA waves of another kernel share its SIMD (two streams in flight).
+# tests/test_abi.py checks the built objects for such instructions.
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize", "-fno-vectorize"]
 
 
 def _hipcc() -> str:

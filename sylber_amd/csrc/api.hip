@@ -306,10 +306,8 @@ static void make_plan(int B, int Lmax, Plan& p) {
     p.o_k = take(M * 768 * 2);
     p.o_vt = take((size_t)B * 12 * 64 * p.Tpv * 2);
     p.o_ctx = take((M + 128) * 768 * 2);
-    static const bool no_alias = getenv("SYLBER_NO_ALIAS") != nullptr;      // A/B switch (development)
-    if (no_alias) p.o_ffn = take((M + 128) * 3072 * 2);
-    else {
-        p.o_ffn = attn_begin;
+    p.o_ffn = attn_begin;
+    {
         const size_t need = (M + 128) * 3072 * 2;
         if (off - attn_begin < need) take(need - (off - attn_begin));
     }

@@ -20,8 +20,6 @@
 // picked per launch by a measured cost model (rounds over 256 CUs x tile area / efficiency).  Workgroup ids are
 // remapped so that each XCD owns a contiguous run of tiles (shared X panel in L2; same row ownership as the
 // LayerNorm / attention launches between the GEMMs).
-#include <stdlib.h>
-
 #include "kernels.h"
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -397,16 +395,6 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    // Multi-round launches: the workgroups of the first round start in four phases `tune_stagger` shader cycles
-    // apart (all four phases on every XCD).  Tiles take equal time, so without this every CU reaches its epilogue
-    // at the same moment and 256 x 128 KB of stores hit HBM as one burst (~3.7 TB/s, ~11 k cycles per tile during
-    // which the matrix pipes idle); staggered, a quarter of the CUs store while the others run their K loops, and the
-    // later rounds inherit the phases because a CU's next workgroup starts when its previous one retires.
-    if (a.tune_stagger > 0 && blockIdx.x < 256 && ntiles > 256) {
-        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned)a.tune_stagger;
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gemm8_bf16_tile<FM, FN, WM, WN, EPI, ACT>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) {
@@ -429,10 +417,7 @@ static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
     }
     int grid = tiles;
     if (a.tune_persist > 0 && tiles > 256) grid = 256;
-    GemmArgs b = a;
-    static const int env_stagger = getenv("SYLBER_GEMM_STAGGER") ? atoi(getenv("SYLBER_GEMM_STAGGER")) : 0;
-    if (b.tune_stagger == 0) b.tune_stagger = env_stagger;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, b);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -37,7 +37,6 @@ struct GemmArgs {
     const float* ln_gamma; const float* ln_beta;
     int tune_cfg;                 // 0 = tile shape chosen by the cost model; k > 0 forces tile configuration k - 1
     int tune_persist;             // > 0: persistent launch (that many workgroups per CU walk the tile list)
-    int tune_stagger;             // 8-wave kernel, multi-round launches: phase offset of the first round in shader cycles
 };
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);

@@ -73,3 +73,13 @@ def test_bench_cli_parses():
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
+
+
+def test_no_packed_fp32_valu_in_the_library(lib):
+    """v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 are banned from every kernel: beside MFMA waves of another kernel on
+    the same SIMD they returned wrong values in lanes 48-63 (profiles/r02_packed_f32_hazard.md)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    from sylber_amd import _lib
+    assert check_isa.banned_instructions(_lib.LIB_PATH) == {}
