@@ -102,7 +102,8 @@ int sylber_segment(sylber_t h, const float* hidden_dev, int32_t B, int32_t T, in
  *   wav, sr = torchaudio.load(file); if sr != 16000: wav = torchaudio.transforms.Resample(sr, 16000)(wav);
  *   wav = (wav - wav.mean()) / wav.std()
  * pcm_dev      interleaved little-endian PCM frames as they sit in the file's data chunk, on the device
- * sample_width bytes per sample: 1 (uint8), 2 (int16), 3 (int24), 4 (int32); scaled to [-1, 1) like torchaudio.load
+ * sample_width bytes per sample: 1 (uint8), 2 (int16), 3 (int24), 4 (int32), scaled to [-1, 1) like torchaudio.load;
+ *              -4 / -8: IEEE float32 / float64 samples (WAVE_FORMAT_IEEE_FLOAT), taken as they are
  * normalize    non-zero: (x - mean) / unbiased std over all channels x frames
  * wav_out_dev  [channels, sylber_ingest_num_frames(frames_in, sr_in)] fp32, every channel one future batch row
  * workspace_dev sylber_ingest_workspace_bytes(sr_in) bytes, 8-byte aligned, owned by the caller
@@ -155,6 +156,13 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *   SYLBER_OPT_GEMM_PERSISTENT         k > 0: GEMM launches of k x 256 persistent workgroups walking the tile list */
 enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3 };
 int sylber_set_option(sylber_t h, int32_t key, int32_t value);
+
+/* the `features is not None` branch of resynthesize (segment_synthesis.py:135-140): features_dev [rows, input_dim] frame
+ * features supplied by the caller (e.g. decoded unit embeddings) -> cond_dev [rows, output_dim] = MLP(features), rows with
+ * ((f**2).sum(-1))**.5 < 1e-4 zeroed (no 1e-8 under the root, threshold fixed at 1e-4, :136-137);
+ * workspace_dev: sylber_condition_workspace_floats(m, rows, 1) floats */
+int sylber_condition_features(sylber_mlp_t m, const float* features_dev, int32_t rows, float* cond_dev, float* workspace_dev,
+                              void* stream);
 
 /* ---- introspection used by parity tests and the benchmark ------------------------------------ */
 /* run sylber_forward only up to a stage: 0 = all, 1 = conv stack, 2 = +projection/pos-conv/LN,

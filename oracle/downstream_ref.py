@@ -37,14 +37,29 @@ def mlp_forward(sd, x: torch.Tensor) -> torch.Tensor:
     return F.linear(x, sd["mlp.%d.weight" % (2 * n)], sd["mlp.%d.bias" % (2 * n)])                        # :46
 
 
-def resynth_front(sd, hidden: torch.Tensor, normthreshold: float, merge_threshold: float = 0.8):
-    """segment_synthesis.py:106-139 without the quantizer branch: returns (input, averaged_target_hidden_states, segments)"""
+def resynth_front(sd, hidden: torch.Tensor, normthreshold: float, merge_threshold: float = 0.8, centroids=None,
+                  normalize: bool = False):
+    """segment_synthesis.py:106-139: returns (input, averaged_target_hidden_states, segments).  ``centroids`` [K,768]
+    switches on the quantizer branch (:121-125): every segment mean is replaced by the codebook entry of its nearest
+    centroid (``get_indices`` :98-111 -> ``get_output_from_indices``)."""
     norms = ((hidden ** 2).sum(-1) + 1e-8) ** .5                                                            # :110
     segments = [segment_oracle.get_segment(s.numpy(), normthreshold, merge_threshold) for s in hidden]      # :112
     avg = torch.zeros_like(hidden)                                                                          # :115
     for b in range(len(hidden)):
         for s, e in segments[b].reshape(-1, 2):
-            avg[b][s:e] = hidden[b][s:e].mean(0)                                                            # :121,126
+            ft = hidden[b][s:e].mean(0)                                                                     # :121
+            if centroids is not None:                                                                       # :122-125
+                idx, _ = km_indices(ft.numpy()[None], centroids, normalize)
+                ft = torch.from_numpy(np.asarray(centroids, np.float32)[idx[0]])
+            avg[b][s:e] = ft                                                                                # :126
     inp = mlp_forward(sd, avg)                                                                              # :138
     inp[norms < normthreshold] = 0.0                                                                        # :139
     return inp, avg, segments
+
+
+def resynth_front_features(sd, features: torch.Tensor) -> torch.Tensor:
+    """the ``features is not None`` branch, segment_synthesis.py:135-139: no 1e-8 under the root, threshold 1e-4"""
+    norms = ((features ** 2).sum(-1)) ** .5                                                                 # :136
+    inp = mlp_forward(sd, features)                                                                         # :138
+    inp[norms < 1e-4] = 0.0                                                                                 # :137,139
+    return inp

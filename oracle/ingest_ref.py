@@ -34,7 +34,11 @@ TARGET_RATE = 16000
 def decode_pcm(raw: np.ndarray, sample_width: int, channels: int) -> np.ndarray:
     """interleaved little-endian PCM bytes -> float32 [C, N] scaled like torchaudio.load (sylber.py:83)"""
     raw = np.ascontiguousarray(raw, dtype=np.uint8)
-    if sample_width == 2:
+    if sample_width == -4:                                 # WAVE_FORMAT_IEEE_FLOAT: torchaudio.load returns the samples as stored
+        x = raw.view("<f4").astype(np.float32)
+    elif sample_width == -8:
+        x = raw.view("<f8").astype(np.float32)
+    elif sample_width == 2:
         x = raw.view("<i2").astype(np.float32) * np.float32(1.0 / 32768.0)
     elif sample_width == 4:
         x = raw.view("<i4").astype(np.float32) * np.float32(1.0 / 2147483648.0)

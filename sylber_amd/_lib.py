@@ -66,6 +66,7 @@ EXPORTS = {
     "sylber_condition_workspace_floats": (c_int64, [c_void_p, c_int32, c_int32]),
     "sylber_condition": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
+    "sylber_condition_features": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "sylber_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
 }

@@ -699,6 +699,15 @@ extern "C" int sylber_segment(sylber_t c, const float* hidden_dev, int32_t B, in
     if (!c || !hidden_dev || !seg_dev || !nseg_dev) { syl_set_error("sylber_segment", "null argument"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     GUARD_DEVICE(c->device);
+    // utterances beyond 3940 frames (78.8 s) keep their bookkeeping in a global slab instead of LDS (grow-only)
+    const size_t need = segment_scratch_floats(B, T, D);
+    if (need > c->seg_scratch_floats) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->seg_scratch) HIP_TRY(hipFree(c->seg_scratch));
+        c->seg_scratch = nullptr; c->seg_scratch_floats = 0;
+        HIP_TRY(hipMalloc((void**)&c->seg_scratch, need * 4));
+        c->seg_scratch_floats = need;
+    }
     ProfScope ps(c, s, "segment");
     return launch_segment(hidden_dev, B, T, D, norm_thr, merge_thr, seg_dev, nseg_dev, feat_dev, c->seg_scratch, s);
 }

@@ -34,10 +34,11 @@ __host__ __device__ __forceinline__ float bf2f(bf16_t h) {
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 // device-side packing: the fptrunc lowers to v_cvt_pk_bf16_f32 (RNE) on gfx950
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    bf16x2_t p;
-    p[0] = (__bf16)lo;
-    p[1] = (__bf16)hi;
-    return __builtin_bit_cast(uint32_t, p);
+    // an explicit <2 x float> -> <2 x bfloat> truncation: one v_cvt_pk_bf16_f32 without relying on the SLP vectorizer
+    // (which is off, see build.py)
+    typedef float f32pair_t __attribute__((ext_vector_type(2)));
+    const f32pair_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ bf16_t f2bf_dev(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 

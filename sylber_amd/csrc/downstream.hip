@@ -112,6 +112,13 @@ extern "C" int sylber_km_decode(const int32_t* idx_dev, int32_t n, const float* 
 }
 
 // ---- N3 ---------------------------------------------------------------------------------------------------------
+// entry points run on the handle's GPU and leave the caller's current device as they found it
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); }
+    ~DevGuard() { int cur = -1; if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev); }
+};
+
 struct sylber_mlp {
     int device = 0, input_dim = 0, output_dim = 0, num_hidden = 0, dims[SYLBER_MLP_MAX_HIDDEN] = {0};
     float* base = nullptr; size_t bytes = 0;
@@ -126,7 +133,7 @@ extern "C" int sylber_mlp_create(const SylberMlpWeights* w, int device, sylber_m
     }
     for (int i = 0; i < w->num_hidden; ++i)
         if (w->hidden_dims[i] != 512 && w->hidden_dims[i] != 768) { syl_set_error("sylber_mlp_create", "hidden dims must be 512 or 768 (LayerNorm kernel)"); return 1; }
-    HIP_TRY(hipSetDevice(device));
+    DevGuard dg(device);
     sylber_mlp* m = new sylber_mlp();
     m->device = device; m->input_dim = w->input_dim; m->output_dim = w->output_dim; m->num_hidden = w->num_hidden;
     std::vector<float> host;
@@ -161,7 +168,7 @@ extern "C" int sylber_mlp_create(const SylberMlpWeights* w, int device, sylber_m
 }
 extern "C" void sylber_mlp_destroy(sylber_mlp_t m) {
     if (!m) return;
-    hipSetDevice(m->device);
+    DevGuard dg(m->device);
     if (m->base) hipFree(m->base);
     delete m;
 }
@@ -216,27 +223,16 @@ __global__ __launch_bounds__(256) void cond_scatter_kernel(const float* __restri
     if (avg_out) for (int c = lane; c < D; c += 64) avg_out[(size_t)f * D + c] = j >= 0 ? feat[((size_t)b * T + j) * D + c] : 0.f;
 }
 
-extern "C" int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg_dev, const int32_t* nseg_dev, const float* feat_dev,
-                                int32_t B, int32_t T, int32_t S, float norm_thr, float* avg_hidden_dev, float* cond_dev, float* workspace_dev,
-                                void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (!m || !hidden_dev || !seg_dev || !nseg_dev || !feat_dev || !cond_dev || !workspace_dev) { syl_set_error("sylber_condition", "null argument"); return 1; }
-    if (B < 1 || T < 1 || S < 1 || S > T) { syl_set_error("sylber_condition", "need B, T >= 1 and 1 <= S <= T"); return 1; }
-    HIP_TRY(hipSetDevice(m->device));
-    const int D = m->input_dim, R = B * S + 1, MD = mlp_maxdim(m);
-    float* x0 = workspace_dev;
-    float* ha = x0 + (size_t)R * D; float* hb = ha + (size_t)R * MD; float* hc = hb + (size_t)R * MD;
-    float* yo = hc + (size_t)R * MD;
-    hipLaunchKernelGGL(cond_gather_kernel, dim3(R), dim3(256), 0, s, feat_dev, nseg_dev, x0, B, T, S, D);
-    HIP_TRY(hipGetLastError());
-    const float* cur = x0; int in = D;
+// the `MLP` module (segment_synthesis.py:35-53) over R rows: x0 [R, input_dim] -> yo [R, output_dim]; ha/hb/hc: [R, maxdim] each
+static int run_mlp(const sylber_mlp* m, const float* x0, int R, float* ha, float* hb, float* hc, float* yo, hipStream_t s) {
+    const float* cur = x0; int in = m->input_dim;
     for (int i = 0; i < m->num_hidden; ++i) {
         const int d = m->dims[i];
         GemmArgsF32 g = {};
         g.X = cur; g.ldx = in; g.W = m->h[i].lin_w; g.M = R; g.N = d; g.K = in; g.bias = m->h[i].lin_b; g.out0 = ha; g.ld0 = d;
         if (launch_gemm_f32(g, s)) return 1;                                   // x = Linear(in, d)(x)
         GemmArgsF32 f1 = {};
-        f1.X = ha; f1.ldx = d; f1.W = m->h[i].ff1_w; f1.M = R; f1.N = d; f1.K = d; f1.bias = m->h[i].ff1_b; f1.act = 2; f1.out0 = hb; f1.ld0 = d;
+        f1.X = ha; f1.ldx = d; f1.W = m->h[i].ff1_w; f1.M = R; f1.N = d; f1.K = d; f1.bias = m->h[i].ff1_b; f1.act = ACTF_RELU; f1.out0 = hb; f1.ld0 = d;
         if (launch_gemm_f32(f1, s)) return 1;                                  // relu(linear1(x))   (RFF, :28)
         GemmArgsF32 f2 = {};
         f2.X = hb; f2.ldx = d; f2.W = m->h[i].ff2_w; f2.M = R; f2.N = d; f2.K = d; f2.bias = m->h[i].ff2_b; f2.out0 = hc; f2.ld0 = d;
@@ -250,10 +246,57 @@ extern "C" int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const i
     }
     GemmArgsF32 go = {};
     go.X = cur; go.ldx = in; go.W = m->out_w; go.M = R; go.N = m->output_dim; go.K = in; go.bias = m->out_b; go.out0 = yo; go.ld0 = m->output_dim;
-    if (launch_gemm_f32(go, s)) return 1;
+    return launch_gemm_f32(go, s);
+}
+
+extern "C" int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg_dev, const int32_t* nseg_dev, const float* feat_dev,
+                                int32_t B, int32_t T, int32_t S, float norm_thr, float* avg_hidden_dev, float* cond_dev, float* workspace_dev,
+                                void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!m || !hidden_dev || !seg_dev || !nseg_dev || !feat_dev || !cond_dev || !workspace_dev) { syl_set_error("sylber_condition", "null argument"); return 1; }
+    if (B < 1 || T < 1 || S < 1 || S > T) { syl_set_error("sylber_condition", "need B, T >= 1 and 1 <= S <= T"); return 1; }
+    DevGuard dg(m->device);
+    const int D = m->input_dim, R = B * S + 1, MD = mlp_maxdim(m);
+    float* x0 = workspace_dev;
+    float* ha = x0 + (size_t)R * D; float* hb = ha + (size_t)R * MD; float* hc = hb + (size_t)R * MD;
+    float* yo = hc + (size_t)R * MD;
+    hipLaunchKernelGGL(cond_gather_kernel, dim3(R), dim3(256), 0, s, feat_dev, nseg_dev, x0, B, T, S, D);
+    HIP_TRY(hipGetLastError());
+    if (run_mlp(m, x0, R, ha, hb, hc, yo, s)) return 1;
     const long frames = (long)B * T;
     hipLaunchKernelGGL(cond_scatter_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, s, hidden_dev, seg_dev, nseg_dev, feat_dev, yo, B, T, S, D,
                        m->output_dim, norm_thr, avg_hidden_dev, cond_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the `features is not None` branch of resynthesize (segment_synthesis.py:135-140): the caller hands in the (already
+// averaged / decoded) frame features; input = MLP(features), zeroed where ((features**2).sum(-1))**.5 < 1e-4 -- NO 1e-8
+// under the root here, and the threshold is the constant 1e-4 (:136-137)
+__global__ __launch_bounds__(256) void cond_mask_rows_kernel(const float* __restrict__ feats, const float* __restrict__ mlp_rows, long rows, int D, int OD,
+                                                             float* __restrict__ cond_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long f = (long)blockIdx.x * 4 + wave;
+    if (f >= rows) return;
+    const float* h = feats + (size_t)f * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s = fmaf(h[c], h[c], s);
+    s = wave_sum(s);
+    const bool silent = sqrtf(s) < 1e-4f;
+    for (int c = lane; c < OD; c += 64) cond_out[(size_t)f * OD + c] = silent ? 0.f : mlp_rows[(size_t)f * OD + c];
+}
+
+extern "C" int sylber_condition_features(sylber_mlp_t m, const float* features_dev, int32_t rows, float* cond_dev, float* workspace_dev,
+                                         void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!m || !features_dev || !cond_dev || !workspace_dev) { syl_set_error("sylber_condition_features", "null argument"); return 1; }
+    if (rows < 1) { syl_set_error("sylber_condition_features", "need rows >= 1"); return 1; }
+    DevGuard dg(m->device);
+    const int R = rows, MD = mlp_maxdim(m);
+    float* ha = workspace_dev; float* hb = ha + (size_t)R * MD; float* hc = hb + (size_t)R * MD; float* yo = hc + (size_t)R * MD;
+    if (run_mlp(m, features_dev, R, ha, hb, hc, yo, s)) return 1;
+    hipLaunchKernelGGL(cond_mask_rows_kernel, dim3((unsigned)(((long)R + 3) / 4)), dim3(256), 0, s, features_dev, yo, (long)R, m->input_dim,
+                       m->output_dim, cond_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }

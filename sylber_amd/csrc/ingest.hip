@@ -72,8 +72,11 @@ static const IngestTable* get_table(int sr_in) {
     return t;
 }
 
-// torchaudio.load scaling: int16 / 2^15, int32 / 2^31, 24-bit / 2^23, uint8 (x - 128) / 128
+// torchaudio.load scaling: int16 / 2^15, int32 / 2^31, 24-bit / 2^23, uint8 (x - 128) / 128; IEEE-float files
+// (width -4 = float32, -8 = float64) are taken as they are (float64 rounded to float32)
 __device__ __forceinline__ float pcm_sample(const unsigned char* __restrict__ pcm, int width, long idx) {
+    if (width == -4) return ((const float*)pcm)[idx];
+    if (width == -8) return (float)((const double*)pcm)[idx];
     if (width == 2) return (float)((const short*)pcm)[idx] * (1.0f / 32768.0f);
     if (width == 4) return (float)((const int*)pcm)[idx] * (1.0f / 2147483648.0f);
     if (width == 1) return ((float)pcm[idx] - 128.0f) * (1.0f / 128.0f);
@@ -174,7 +177,9 @@ extern "C" int sylber_ingest(const void* pcm_dev, int32_t sample_width, int32_t 
                              int32_t normalize, float* wav_out_dev, void* workspace_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!pcm_dev || !wav_out_dev || !workspace_dev) { syl_set_error("sylber_ingest", "null pointer"); return 1; }
-    if (sample_width < 1 || sample_width > 4) { syl_set_error("sylber_ingest", "sample width must be 1..4 bytes (PCM)"); return 1; }
+    if (!((sample_width >= 1 && sample_width <= 4) || sample_width == -4 || sample_width == -8)) {
+        syl_set_error("sylber_ingest", "sample width must be 1..4 bytes (integer PCM) or -4 / -8 (IEEE float32 / float64)"); return 1;
+    }
     if (channels < 1 || channels > 65535 || frames_in < 1 || sr_in < 1) { syl_set_error("sylber_ingest", "bad channels / frames / rate"); return 1; }
     const unsigned char* pcm = (const unsigned char*)pcm_dev;
     double* part_sum = (double*)workspace_dev;

@@ -105,15 +105,24 @@ __device__ __forceinline__ void mean_rows3(const float* __restrict__ states, int
     dst[tid] = a0 / n; dst[tid + 256] = a1 / n; dst[tid + 512] = a2 / n;
 }
 
+// GS = false: all bookkeeping lives in LDS (dynamic, sized by T): the refinement loop is a chain of dependent reads of
+// the segment table, which from global memory cost an L2 round trip per step.  That fits T <= 3940 frames (78.8 s of
+// audio) in the 160 KiB of a CU.  GS = true (longer utterances; the reference's get_segment has no length limit): the
+// T-sized arrays move to a per-utterance slab of global scratch, only the two 768-float centroids and the counters
+// stay in LDS; same arithmetic, same order, same results -- a workgroup's own global writes are visible to all of its
+// waves after __syncthreads().
+template <bool GS>
 __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ hidden, int T, float norm_thr, float merge_thr,
                                                       int64_t* __restrict__ seg_out, int* __restrict__ nseg_out,
-                                                      float* __restrict__ feat_out) {
-    // all bookkeeping lives in LDS (dynamic, sized by T): the refinement loop is a chain of dependent
-    // reads of the segment table, which from global memory cost an L2 round trip per step
+                                                      float* __restrict__ feat_out, float* __restrict__ scratch, size_t scratch_stride) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     float* ca_s = lds_f;                       // [768]
     float* cb_s = ca_s + SEG_D;                // [768]
-    float* simp_s = cb_s + SEG_D;              // [T]
+    int* sh_i = (int*)(cb_s + SEG_D);          // [8]
+    float* tbase;
+    if constexpr (GS) tbase = scratch + (size_t)blockIdx.x * scratch_stride;
+    else tbase = cb_s + SEG_D + 8;
+    float* simp_s = tbase;                     // [T]
     float* simn_s = simp_s + T;                // [T]
     float* sweep_s = simn_s + T;               // [T]
     float* nsq = sweep_s + T;                  // [T] sqrt path norms (mask; 2-D cossim)
@@ -121,7 +130,6 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
     int* seg = (int*)(npw + T);                // [T+1][2]
     int* mid = seg + 2 * (T + 1);              // [T+1][2]
     int* merged = mid + 2 * (T + 1);           // [T+1]
-    int* sh_i = merged + (T + 1);              // [8]
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* states = hidden + (size_t)b * T * SEG_D;
 
@@ -271,19 +279,30 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
     }
 }
 
-static size_t segment_lds_bytes(int T) { return ((size_t)2 * SEG_D + 5 * (size_t)T + 5 * ((size_t)T + 1) + 8) * 4; }
+static size_t segment_tsized_floats(int T) { return 5 * (size_t)T + 5 * ((size_t)T + 1); }
+static size_t segment_lds_bytes(int T) { return ((size_t)2 * SEG_D + 8 + segment_tsized_floats(T)) * 4; }
+static size_t segment_slab_floats(int T) { return (segment_tsized_floats(T) + 63) & ~(size_t)63; }
 
-size_t segment_scratch_floats(int B, int T, int D) { (void)B; (void)T; (void)D; return 0; }   // everything lives in LDS
+// floats of global scratch launch_segment needs (0 while an utterance's bookkeeping fits the 160 KiB of LDS)
+size_t segment_scratch_floats(int B, int T, int D) {
+    (void)D;
+    return segment_lds_bytes(T) > 160 * 1024 ? (size_t)B * segment_slab_floats(T) : 0;
+}
 
 int launch_segment(const float* hidden, int B, int T, int D, float norm_thr, float merge_thr, int64_t* seg, int* nseg,
                    float* feat, float* scratch, hipStream_t s) {
-    (void)scratch;
     if (D != SEG_D) { syl_set_error("launch_segment", "feature dim must be 768"); return 1; }
+    if (T < 1) { syl_set_error("launch_segment", "T must be >= 1"); return 1; }
     const size_t lds = segment_lds_bytes(T);
-    if (T < 1 || lds > 160 * 1024) { syl_set_error("launch_segment", "T must be in [1, 3940] (160 KiB of LDS per utterance)"); return 1; }
-    static PerDeviceOnce once;                           // raise the limit to the full 160 KiB once per device
-    if (once.need()) HIP_TRY(hipFuncSetAttribute((const void*)segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(segment_kernel, dim3(B), dim3(256), lds, s, hidden, T, norm_thr, merge_thr, seg, nseg, feat);
+    if (lds <= 160 * 1024) {
+        static PerDeviceOnce once;                       // raise the limit to the full 160 KiB once per device
+        if (once.need()) HIP_TRY(hipFuncSetAttribute((const void*)segment_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(segment_kernel<false>, dim3(B), dim3(256), lds, s, hidden, T, norm_thr, merge_thr, seg, nseg, feat, nullptr, (size_t)0);
+    } else {
+        if (!scratch) { syl_set_error("launch_segment", "utterances beyond 3940 frames need the global scratch slab"); return 1; }
+        hipLaunchKernelGGL(segment_kernel<true>, dim3(B), dim3(256), (2 * SEG_D + 8) * 4, s, hidden, T, norm_thr, merge_thr, seg, nseg, feat,
+                           scratch, segment_slab_floats(T));
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -113,14 +113,24 @@ class SegmentConditioner:
             self.handle = None
 
     def __call__(self, hidden: torch.Tensor, seg: torch.Tensor, nseg: torch.Tensor, feats: torch.Tensor, normthreshold: float,
-                 max_segments: Optional[int] = None):
+                 max_segments: Optional[int] = None, quantizer: Optional["KMQuantizer"] = None):
         """hidden ``[B,T,768]``, (seg, nseg, feats) as returned by ``HubertEncoderHIP.segment`` -> ``(input [B,T,out],
-        averaged_target_hidden_states [B,T,768])`` — the tensors named so at segment_synthesis.py:115,138-139."""
+        averaged_target_hidden_states [B,T,768])`` — the tensors named so at segment_synthesis.py:115,138-139.
+        ``quantizer``: the optional substitution inside the averaging loop (segment_synthesis.py:121-125): every segment
+        mean is replaced by its nearest codebook entry (``get_indices`` -> ``get_output_from_indices``) before it is
+        broadcast to its frames and fed to the MLP."""
         B, T, D = hidden.shape
         if D != self.input_dim:
             raise ValueError("hidden dim %d != MLP input dim %d" % (D, self.input_dim))
         S = int(max_segments) if max_segments is not None else max(1, int(nseg.max().item()))
         S = min(max(S, 1), T)
+        if quantizer is not None:
+            # only the first S slots per utterance are ever read; slots beyond an utterance's own count are ignored by
+            # sylber_condition, so they may hold anything (NaN rows of unused slots map to index 0 and stay unused)
+            head = torch.nan_to_num(feats[:, :S].contiguous())
+            q = quantizer.decode(quantizer.get_indices(head))
+            feats = feats.clone()
+            feats[:, :S] = q
         cond = torch.empty(B, T, self.output_dim, dtype=torch.float32, device=self.device)
         avg = torch.empty(B, T, D, dtype=torch.float32, device=self.device)
         ws = torch.empty(int(self.lib.sylber_condition_workspace_floats(self.handle, B, S)), dtype=torch.float32, device=self.device)
@@ -129,3 +139,19 @@ class SegmentConditioner:
                                                  ctypes.c_float(float(np.float32(normthreshold))), _vp(avg), _vp(cond), _vp(ws),
                                                  _stream(self.device)), "sylber_condition")
         return cond, avg
+
+    def from_features(self, features: torch.Tensor) -> torch.Tensor:
+        """the ``features is not None`` branch of ``resynthesize`` (segment_synthesis.py:135-140): ``features [B,T,768]``
+        (already averaged / decoded by the caller) -> ``input [B,T,out]`` = MLP(features) with the frames whose
+        ``((features**2).sum(-1))**.5 < 1e-4`` zeroed (threshold and missing 1e-8 exactly as the reference)."""
+        lead = tuple(features.shape[:-1])
+        x = features.reshape(-1, features.shape[-1]).to(self.device, torch.float32).contiguous()
+        if x.shape[1] != self.input_dim:
+            raise ValueError("feature dim %d != MLP input dim %d" % (x.shape[1], self.input_dim))
+        rows = x.shape[0]
+        cond = torch.empty(rows, self.output_dim, dtype=torch.float32, device=self.device)
+        ws = torch.empty(int(self.lib.sylber_condition_workspace_floats(self.handle, rows, 1)), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sylber_condition_features(self.handle, _vp(x), rows, _vp(cond), _vp(ws), _stream(self.device)),
+                       "sylber_condition_features")
+        return cond.reshape(lead + (self.output_dim,))

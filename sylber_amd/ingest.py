@@ -5,7 +5,7 @@ are in csrc/ingest.hip behind ``sylber_ingest`` of include/sylber_hip.h."""
 from __future__ import annotations
 
 import ctypes
-import wave as _wave
+import struct
 from typing import NamedTuple
 
 import numpy as np
@@ -18,21 +18,51 @@ class PcmFile(NamedTuple):
     data: np.ndarray      # uint8, the raw little-endian interleaved data chunk
     sample_rate: int
     channels: int
-    sample_width: int     # bytes per sample (1 = unsigned, 2/3/4 = signed)
+    sample_width: int     # bytes per sample (1 = unsigned, 2/3/4 = signed); -4 / -8 = IEEE float32 / float64
     frames: int
 
 
 def read_pcm(path: str) -> PcmFile:
-    """Header parse + one read of the data chunk (stdlib ``wave``: integer PCM only); no sample arithmetic."""
-    with _wave.open(str(path), "rb") as w:
-        sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
-        raw = w.readframes(n)
-    if width not in (1, 2, 3, 4):
-        raise ValueError("unsupported sample width %d" % width)
-    n = len(raw) // (width * nch)            # a truncated file reports more frames than it holds
-    if n < 1:
+    """RIFF/WAVE header parse + one read of the data chunk; no sample arithmetic on the host.  Integer PCM
+    (WAVE_FORMAT_PCM, 8/16/24/32 bit), IEEE float (WAVE_FORMAT_IEEE_FLOAT, 32/64 bit) and WAVE_FORMAT_EXTENSIBLE
+    wrappers of either -- what ``torchaudio.load`` reads from a ``.wav`` (sylber.py:83).  Compressed containers
+    (flac / mp3 / ogg, which torchaudio decodes through ffmpeg / sox) are NOT supported: ValueError."""
+    with open(str(path), "rb") as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise ValueError("%s is not a RIFF/WAVE file (compressed containers are not supported)" % path)
+        fmt = None
+        raw = None
+        while True:
+            ch = f.read(8)
+            if len(ch) < 8:
+                break
+            cid, size = ch[:4], struct.unpack("<I", ch[4:])[0]
+            if cid == b"fmt ":
+                fmt = f.read(size)
+            elif cid == b"data":
+                raw = f.read(size)                       # a truncated file simply yields fewer bytes
+                break
+            else:
+                f.seek(size, 1)
+            if size & 1:
+                f.seek(1, 1)                             # chunks are word aligned
+    if fmt is None or raw is None or len(fmt) < 16:
+        raise ValueError("%s has no fmt / data chunk" % path)
+    tag, nch, sr, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:                 # WAVE_FORMAT_EXTENSIBLE: the real tag opens the SubFormat GUID
+        tag = struct.unpack("<H", fmt[24:26])[0]
+    if tag == 1 and bits in (8, 16, 24, 32):
+        width = bits // 8
+    elif tag == 3 and bits in (32, 64):
+        width = -(bits // 8)                             # negative = IEEE float (include/sylber_hip.h)
+    else:
+        raise ValueError("%s: unsupported WAVE format tag %d with %d bits per sample" % (path, tag, bits))
+    bps = abs(width) * nch
+    n = len(raw) // bps
+    if n < 1 or nch < 1:
         raise ValueError("%s holds no audio frames" % path)
-    return PcmFile(np.frombuffer(raw, dtype=np.uint8, count=n * width * nch).copy(), int(sr), int(nch), int(width), int(n))
+    return PcmFile(np.frombuffer(raw, dtype=np.uint8, count=n * bps).copy(), int(sr), int(nch), int(width), int(n))
 
 
 def num_frames_16k(frames: int, sample_rate: int) -> int:

@@ -77,3 +77,47 @@ def test_resynth_front_end_to_end():
     # a smaller segment-slot budget than frames gives the same answer
     inp2, _ = cond(hd, seg, nseg, feats, normthreshold=2.6, max_segments=int(nseg.max()) + 3)
     assert torch.equal(inp, inp2)
+
+
+def test_resynth_front_features_branch():
+    """segment_synthesis.py:135-139: caller-supplied frame features; silent = norm WITHOUT the 1e-8 below 1e-4, so an
+    all-zero frame IS masked here (the hidden-state branch, with its 1e-8, would keep it)"""
+    from sylber_amd.downstream import SegmentConditioner
+    msd = synthetic_mlp_state_dict(2)
+    cond = SegmentConditioner(msd)
+    g = torch.Generator().manual_seed(5)
+    f = torch.randn(2, 37, 768, generator=g)
+    f[0, 3] = 0.0                                                # silent frame
+    f[1, 10] = 5e-6                                              # norm 1.4e-4: just above the threshold
+    f[1, 11] = 3e-6                                              # norm 8.3e-5: below
+    got = cond.from_features(f.cuda()).cpu().numpy()
+    exp = R.resynth_front_features(msd, f).numpy()
+    assert got.shape == exp.shape == (2, 37, 256)
+    assert np.array_equal(got == 0.0, exp == 0.0)
+    assert (got[0, 3] == 0).all() and (got[1, 11] == 0).all() and (got[1, 10] != 0).any()
+    assert np.abs(got - exp).max() <= 2e-4 * np.abs(exp).max()
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_resynth_front_with_quantizer_hook(normalize):
+    """segment_synthesis.py:121-125: segment means replaced by their nearest codebook entry before the broadcast"""
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.downstream import KMQuantizer, SegmentConditioner
+    msd = synthetic_mlp_state_dict(1)
+    enc = HubertEncoderHIP(synthetic_state_dict(0, num_layers=1), num_layers=1)
+    cond = SegmentConditioner(msd)
+    h = np.stack([syllable_states(150, 13), syllable_states(150, 14)])
+    rng = np.random.default_rng(3)
+    cent = (rng.standard_normal((500, 768)) * (0.25 if not normalize else 6.0 / np.sqrt(768))).astype(np.float32)
+    hd = torch.from_numpy(h).cuda()
+    seg, nseg, feats = enc.segment(hd, 2.6, 0.8)
+    q = KMQuantizer(cent, normalize=normalize)
+    inp, avg = cond(hd, seg, nseg, feats, normthreshold=2.6, quantizer=q)
+    exp_inp, exp_avg, _ = R.resynth_front(msd, torch.from_numpy(h), 2.6, 0.8, centroids=cent, normalize=normalize)
+    got_avg, e_avg = avg.cpu().numpy(), exp_avg.numpy()
+    # every frame carries either zeros or one codebook row; the rows agree with the float64 nearest-centroid oracle
+    # except on numerical ties (none expected with 500 random centroids)
+    assert np.array_equal(got_avg, e_avg)
+    got, exp = inp.cpu().numpy(), exp_inp.numpy()
+    assert np.array_equal(got == 0.0, exp == 0.0)
+    assert np.abs(got - exp).max() <= 2e-4 * np.abs(exp).max()

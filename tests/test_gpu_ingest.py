@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def _pcm(raw, sr, ch, width):
     from sylber_amd.ingest import PcmFile
     raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
-    return PcmFile(raw, sr, ch, width, raw.size // (ch * width))
+    return PcmFile(raw, sr, ch, width, raw.size // (ch * abs(width)))
 
 
 def _signal(n, ch, seed):
@@ -26,12 +26,17 @@ def _signal(n, ch, seed):
 
 
 @pytest.mark.parametrize("sr,ch,width", [(16000, 1, 2), (16000, 2, 1), (8000, 1, 2), (22050, 2, 2), (44100, 1, 2),
-                                         (48000, 2, 4), (11025, 1, 3), (32000, 1, 1), (44100, 1, 3)])
+                                         (48000, 2, 4), (11025, 1, 3), (32000, 1, 1), (44100, 1, 3),
+                                         (16000, 1, -4), (44100, 2, -4), (48000, 1, -8)])
 def test_ingest_matches_oracle(sr, ch, width):
     from sylber_amd.ingest import ingest_pcm, num_frames_16k
     n = 3000 if sr != 16000 else 5000
     x = _signal(n, ch, sr + ch)
-    if width == 2:
+    if width == -4:
+        raw = x.astype("<f4")                                     # WAVE_FORMAT_IEEE_FLOAT
+    elif width == -8:
+        raw = x.astype("<f8")
+    elif width == 2:
         raw = np.round(x * 32767).astype("<i2")
     elif width == 4:
         raw = np.round(x * (2 ** 31 - 1)).astype("<i4")
@@ -98,3 +103,32 @@ def test_segmenter_accepts_non_16k_files(tmp_path):
     assert np.isfinite(b[0]["hidden_states"]).all()
     # the batch row of the 16 kHz file reproduces the single-file call (same length => no padding difference)
     assert np.array_equal(a["segments"], b[1]["segments"])
+
+
+def test_float_and_extensible_wav_headers(tmp_path):
+    """read_pcm parses WAVE_FORMAT_IEEE_FLOAT and WAVE_FORMAT_EXTENSIBLE headers (torchaudio.load reads both); a
+    non-RIFF file is refused with a clear error"""
+    import struct
+    from sylber_amd.ingest import ingest_file, read_pcm
+    x = _signal(4000, 1, 5).astype("<f4")
+
+    def riff(fmt, data):
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"LIST" + struct.pack("<I", 3) + b"abc\0" + b"data" + struct.pack("<I", len(data)) + data
+        return b"RIFF" + struct.pack("<I", len(body)) + body
+
+    p1 = tmp_path / "f32.wav"
+    p1.write_bytes(riff(struct.pack("<HHIIHH", 3, 1, 16000, 16000 * 4, 4, 32), x.tobytes()))
+    pcm = read_pcm(str(p1))
+    assert (pcm.sample_rate, pcm.channels, pcm.sample_width, pcm.frames) == (16000, 1, -4, 4000)
+    got = ingest_file(str(p1), "cuda:0", normalize=False).cpu().numpy()
+    assert np.array_equal(got[0], x[:, 0])
+    sub = struct.pack("<H", 1) + bytes.fromhex("000000001000800000aa00389b71")
+    i16 = np.round(x * 32767).astype("<i2")
+    p2 = tmp_path / "ext.wav"
+    p2.write_bytes(riff(struct.pack("<HHIIHH", 0xFFFE, 1, 16000, 32000, 2, 16) + struct.pack("<HHI", 22, 16, 4) + sub, i16.tobytes()))
+    pcm2 = read_pcm(str(p2))
+    assert (pcm2.sample_width, pcm2.frames) == (2, 4000)
+    p3 = tmp_path / "x.flac"
+    p3.write_bytes(b"fLaC" + b"\0" * 64)
+    with pytest.raises(ValueError):
+        read_pcm(str(p3))

@@ -79,3 +79,16 @@ def test_properties_full_size(enc):
         for a, b in s:
             covered[a:b] = True
         assert np.array_equal(covered, norms >= np.float32(2.6))
+
+
+def test_long_utterance_global_scratch_path(enc):
+    """T > 3940 frames (78.8 s): the bookkeeping moves from LDS to a global slab; same results, bit for bit
+    (the reference's get_segment has no length limit, segment_utils.py:72)."""
+    for T, mode, seed0 in [(3941, "long", 900), (6000, "normal", 910), (4500, "edge", 920)]:
+        sts = [syllable_states(T, seed0 + s, mode=mode) for s in range(3)]
+        seg, nseg, feats = _run(enc, sts, 2.6, 0.8)
+        for j, st in enumerate(sts):
+            exp = segment_oracle.get_segment(st, 2.6, 0.8).reshape(-1, 2)
+            assert nseg[j] == len(exp) and np.array_equal(seg[j, :nseg[j]], exp), (T, mode, j)
+            if len(exp):
+                assert np.array_equal(feats[j, :nseg[j]], segment_oracle.mean_pool(st, exp), equal_nan=True)

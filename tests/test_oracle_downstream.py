@@ -50,3 +50,24 @@ def test_resynth_front_semantics():
             covered[s:e] = True
             assert np.allclose(avg[b, s:e].numpy(), h[b, s:e].mean(0).numpy()[None], atol=1e-6)
         assert np.all(avg[b].numpy()[~covered] == 0.0)
+
+
+def test_km_indices_independent_cross_check_cdist():
+    """vector_quantize_pytorch is absent (N4 parity stays UNPINNED); EuclideanCodebook quantises with
+    ``dist = -torch.cdist(x, embed); embed_ind = dist.argmax(-1)`` -- evaluated here with torch.cdist itself and compared
+    with the oracle's float64 arg-min: identical indices except on numerical ties"""
+    import torch
+    from oracle import downstream_ref as R
+    rng = np.random.default_rng(4)
+    c = rng.standard_normal((2000, 768)).astype(np.float32)
+    x = (c[rng.integers(0, 2000, 400)] + 0.8 * rng.standard_normal((400, 768))).astype(np.float32)
+    for normalize in (False, True):
+        xi = x
+        if normalize:
+            xi = x / np.sqrt((x ** 2).sum(-1) + np.float32(1e-8))[:, None] * np.float32(6)
+        ref = (-torch.cdist(torch.from_numpy(xi)[None], torch.from_numpy(c)[None]))[0].argmax(-1).numpy()
+        got, d2 = R.km_indices(x, c, normalize)
+        diff = np.nonzero(ref != got)[0]
+        for r in diff:
+            assert abs(d2[r, ref[r]] - d2[r, got[r]]) <= 1e-4 * abs(d2[r, got[r]])
+        assert len(diff) <= 2

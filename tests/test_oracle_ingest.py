@@ -83,3 +83,26 @@ def test_read_pcm_header_only(tmp_path):
     pcm = read_pcm(p)
     assert (pcm.sample_rate, pcm.channels, pcm.sample_width, pcm.frames) == (22050, 2, 2, 100)
     assert np.array_equal(pcm.data.view("<i2"), data)
+
+
+def test_resampler_independent_cross_check_scipy():
+    """torchaudio is absent (resampler parity stays UNPINNED); as an independent check of the restated algorithm the
+    oracle's 44.1 kHz -> 16 kHz and 48 kHz -> 16 kHz outputs are compared with scipy.signal.resample_poly (a different
+    polyphase low-pass design) on band-limited material: the two agree in the interior to well below the -40 dB that
+    any filter-shape difference in the transition band could explain, the sample count is ceil(16000 N / sr), and a
+    16 kHz input passes through unchanged."""
+    from scipy.signal import resample_poly
+    rng = np.random.default_rng(1)
+    for sr, up, down in [(44100, 160, 441), (48000, 1, 3), (22050, 320, 441)]:
+        n = sr // 2
+        t = np.arange(n) / sr
+        x = sum(a * np.sin(2 * np.pi * f * t + p) for a, f, p in
+                zip(rng.uniform(0.2, 1.0, 6), rng.uniform(80.0, 5500.0, 6), rng.uniform(0, 6.28, 6))).astype(np.float32)
+        y = R.resample_to_16k(x[None], sr)[0]
+        assert y.shape[0] == -(-16000 * n // sr)
+        z = resample_poly(x.astype(np.float64), up, down)[: y.shape[0]]
+        core = slice(200, y.shape[0] - 200)
+        err = np.sqrt(((y[core] - z[core]) ** 2).mean() / (z[core] ** 2).mean())
+        assert err < 5e-3, (sr, err)
+    same = rng.standard_normal(4000).astype(np.float32)
+    assert np.array_equal(R.resample_to_16k(same[None], 16000)[0], same)
