@@ -37,7 +37,10 @@ typedef struct sylber_ctx* sylber_t;
 /* SYLBER_FP8 (BASELINE.json configs[4]): as SYLBER_BF16, but the four projection GEMMs around the attention (q/k/v, out) and the two FFN
  * GEMMs of every encoder layer (all of the encoder's weight GEMMs) run on OCP microscaling FP8 operands (e4m3 elements, one E8M0 power-of-two scale per 32 elements along K) through the
  * block-scaled gfx950 MFMA, fp32 accumulation; tolerance vs the bf16 mode is stated in tests/test_gpu_fp8.py */
-enum { SYLBER_BF16 = 0, SYLBER_FP32 = 1, SYLBER_FP8 = 2 };
+/* SYLBER_FP16: exactly the SYLBER_BF16 path (same kernels, same matrix-pipe rate) with IEEE half as the 16-bit operand /
+ * activation format: 10 instead of 7 mantissa bits at every hand-over, conversions saturate at +-65504 (measured agreement
+ * with the fp32 reference: DESIGN.md) */
+enum { SYLBER_BF16 = 0, SYLBER_FP32 = 1, SYLBER_FP8 = 2, SYLBER_FP16 = 3 };
 
 /* HOST pointers to fp32 weights in the layout of HubertModel.state_dict().
  * Replaces the state_dict hand-over at sylber.py:51-54. */

@@ -67,6 +67,7 @@ struct GraphEntry { int B, Lmax, stop_stage; const void* in; void* out; hipGraph
 
 struct sylber_ctx {
     int device = 0, precision = 0, num_layers = 9;
+    int fmt = FMT_BF16;           // 16-bit operand format of the MFMA path
     // weights
     char* wbase = nullptr; size_t wbytes = 0;
     char* f8base = nullptr; size_t f8bytes = 0;
@@ -97,10 +98,12 @@ struct Packer {
     std::vector<char> host;
     size_t add(size_t bytes) { size_t off = (host.size() + 255) & ~(size_t)255; host.resize(off + bytes); return off; }
     size_t add_f32(const float* src, size_t n) { size_t o = add(n * 4); memcpy(host.data() + o, src, n * 4); return o; }
+    int fmt = FMT_BF16;           // 16-bit format of the MFMA operands (FMT_F16 for SYLBER_FP16)
     size_t add_bf16(const float* src, size_t n) {
         size_t o = add(n * 2);
         bf16_t* d = (bf16_t*)(host.data() + o);
-        for (size_t i = 0; i < n; ++i) d[i] = f2bf(src[i]);
+        if (fmt == FMT_F16) for (size_t i = 0; i < n; ++i) d[i] = f2h_host(src[i]);
+        else for (size_t i = 0; i < n; ++i) d[i] = f2bf(src[i]);
         return o;
     }
 };
@@ -108,12 +111,14 @@ struct Packer {
 extern "C" int sylber_create(const SylberWeights* w, int device, int precision, sylber_t* out) {
     if (!w || !out) { syl_set_error("sylber_create", "null argument"); return 1; }
     if (w->num_layers < 1 || w->num_layers > SYLBER_MAX_LAYERS) { syl_set_error("sylber_create", "num_layers out of range"); return 1; }
-    if (precision != SYLBER_BF16 && precision != SYLBER_FP32 && precision != SYLBER_FP8) { syl_set_error("sylber_create", "unknown precision"); return 1; }
+    if (precision != SYLBER_BF16 && precision != SYLBER_FP32 && precision != SYLBER_FP8 && precision != SYLBER_FP16) { syl_set_error("sylber_create", "unknown precision"); return 1; }
     const bool f32 = precision == SYLBER_FP32;
     GUARD_DEVICE(device);
     sylber_ctx* c = new sylber_ctx();
     c->device = device; c->precision = precision; c->num_layers = w->num_layers;
+    c->fmt = precision == SYLBER_FP16 ? FMT_F16 : FMT_BF16;
     Packer P;
+    P.fmt = c->fmt;
     size_t o_conv0 = P.add_f32(w->conv_w[0], 512 * 10);
     size_t o_gnw = P.add_f32(w->gn_w, 512), o_gnb = P.add_f32(w->gn_b, 512);
     size_t o_conv[7] = {0};
@@ -431,36 +436,36 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     // ---- conv layer 0 + GroupNorm + GELU
     RUN("conv0_stats", launch_conv0_stats(wav_dev, B, Lmax, p.L[0], part, p.nchunk, s));
     RUN("conv0_finalize", launch_conv0_finalize(part, p.nchunk, c->conv0_w, c->gn_w, c->gn_b, B, p.L[0], ss, s));
-    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s));
+    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s, c->fmt));
     // ---- conv layers 1..6 as implicit GEMM (ping-pong)
     bf16_t* src = bufA; bf16_t* dst = bufB;
     for (int i = 1; i < 7; ++i) {
         GemmArgs a = {};
         a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w[i];
         a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = ACT_GELU_FAST;
-        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist;
+        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.fmt = c->fmt;
         static const char* nm[7] = {"", "gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_conv6"};
         RUN(nm[i], launch_gemm_bf16(EPI_BF16, a, s));
         bf16_t* t = src; src = dst; dst = t;
     }
     bf16_t* feats = src;   // [B*Tp][512]
     if (c->stop_stage == 1) {
-        RUN("copy_out", launch_bf16_to_f32_rows(feats, 512, hidden_dev, B, p.Tp, p.T, 512, s));
+        RUN("copy_out", launch_bf16_to_f32_rows(feats, 512, hidden_dev, B, p.Tp, p.T, 512, s, c->fmt));
         return 0;
     }
     // ---- feature projection: LN(512) -> Linear(512->768), zero padded frames
     {
         LnArgs a = {};
         a.in = feats; a.in_bf16 = 1; a.ld_in = 512; a.gamma = c->fp_ln_w; a.beta = c->fp_ln_b;
-        a.out_bf16 = ln512; a.ld_bf16 = 512; a.M = M; a.D = 512;
+        a.out_bf16 = ln512; a.ld_bf16 = 512; a.M = M; a.D = 512; a.fmt = c->fmt;
         RUN("ln512", launch_layernorm(a, s));
         GemmArgs g = {};
         g.X = ln512; g.ldx = 512; g.W = c->fp_w; g.M = M; g.N = 768; g.K = 512; g.bias = c->fp_b;
-        g.out0 = xf32; g.ld0 = 768; g.out1 = xpad; g.Tp = p.Tp; g.T = p.T; g.valid = valid; g.xpad_rows = p.Tp + 128;
+        g.out0 = xf32; g.ld0 = 768; g.out1 = xpad; g.Tp = p.Tp; g.T = p.T; g.valid = valid; g.xpad_rows = p.Tp + 128; g.fmt = c->fmt;
         RUN("gemm_proj", launch_gemm_bf16(EPI_PROJ, g, s));
     }
     // ---- positional conv + residual, encoder LayerNorm
-    RUN("posconv", launch_posconv(xpad, c->pos_w, c->pos_b, xf32, pre, B, p.Tp, 1, s));
+    RUN("posconv", launch_posconv(xpad, c->pos_w, c->pos_b, xf32, pre, B, p.Tp, 1, s, c->fmt));
     // SYLBER_FP8: the FFN runs on MXFP8 operands; the LayerNorm in front of it then emits e4m3 + E8M0 block scales
     // instead of bf16 (into the same buffer), and FFN1 leaves its GELU output as MXFP8 for FFN2
     const bool f8 = c->precision == SYLBER_FP8;
@@ -470,7 +475,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     uint8_t* ffn8 = (uint8_t*)ffn; uint8_t* ffn8s = ffn8 + (((size_t)M * 3072 + 255) & ~(size_t)255);  // 96 Mp bytes
     auto run_ln = [&](const float* gam, const float* bet, bool last, bool to_fp8 = false) -> int {
         LnArgs a = {};
-        a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = M; a.D = 768;
+        a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = M; a.D = 768; a.fmt = c->fmt;
         if (last) { a.out_f32 = hidden_dev; a.ld_f32 = 768; a.Tp = p.Tp; a.T = p.T; }
         else if (to_fp8) { a.out_fp8 = h8; a.ld_fp8 = 768; a.out_scale = h8s; a.scale_rows = Mp; a.out_stats = stats; }
         else { a.out_bf16 = hbf; a.ld_bf16 = 768; a.out_stats = stats; }   // no fp32 copy: see EPI_F32_RESLN
@@ -496,7 +501,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             GemmArgs g = {};
             g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 2304; g.K = 768; g.bias = d.bqkv;
             g.out0 = q; g.out1 = k; g.out2 = vt; g.Tp = p.Tp; g.Tpv = p.Tpv; g.T = p.T;
-            g.tune_cfg = c->opt_gemm_cfg; g.tune_persist = c->opt_gemm_persist;
+            g.tune_cfg = c->opt_gemm_cfg; g.tune_persist = c->opt_gemm_persist; g.fmt = c->fmt;
             RUN("gemm_qkv", launch_gemm_bf16(EPI_QK, g, s));
         }
         if (f8) {
@@ -507,11 +512,11 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             o.X8 = ctx8; o.ldx8 = 768; o.XS = ctx8s; o.xs_rows = Mp; o.W8 = d.woq; o.WS = d.wos; o.ws_rows = 768;
             RUN("gemm_out", launch_gemm_mxfp8(EPI_F32_RESLN, o, s));
         } else {
-        RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, c->opt_attn_qw, s));
+        RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, c->opt_attn_qw, s, c->fmt));
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
         o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
-        o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist;
+        o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist; o.fmt = c->fmt;
         RUN("gemm_out", launch_gemm_bf16(EPI_F32_RESLN, o, s));
         }
         RUN("layernorm", run_ln(d.ln1w, d.ln1b, false, f8));
@@ -528,12 +533,12 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         } else {
         GemmArgs f1 = {};
         f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = 1;
-        f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist;
+        f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist; f1.fmt = c->fmt;
         RUN("gemm_ffn1", launch_gemm_bf16(EPI_BF16, f1, s));
         GemmArgs f2 = {};
         f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
         f2.out0 = pre; f2.ld0 = 768; f2.res = pre; f2.ldres = 768; f2.ln_stats = stats; f2.ln_gamma = d.ln1w; f2.ln_beta = d.ln1b;
-        f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist;
+        f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist; f2.fmt = c->fmt;
         RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RESLN, f2, s));
         }
         RUN("layernorm", run_ln(d.ln2w, d.ln2b, last, f8));

@@ -30,7 +30,7 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 // QW = 32-query sub-tiles per wave.  QW = 2 halves the LDS fragment reads and the LDS-DMA instructions per
 // MFMA (every K / V^T fragment feeds two MFMAs); the DMA issue is the most expensive instruction of the loop
 // (profiles/r01_mfma_ceiling.md).
-template <int QW, bool F8 = false>
+template <int QW, bool F8 = false, int FMT = FMT_BF16>
 __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                 const bf16_t* __restrict__ Vt, const int* __restrict__ valid,
                                                                 bf16_t* __restrict__ ctx, int T, int Tp, int Tpv,
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
                 const bf16x8_t kf = *(const bf16x8_t*)(kb + s2 * 32 * 128 + frow + (((2 * ks + h) ^ swz) << 4));
 #pragma unroll
                 for (int qs = 0; qs < QW; ++qs)
-                    sacc[qs][s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qs][ks], sacc[qs][s2], 0, 0, 0);
+                    sacc[qs][s2] = H16<FMT>::mfma(kf, qf[qs][ks], sacc[qs][s2]);
             }
         // ---- mask + online softmax (lane-local; partner lane^32 holds the other 32 keys of this query)
         const bool tail = kv0 + AT_KV > nvalid;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
                     for (int e = 0; e < 8; ++e) {
                         const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qs][s2][8 * j + e], LOG2E, -mb));
                         psum += p;
-                        pf[qs][2 * s2 + j][e] = (__bf16)p;
+                        pf[qs][2 * s2 + j][e] = __builtin_bit_cast(__bf16, H16<FMT>::cvt(p));
                     }
             l_run[qs] = fmaf(l_run[qs], alpha, psum);
             m_run[qs] = m_new;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
                 const bf16x8_t vf = *(const bf16x8_t*)(vb + ds * 32 * 128 + frow + (((2 * u + h) ^ swz) << 4));
 #pragma unroll
                 for (int qs = 0; qs < QW; ++qs)
-                    oacc[qs][ds] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qs][u], oacc[qs][ds], 0, 0, 0);
+                    oacc[qs][ds] = H16<FMT>::mfma(vf, pf[qs][u], oacc[qs][ds]);
             }
     }
     // ---- finalize: 1/l, store ctx[b*Tp + q][head*64 + d]
@@ -228,10 +228,10 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     uint2 ra, rb;
-                    ra.x = pack_bf16x2(oacc[qs][ds][8 * pr + 0] * inv, oacc[qs][ds][8 * pr + 1] * inv);
-                    ra.y = pack_bf16x2(oacc[qs][ds][8 * pr + 2] * inv, oacc[qs][ds][8 * pr + 3] * inv);
-                    rb.x = pack_bf16x2(oacc[qs][ds][8 * pr + 4] * inv, oacc[qs][ds][8 * pr + 5] * inv);
-                    rb.y = pack_bf16x2(oacc[qs][ds][8 * pr + 6] * inv, oacc[qs][ds][8 * pr + 7] * inv);
+                    ra.x = H16<FMT>::pack2(oacc[qs][ds][8 * pr + 0] * inv, oacc[qs][ds][8 * pr + 1] * inv);
+                    ra.y = H16<FMT>::pack2(oacc[qs][ds][8 * pr + 2] * inv, oacc[qs][ds][8 * pr + 3] * inv);
+                    rb.x = H16<FMT>::pack2(oacc[qs][ds][8 * pr + 4] * inv, oacc[qs][ds][8 * pr + 5] * inv);
+                    rb.y = H16<FMT>::pack2(oacc[qs][ds][8 * pr + 6] * inv, oacc[qs][ds][8 * pr + 7] * inv);
                     const uint2 keep = h ? rb : ra, send = h ? ra : rb;
                     uint2 got;
                     got.x = (unsigned)__shfl_xor((int)send.x, 32, 64); got.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
@@ -243,30 +243,34 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
 }
 
 static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, void* ctx, uint8_t* ctx_scale,
-                                long scale_rows, int B, int T, int Tp, int Tpv, int force_qw, hipStream_t s) {
+                                long scale_rows, int B, int T, int Tp, int Tpv, int force_qw, int fmt, hipStream_t s) {
     if (Tpv % 64 != 0 || Tpv < T) { syl_set_error("launch_attention", "Tpv must be a multiple of 64 and >= T"); return 1; }
     // 64 queries per wave when there are enough query blocks to fill the chip, else 32
     int qw = ((long)((T + 255) / 256) * SYL_HEADS * B >= 512) ? 2 : 1;
     if (force_qw == 1 || force_qw == 2) qw = force_qw;
     const dim3 grid((qw == 2 ? (T + 255) / 256 : (T + 127) / 128) * SYL_HEADS * B);
+    bf16_t* c = (bf16_t*)ctx;
     if (ctx_scale) {
-        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, ctx_scale, scale_rows);
-        else hipLaunchKernelGGL((attention_bf16_kernel<1, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, ctx_scale, scale_rows);
+        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, ctx_scale, scale_rows);
+        else hipLaunchKernelGGL((attention_bf16_kernel<1, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, ctx_scale, scale_rows);
+    } else if (fmt == FMT_F16) {
+        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, false, FMT_F16>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
+        else hipLaunchKernelGGL((attention_bf16_kernel<1, false, FMT_F16>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
     } else {
-        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, nullptr, 0L);
-        else hipLaunchKernelGGL((attention_bf16_kernel<1, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, (bf16_t*)ctx, T, Tp, Tpv, nullptr, 0L);
+        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
+        else hipLaunchKernelGGL((attention_bf16_kernel<1, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T, int Tp,
-                     int Tpv, int qw, hipStream_t s) {
-    return launch_attention_any(q, k, vt, valid, ctx, nullptr, 0, B, T, Tp, Tpv, qw, s);
+                     int Tpv, int qw, hipStream_t s, int fmt) {
+    return launch_attention_any(q, k, vt, valid, ctx, nullptr, 0, B, T, Tp, Tpv, qw, fmt, s);
 }
 
 // same attention, context written as MXFP8 ([B*Tp][768] e4m3 + K-pair-major E8M0 scales with row pitch scale_rows)
 int launch_attention_f8out(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, uint8_t* ctx8, uint8_t* ctx_scale,
                            long scale_rows, int B, int T, int Tp, int Tpv, int qw, hipStream_t s) {
-    return launch_attention_any(q, k, vt, valid, ctx8, ctx_scale, scale_rows, B, T, Tp, Tpv, qw, s);
+    return launch_attention_any(q, k, vt, valid, ctx8, ctx_scale, scale_rows, B, T, Tp, Tpv, qw, FMT_BF16, s);
 }

@@ -42,6 +42,58 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf_dev(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
+// ---- the 16-bit operand format of the MFMA path -------------------------------------------------------------------
+// FMT_BF16 (default, BASELINE configs[1]): 8 exponent / 7 mantissa bits.  FMT_F16 (precision "fp16"): IEEE half, 10
+// mantissa bits = 8x finer rounding of every activation / weight hand-over at the SAME matrix-pipe rate
+// (v_mfma_f32_32x32x16_f16); conversions saturate at +-65504 instead of overflowing to infinity.  Buffers hold raw 16-bit
+// words either way (bf16_t = unsigned short), so layouts, LDS images and LDS-DMA staging are identical.
+enum { FMT_BF16 = 0, FMT_F16 = 1 };
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <int FMT> struct H16 {
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    static __device__ __forceinline__ bf16_t cvt(float f) { return f2bf_dev(f); }
+    static __device__ __forceinline__ float up(bf16_t h) { return bf2f(h); }
+    static __device__ __forceinline__ f32x16_t mfma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct H16<FMT_F16> {
+    static __device__ __forceinline__ float sat(float f) { return __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f); }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        typedef float f32pair_t __attribute__((ext_vector_type(2)));
+        const f32pair_t v = {sat(lo), sat(hi)};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+    }
+    static __device__ __forceinline__ bf16_t cvt(float f) { return __builtin_bit_cast(unsigned short, (_Float16)sat(f)); }
+    static __device__ __forceinline__ float up(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+    static __device__ __forceinline__ f32x16_t mfma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+// host: float -> IEEE half, round to nearest even, saturating (weights packed at sylber_create)
+__host__ __forceinline__ bf16_t f2h_host(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    const uint32_t sign = (v.u >> 16) & 0x8000u;
+    uint32_t a = v.u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (bf16_t)(sign | 0x7e00u);                 // NaN
+    if (a >= 0x477ff000u) return (bf16_t)(sign | 0x7bffu);                // >= 65520 rounds beyond max: saturate at 65504
+    if (a < 0x38800000u) {                                                // subnormal half (or zero)
+        if (a < 0x33000000u) return (bf16_t)sign;
+        const int e = (int)(a >> 23);
+        const uint32_t m = (a & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;                                        // 14 .. 24
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (bf16_t)(sign | r);
+    }
+    a += 0xc8000000u;                                                     // rebias exponent 127 -> 15
+    a += 0xfffu + ((a >> 13) & 1u);
+    return (bf16_t)(sign | (a >> 13));
+}
+
+
 // ---- GELU --------------------------------------------------------------------------------------
 // exact erf form (reference: transformers activations "gelu" = 0.5 x (1 + erf(x / sqrt 2)))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

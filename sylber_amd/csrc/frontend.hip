@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) void conv0_finalize_kernel(const double* __res
 // grid (ceil(R0/256), B); wave w of a block produces rows l = 256*blockIdx.x + 64*w + i; lane owns 8 channels
 // (80 tap weights + scale/shift stay in registers across 64 rows).  The 1285 waveform samples a block needs are staged in LDS once (coalesced), then every row reads its 10
 // taps as LDS broadcasts instead of 10 wave-uniform global loads.
-template <bool OUT_F32, bool ERF>
+template <bool OUT_F32, bool ERF, int FMT>
 __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int Lmax, int L0, int R0,
                                                             const float* __restrict__ w0,
                                                             const float* __restrict__ scale_shift, void* __restrict__ out) {
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             // 1 GiB per 32 clips, consumed exactly once by conv1: stream it past the caches
             typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
             u32x4_t pk;
-            pk[0] = pack_bf16x2(y[0], y[1]); pk[1] = pack_bf16x2(y[2], y[3]);
-            pk[2] = pack_bf16x2(y[4], y[5]); pk[3] = pack_bf16x2(y[6], y[7]);
+            pk[0] = H16<FMT>::pack2(y[0], y[1]); pk[1] = H16<FMT>::pack2(y[2], y[3]);
+            pk[2] = H16<FMT>::pack2(y[4], y[5]); pk[3] = H16<FMT>::pack2(y[6], y[7]);
             __builtin_nontemporal_store(pk, (u32x4_t*)((bf16_t*)out + o));
         }
     }
@@ -168,19 +168,21 @@ int launch_conv0_finalize(const double* partials, int nchunk, const float* w0, c
     return 0;
 }
 int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, const float* w0, const float* scale_shift,
-                         void* out, int out_f32, hipStream_t s) {
+                         void* out, int out_f32, hipStream_t s, int fmt) {
     dim3 grid((R0 + C0_ROWS - 1) / C0_ROWS, B);
     if (out_f32)
-        hipLaunchKernelGGL((conv0_gn_gelu_kernel<true, true>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<true, true, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
+    else if (fmt == FMT_F16)
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_F16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
     else
-        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, D/64 values per lane in registers.
-template <int D, bool IN_BF16>
+template <int D, bool IN_BF16, int FMT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     constexpr int V = D / 256;   // float4 groups per lane (2 for 512, 3 for 768)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
         const int c = i * 256 + lane * 4;
         if constexpr (IN_BF16) {
             const uint2 raw = *(const uint2*)((const bf16_t*)a.in + (size_t)m * a.ld_in + c);
-            x[i][0] = bf2f((bf16_t)(raw.x & 0xffff)); x[i][1] = bf2f((bf16_t)(raw.x >> 16));
-            x[i][2] = bf2f((bf16_t)(raw.y & 0xffff)); x[i][3] = bf2f((bf16_t)(raw.y >> 16));
+            x[i][0] = H16<FMT>::up((bf16_t)(raw.x & 0xffff)); x[i][1] = H16<FMT>::up((bf16_t)(raw.x >> 16));
+            x[i][2] = H16<FMT>::up((bf16_t)(raw.y & 0xffff)); x[i][3] = H16<FMT>::up((bf16_t)(raw.y >> 16));
         } else {
             const float4 v = *(const float4*)((const float*)a.in + (size_t)m * a.ld_in + c);
             x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
         const float y3 = fmaf((x[i][3] - mean) * rstd, g.w, be.w);
         if (a.out_f32) *(float4*)(a.out_f32 + (size_t)orow * a.ld_f32 + c) = make_float4(y0, y1, y2, y3);
         if (a.out_bf16) {
-            uint2 pk; pk.x = pack_bf16x2(y0, y1); pk.y = pack_bf16x2(y2, y3);
+            uint2 pk; pk.x = H16<FMT>::pack2(y0, y1); pk.y = H16<FMT>::pack2(y2, y3);
             *(uint2*)(a.out_bf16 + (size_t)m * a.ld_bf16 + c) = pk;
         }
         if (a.out_fp8) {
@@ -250,12 +252,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     }
 }
 
+template <int FMT>
+static bool launch_ln_fmt(const LnArgs& a, dim3 grid, hipStream_t s) {
+    if (a.D == 768 && !a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<768, false, FMT>), grid, dim3(256), 0, s, a);
+    else if (a.D == 768 && a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<768, true, FMT>), grid, dim3(256), 0, s, a);
+    else if (a.D == 512 && !a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<512, false, FMT>), grid, dim3(256), 0, s, a);
+    else if (a.D == 512 && a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<512, true, FMT>), grid, dim3(256), 0, s, a);
+    else return false;
+    return true;
+}
+
 int launch_layernorm(const LnArgs& a, hipStream_t s) {
     dim3 grid((a.M + 3) / 4);
-    if (a.D == 768 && !a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<768, false>), grid, dim3(256), 0, s, a);
-    else if (a.D == 768 && a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<768, true>), grid, dim3(256), 0, s, a);
-    else if (a.D == 512 && !a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<512, false>), grid, dim3(256), 0, s, a);
-    else if (a.D == 512 && a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<512, true>), grid, dim3(256), 0, s, a);
+    if (a.fmt == FMT_F16 ? launch_ln_fmt<FMT_F16>(a, grid, s) : launch_ln_fmt<FMT_BF16>(a, grid, s)) {}
     else { syl_set_error("launch_layernorm", "D must be 512 or 768"); return 1; }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -280,14 +289,14 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
 
 // compacting copy bf16 [B][Tp][D] (row stride ld_in) -> f32 [B][T][D]
 __global__ __launch_bounds__(256) void bf16_rows_to_f32_kernel(const bf16_t* __restrict__ in, long ld_in, float* __restrict__ out,
-                                                               int Tp, int T, int D) {
+                                                               int Tp, int T, int D, int fmt) {
     const int b = blockIdx.y, t = blockIdx.x;
     const bf16_t* src = in + ((size_t)b * Tp + t) * ld_in;
     float* dst = out + ((size_t)b * T + t) * D;
-    for (int c = threadIdx.x; c < D; c += 256) dst[c] = bf2f(src[c]);
+    for (int c = threadIdx.x; c < D; c += 256) dst[c] = fmt == FMT_F16 ? H16<FMT_F16>::up(src[c]) : bf2f(src[c]);
 }
-int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s) {
-    hipLaunchKernelGGL(bf16_rows_to_f32_kernel, dim3(T, B), dim3(256), 0, s, in, ld_in, out, Tp, T, D);
+int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s, int fmt) {
+    hipLaunchKernelGGL(bf16_rows_to_f32_kernel, dim3(T, B), dim3(256), 0, s, in, ld_in, out, Tp, T, D, fmt);
     HIP_TRY(hipGetLastError());
     return 0;
 }

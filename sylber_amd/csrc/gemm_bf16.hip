@@ -34,7 +34,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int FM, int FN, int BK, int NSTAGE, bool PRIO, int EPI, int ACT>
+template <int FM, int FN, int BK, int NSTAGE, bool PRIO, int EPI, int ACT, int FMT>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile_id, char* smem) {
     constexpr int BM = 64 * FM, BN = 64 * FN;
     constexpr int RB = BK * 2;               // bytes per LDS row (128 or 64)
@@ -107,7 +107,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn) {
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][fn], xf[buf][fm], acc[fm][fn], 0, 0, 0);
+                acc[fm][fn] = H16<FMT>::mfma(wf[buf][fn], xf[buf][fm], acc[fm][fn]);
             }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
@@ -121,7 +121,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             const int fm = i / FN, fn = i % FN;
-            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][fn], xf[buf][fm], acc[fm][fn], 0, 0, 0);
+            acc[fm][fn] = H16<FMT>::mfma(wf[buf][fn], xf[buf][fm], acc[fm][fn]);
             // pieces are spread evenly: piece p0 + j goes after MFMA number ceil((j+1)*NM/np) - 1
 #pragma unroll
             for (int p = 0; p < NPW; ++p) {
@@ -194,9 +194,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
         static_assert(4 * StagedEpi<FN, EPI>::BYTES <= NSTAGE * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();                 // every wave is done reading operand tiles
         char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
-        epilogue_staged<FM, FN, EPI, ACT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
+        epilogue_staged<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
     } else {
-        epilogue_direct<FM, FN, EPI, ACT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
+        epilogue_direct<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
     }
 }
 
@@ -205,25 +205,25 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
 // in-flight batch (a different kernel, in a different phase) can take the second one: its K loop then runs
 // under this launch's HBM-bound epilogue and vice versa, instead of two workgroups of the SAME launch hitting
 // their epilogues together.
-template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT>
+template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT, int FMT>
 __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int BM = 64 * FM, BN = 64 * FN;
     const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        gemm_bf16_tile<FM, FN, BK, NSTAGE, PRIO, EPI, ACT>(a, tile, smem);
+        gemm_bf16_tile<FM, FN, BK, NSTAGE, PRIO, EPI, ACT, FMT>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) __builtin_amdgcn_s_barrier();   // LDS (operand ring / epilogue staging) is reused
     }
 }
 
-template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT>
+template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT, int FMT>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * FM, BN = 64 * FN;
     constexpr int LDS = NSTAGE * (BM + BN) * BK * 2;
     if (a.K % BK != 0) { syl_set_error("launch_gemm_bf16", "K must be a multiple of the K step"); return 1; }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static PerDeviceOnce attr_once;
-    auto kern = gemm_bf16_kernel<FM, FN, BK, NSTAGE, MINB, PRIO, EPI, ACT>;
+    auto kern = gemm_bf16_kernel<FM, FN, BK, NSTAGE, MINB, PRIO, EPI, ACT, FMT>;
     if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
@@ -245,7 +245,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 // Hazards: a step's DMA is retired (vmcnt) two program barriers before its first ds_read (one more than
 // usual because the groups are staggered); fragment reads complete (lgkmcnt(0)) before the barrier that
 // lets the other group refill that slot.
-template <int FM, int FN, int WM, int WN, int EPI, int ACT>
+template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT>
 __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int tile_id, char* smem) {
     // K step 32 (64-byte LDS rows), 4-slot ring: the DMA of step s+3 is issued in step s and retired with
     // counted vmcnt, never 0 in the steady state.  (A 2-slot ring of 64-wide stages measured 5-12 % slower.)
@@ -357,7 +357,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
 #pragma unroll
         for (int i = 0; i < NMF; ++i) {
             const int kk = i / (FM * FN), fm = (i / FN) % FM, fn = i % FN;
-            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][fn], xf[kk][fm], acc[fm][fn], 0, 0, 0);
+            acc[fm][fn] = H16<FMT>::mfma(wf[kk][fn], xf[kk][fm], acc[fm][fn]);
             // after MFMA number (q+1)*NMF/NPW_HI - 1 issue piece q
             if ((i + 1) % (NMF / NPW_HI) == 0) {
                 const int q = (i + 1) / (NMF / NPW_HI) - 1;
@@ -379,9 +379,9 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         static_assert(8 * StagedEpi<FN, EPI>::BYTES <= 4 * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();                 // every wave is done reading operand tiles
         char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
-        epilogue_staged<FM, FN, EPI, ACT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
+        epilogue_staged<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
     } else {
-        epilogue_direct<FM, FN, EPI, ACT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
+        epilogue_direct<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
     }
 }
 
@@ -390,13 +390,13 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
 // workgroup's tiles all map to its own XCD's chunk).  Measured with rocprofv3 PMC (profiles/r01_mfma_util.md): the
 // one-tile-per-workgroup launch keeps the matrix pipe busy only 41 % of its resident cycles although the K loop alone
 // is at 81 % — every tile boundary costs a workgroup dispatch on a CU that holds nothing else.
-template <int FM, int FN, int WM, int WN, int EPI, int ACT>
+template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT>
 __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        gemm8_bf16_tile<FM, FN, WM, WN, EPI, ACT>(a, tile, smem);
+        gemm8_bf16_tile<FM, FN, WM, WN, EPI, ACT, FMT>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) {
             // the ring is reused: this tile's epilogue staging reads and its stores' source data are done with LDS
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -405,13 +405,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     }
 }
 
-template <int FM, int FN, int WM, int WN, int EPI, int ACT>
+template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT>
 static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDS = 4 * (BM + BN) * 64;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static PerDeviceOnce attr_once;
-    auto kern = gemm8_bf16_kernel<FM, FN, WM, WN, EPI, ACT>;
+    auto kern = gemm8_bf16_kernel<FM, FN, WM, WN, EPI, ACT, FMT>;
     if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
@@ -428,8 +428,8 @@ static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
 //   cfg 10 256x256, 8 waves staggered, 1 WG/CU best for the big GEMMs (conv1-5, FFN1): +20-25 %
 // Two co-resident workgroups (cfg 3/4) cover each other's epilogue / barrier / DMA-issue time; the big
 // tile (cfg 10) instead halves the per-FLOP L1/TA traffic.  Cost = rounds x (tile area per CU) / eff.
-template <int EPI, int ACT>
-static int launch_t(const GemmArgs& a, hipStream_t s) {
+template <int EPI, int ACT, int FMT>
+static int launch_f(const GemmArgs& a, hipStream_t s) {
     struct Cfg { int id, bm, bn, per_cu; double eff; };
     const Cfg cfgs[3] = {{3, 128, 128, 2, 0.93}, {4, 128, 192, 2, 1.00}, {10, 256, 256, 1, 1.20}};
     int best = 0;
@@ -444,12 +444,19 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
     int cfg = cfgs[best].id;
     if (a.tune_cfg > 0) cfg = a.tune_cfg - 1;            // per-call override (sylber_set_option / parity tests)
     switch (cfg) {
-        case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
-        case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT>(a, s);   // 128x128, 2 WG/CU
-        case 10: return launch_cfg8<4, 2, 2, 4, EPI, ACT>(a, s);            // 256x256, 8 waves staggered
-        case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT>(a, s);            // 256x192, 8 waves staggered
-        default: return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT>(a, s);  // 128x192, 2 WG/CU
+        case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT, FMT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
+        case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);   // 128x128, 2 WG/CU
+        case 10: return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);            // 256x256, 8 waves staggered
+        case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
+        default: return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);  // 128x192, 2 WG/CU
     }
+}
+
+// operand format (GemmArgs::fmt): the fp16 instantiations exist for the epilogues the fp16 forward uses
+template <int EPI, int ACT>
+static int launch_t(const GemmArgs& a, hipStream_t s) {
+    if (a.fmt == FMT_F16) return launch_f<EPI, ACT, FMT_F16>(a, s);
+    return launch_f<EPI, ACT, FMT_BF16>(a, s);
 }
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s) {

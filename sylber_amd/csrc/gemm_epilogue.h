@@ -47,7 +47,7 @@ __device__ __forceinline__ void load_colvec(const float* __restrict__ p, int nco
 
 // Direct (register -> global) epilogue of a whole wave tile, FM x FN fragments: EPI_BF16 / EPI_F32 / EPI_F32_RES /
 // EPI_F32_RESLN.  A store instruction covers 32 rows x 32 bytes; loads of the residual likewise.
-template <int FM, int FN, int EPI, int ACT>
+template <int FM, int FN, int EPI, int ACT, int FMT = FMT_BF16>
 __device__ __forceinline__ void epilogue_direct(const GemmArgs& a, const f32x16_t (&acc)[FM][FN], int mrow0, int ncol0, int lane) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_F32_RES || EPI == EPI_F32_RESLN, "direct epilogue");
     const int ml = lane & 31, h = lane >> 5;
@@ -96,7 +96,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& a, const f32x16_
                 const size_t o = (size_t)mrow[fm] * a.ld0 + ncl[g];
                 if constexpr (EPI == EPI_BF16) {
                     apply_act4<ACT>(v0, v1, v2, v3);
-                    uint2 pk; pk.x = pack_bf16x2(v0, v1); pk.y = pack_bf16x2(v2, v3);
+                    uint2 pk; pk.x = H16<FMT>::pack2(v0, v1); pk.y = H16<FMT>::pack2(v2, v3);
                     if (ok) *(uint2*)((bf16_t*)a.out0 + o) = pk;
                 } else if constexpr (EPI == EPI_F32) {
                     apply_act4<ACT>(v0, v1, v2, v3);
@@ -139,7 +139,7 @@ struct StagedEpi {
 // contiguous (and bits 2/3 of the key index swapped, see attention.hip).  The wave transposes its 32 tokens x 32 FN
 // features through its private LDS region (ds_write_b16 at [feature][pos(token)], 64-byte rows) and stores 16-byte
 // chunks = 8 keys of one feature row; a 32-token block never straddles utterances because Tp % 32 == 0.
-template <int FN>
+template <int FN, int FMT = FMT_BF16>
 __device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x16_t (&acc)[FN], const float4 (&bias)[FN][4], int mrow0,
                                                    int ncol0, char* lds, int lane) {
     const int ml = lane & 31, h = lane >> 5;
@@ -150,10 +150,10 @@ __device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x
         for (int g = 0; g < 4; ++g) {
             const int nl = 32 * fn + 8 * g + 4 * h;
             const float4 bb = bias[fn][g];
-            *(bf16_t*)(lds + (nl + 0) * 64 + pos * 2) = f2bf_dev(acc[fn][4 * g + 0] + bb.x);
-            *(bf16_t*)(lds + (nl + 1) * 64 + pos * 2) = f2bf_dev(acc[fn][4 * g + 1] + bb.y);
-            *(bf16_t*)(lds + (nl + 2) * 64 + pos * 2) = f2bf_dev(acc[fn][4 * g + 2] + bb.z);
-            *(bf16_t*)(lds + (nl + 3) * 64 + pos * 2) = f2bf_dev(acc[fn][4 * g + 3] + bb.w);
+            *(bf16_t*)(lds + (nl + 0) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 0] + bb.x);
+            *(bf16_t*)(lds + (nl + 1) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 1] + bb.y);
+            *(bf16_t*)(lds + (nl + 2) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 2] + bb.z);
+            *(bf16_t*)(lds + (nl + 3) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 3] + bb.w);
         }
     if (mrow0 >= a.M) return;
     const int b = mrow0 / a.Tp, t0 = mrow0 - b * a.Tp;
@@ -173,7 +173,7 @@ __device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x
 }
 
 // one 32-row block of a wave's tile; `bias` = load_colvec(a.bias, ncol0, ...) of the wave (loaded once per tile)
-template <int FN, int EPI, int ACT>
+template <int FN, int EPI, int ACT, int FMT = FMT_BF16>
 __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_t (&acc)[FN], const float4 (&bias)[FN][4], int mrow0,
                                                 int ncol0, char* lds, int lane) {
     using S = StagedEpi<FN, EPI>;
@@ -181,7 +181,7 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
         // one launch for q, k and v (N = 2304): the V third leaves through the transposing epilogue (wave-uniform:
         // every wave's column range lies inside one third, 768 being a multiple of every wave width in use)
         static_assert(FN * 32 * 64 <= S::BYTES, "V^T staging must fit the wave's region");
-        if (ncol0 >= 2 * SYL_HIDDEN) { epilogue_vt_rows32<FN>(a, acc, bias, mrow0, ncol0, lds, lane); return; }
+        if (ncol0 >= 2 * SYL_HIDDEN) { epilogue_vt_rows32<FN, FMT>(a, acc, bias, mrow0, ncol0, lds, lane); return; }
     }
     const int ml = lane & 31, h = lane >> 5;
     const int m = mrow0 + ml;
@@ -209,7 +209,7 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
             if constexpr (S::F32OUT) {
                 *(float4*)(lds + ml * S::RS + nl * 4) = make_float4(v0, v1, v2, v3);
             } else {
-                uint2 pk; pk.x = pack_bf16x2(v0, v1); pk.y = pack_bf16x2(v2, v3);
+                uint2 pk; pk.x = H16<FMT>::pack2(v0, v1); pk.y = H16<FMT>::pack2(v2, v3);
                 *(uint2*)(lds + ml * S::RS + nl * 2) = pk;
             }
         }
@@ -236,17 +236,17 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
             const float4 v = __builtin_bit_cast(float4, raw);
             *(float4*)((float*)a.out0 + (size_t)mo * a.ld0 + n) = v;
             const int b = mo / a.Tp, t = mo - b * a.Tp;
-            uint2 pk; pk.x = pack_bf16x2(v.x, v.y); pk.y = pack_bf16x2(v.z, v.w);
+            uint2 pk; pk.x = H16<FMT>::pack2(v.x, v.y); pk.y = H16<FMT>::pack2(v.z, v.w);
             *(uint2*)((bf16_t*)a.out1 + ((size_t)b * a.xpad_rows + 64 + t) * SYL_HIDDEN + n) = pk;
         }
     }
 }
 
 // all FM 32-row blocks of a wave's tile through the staged epilogue (bias column vectors loaded once)
-template <int FM, int FN, int EPI, int ACT>
+template <int FM, int FN, int EPI, int ACT, int FMT = FMT_BF16>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& a, const f32x16_t (&acc)[FM][FN], int mrow0, int ncol0, char* lds, int lane) {
     float4 bias[FN][4];
     load_colvec<FN>(a.bias, ncol0, lane >> 5, a.N, bias);
 #pragma unroll
-    for (int fm = 0; fm < FM; ++fm) epilogue_rows32<FN, EPI, ACT>(a, acc[fm], bias, mrow0 + fm * 32, ncol0, lds, lane);
+    for (int fm = 0; fm < FM; ++fm) epilogue_rows32<FN, EPI, ACT, FMT>(a, acc[fm], bias, mrow0 + fm * 32, ncol0, lds, lane);
 }

@@ -35,6 +35,7 @@ struct GemmArgs {
     int xpad_rows;                // rows per utterance of the zero-padded pos-conv input (EPI_PROJ)
     const float* ln_stats;        // [M][2] (mean, rstd) of the rows of `res` (EPI_F32_RESLN)
     const float* ln_gamma; const float* ln_beta;
+    int fmt;                      // FMT_BF16 (0) or FMT_F16: 16-bit format of X, W and of bf16-typed outputs
     int tune_cfg;                 // 0 = tile shape chosen by the cost model; k > 0 forces tile configuration k - 1
     int tune_persist;             // > 0: persistent launch (that many workgroups per CU walk the tile list)
 };
@@ -78,7 +79,7 @@ int launch_conv0_finalize(const double* partials, int nchunk, const float* w0, c
                           int B, int L0, float* scale_shift, hipStream_t s);
 // out: [B][R0][512] (bf16 or f32); rows l >= L0 are written as zeros
 int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, const float* w0,
-                         const float* scale_shift, void* out, int out_f32, hipStream_t s);
+                         const float* scale_shift, void* out, int out_f32, hipStream_t s, int fmt = 0);
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (512 or 768), eps 1e-5, one wave per row
@@ -86,7 +87,8 @@ int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, cons
 //   remap: if Tp>0, input row m=(b,t) with t>=T is skipped and outputs are written compact at b*T+t
 // ------------------------------------------------------------------------------------------------
 struct LnArgs {
-    const void* in; int in_bf16; long ld_in;
+    const void* in; int in_bf16; long ld_in;     // in_bf16: the input rows are 16-bit words of format `fmt`
+    int fmt;                                      // FMT_BF16 / FMT_F16: format of a 16-bit input and of out_bf16
     const float* res; long ld_res;
     const float* gamma; const float* beta;
     float* out_f32; long ld_f32;
@@ -105,7 +107,7 @@ int launch_layernorm(const LnArgs& a, hipStream_t s);
 // ------------------------------------------------------------------------------------------------
 // qw: 0 = automatic, 1 / 2 = 32 / 64 queries per wave
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T,
-                     int Tp, int Tpv, int qw, hipStream_t s);
+                     int Tp, int Tpv, int qw, hipStream_t s, int fmt = 0);
 int launch_attention_f8out(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, uint8_t* ctx8, uint8_t* ctx_scale,
                            long scale_rows, int B, int T, int Tp, int Tpv, int qw, hipStream_t s);   // context as MXFP8 (SYLBER_FP8)
 int launch_attention_f32(const float* q, const float* k, const float* v, const int* valid, float* ctx, int B, int T,
@@ -118,7 +120,7 @@ int launch_attention_f32(const float* q, const float* k, const float* v, const i
 //   out : f32 [B*Tp][768] = x_f32 + gelu(conv + bias)
 // ------------------------------------------------------------------------------------------------
 int launch_posconv(const bf16_t* xpad, const bf16_t* wpk, const float* bias, const float* x_f32, float* out, int B,
-                   int Tp, int act, hipStream_t s);
+                   int Tp, int act, hipStream_t s, int fmt = 0);
 int launch_posconv_f32(const float* xpad, const float* w, const float* bias, const float* x_f32, float* out, int B,
                        int Tp, hipStream_t s);
 
@@ -131,4 +133,4 @@ size_t segment_scratch_floats(int B, int T, int D);
 
 // misc elementwise
 int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
-int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s);
+int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s, int fmt = 0);

@@ -29,7 +29,7 @@ __device__ __forceinline__ void glds16p(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((glb_vptr)g, (lds_vptr)l, 16, 0, 0);
 }
 
-template <int ACT>
+template <int ACT, int FMT>
 __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __restrict__ xpad, const bf16_t* __restrict__ wpk,
                                                               const float* __restrict__ bias, const float* __restrict__ x_f32,
                                                               float* __restrict__ out, int Tp) {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) {
                     const bf16x8_t wf = *(const bf16x8_t*)(wb + tt * PC_SLAB + nf * 32 * 112 + wfrag + q * 32);
-                    acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nf], 0, 0, 0);
+                    acc[nf] = H16<FMT>::mfma(wf, xf, acc[nf]);
                 }
             }
         }
@@ -118,15 +118,17 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
 }
 
 int launch_posconv(const bf16_t* xpad, const bf16_t* wpk, const float* bias, const float* x_f32, float* out, int B, int Tp,
-                   int act, hipStream_t s) {
+                   int act, hipStream_t s, int fmt) {
     dim3 grid((Tp + PC_BM - 1) / PC_BM, SYL_POSG, B);
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
-        HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
-        HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<1, FMT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<2, FMT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<1, FMT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
     }
-    if (act == 2) hipLaunchKernelGGL(posconv_bf16_kernel<2>, grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
-    else hipLaunchKernelGGL(posconv_bf16_kernel<1>, grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
+    if (fmt == FMT_F16) hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_F16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
+    else if (act == 2) hipLaunchKernelGGL((posconv_bf16_kernel<2, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
+    else hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -16,18 +16,18 @@ sd = synthetic_state_dict(0)
 g = np.load(os.path.join(ROOT, "tests/golden/encoder_stages.npz"))
 wav = torch.from_numpy(g["wav"]).cuda(); lengths = [int(x) for x in g["lengths"]]
 print("# Parity report (MI355X) — HIP path vs reference goldens (tests/golden/encoder_stages.npz)\n")
-print("| stage | bf16 rel-RMS | bf16 max-abs | fp32 rel-RMS | fp32 max-abs | fp8 (configs[4]) rel-RMS | fp8 max-abs |\n|---|---:|---:|---:|---:|---:|---:|")
-encs = {p: HubertEncoderHIP(sd, precision=p) for p in ("bf16", "fp32", "fp8")}
+print("| stage | bf16 rel-RMS | bf16 max-abs | fp16 rel-RMS | fp16 max-abs | fp32 rel-RMS | fp32 max-abs | fp8 (configs[4]) rel-RMS | fp8 max-abs |\n|---|---:|---:|---:|---:|---:|---:|---:|---:|")
+encs = {p: HubertEncoderHIP(sd, precision=p) for p in ("bf16", "fp16", "fp32", "fp8")}
 for name, stage, key in [("conv stack", 1, "conv6"), ("encoder input (proj+pos-conv+LN)", 2, "enc_in"), ("layer 0", 3, "layer0"),
                          ("layer 4", 7, "layer4"), ("layer 8 = hidden_states", 0, "layer8")]:
     ref = g[key].transpose(0, 2, 1) if key == "conv6" else g[key]
     row = []
-    for p in ("bf16", "fp32", "fp8"):
+    for p in ("bf16", "fp16", "fp32", "fp8"):
         out = encs[p].forward(wav, lengths, stop_stage=stage).cpu().numpy()
         row += ["%.2e" % rel_rms(out, ref), "%.2e" % np.abs(out - ref).max()]
     print("| %s | %s |" % (name, " | ".join(row)))
 # segment agreement of the end-to-end paths with the fp32 reference segmentation
-for prec in ("bf16", "fp8"):
+for prec in ("bf16", "fp16", "fp8"):
     tot = agree = 0; nb = mb = 0
     for seed in range(16):
         x = syllable_wave(80000, 500 + seed)
