@@ -27,6 +27,62 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((glb_vptr)g, (lds_vptr)l, 16, 0, 0);
 }
 
+// 1/l and the store of one 32-query sub-tile: ctx[b*Tp + q][head*64 + d] (or its MXFP8 form)
+template <bool F8, int FMT>
+__device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l_run, bf16_t* __restrict__ ctx, uint8_t* __restrict__ ctx_scale,
+                                              long scale_rows, int b, int head, int q_first, int ql, int h, int T, int Tp) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q = q_first + ql;
+        if constexpr (F8) {
+            // SYLBER_FP8: the context leaves as MXFP8 for the out-projection GEMM.  A 32-wide d block of a head is one
+            // scale block: 16 values in this lane, 16 in lane ^ 32; the halves swap two runs so that each lane stores
+            // 16 contiguous bytes (a whole 32-byte sector per lane pair); the two scales of a (token, head) are the
+            // adjacent pair of the K-pair-major layout
+            uint8_t* dst8 = (uint8_t*)ctx + ((size_t)b * Tp + (q < T ? q : 0)) * SYL_HIDDEN + head * 64;
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                float amax = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(oacc[ds][r] * inv));
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                const unsigned e = mx_e8m0(amax);
+                const float sc = inv * mx_inv_scale(e);
+                unsigned w[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    w[g] = pack_fp8x4(oacc[ds][4 * g + 0] * sc, oacc[ds][4 * g + 1] * sc, oacc[ds][4 * g + 2] * sc, oacc[ds][4 * g + 3] * sc);
+                const unsigned s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];
+                const unsigned g0 = (unsigned)__shfl_xor((int)s0, 32, 64), g1 = (unsigned)__shfl_xor((int)s1, 32, 64);
+                const uint4 out = h ? make_uint4(g0, w[2], g1, w[3]) : make_uint4(w[0], g0, w[1], g1);
+                if (q < T) {
+                    *(uint4*)(dst8 + 32 * ds + 16 * h) = out;
+                    if (h == 0) ctx_scale[mx_scale_index((long)b * Tp + q, 2 * head + ds, scale_rows)] = (uint8_t)e;
+                }
+            }
+        } else {
+            // the store tail is store-ISSUE bound (16 dwordx2 per lane): the lane halves swap one 4-feature run per pair
+            // of runs, so that each lane stores 8 consecutive features = 8 dwordx4 per lane, whole 32-byte sectors per
+            // lane pair (lane h = 0: d = 16p .. 16p+7, lane h = 1: d = 16p+8 .. 16p+15)
+            bf16_t* dst = ctx + ((size_t)b * Tp + (q < T ? q : 0)) * SYL_HIDDEN + head * 64;
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    uint2 ra, rb;
+                    ra.x = H16<FMT>::pack2(oacc[ds][8 * pr + 0] * inv, oacc[ds][8 * pr + 1] * inv);
+                    ra.y = H16<FMT>::pack2(oacc[ds][8 * pr + 2] * inv, oacc[ds][8 * pr + 3] * inv);
+                    rb.x = H16<FMT>::pack2(oacc[ds][8 * pr + 4] * inv, oacc[ds][8 * pr + 5] * inv);
+                    rb.y = H16<FMT>::pack2(oacc[ds][8 * pr + 6] * inv, oacc[ds][8 * pr + 7] * inv);
+                    const uint2 keep = h ? rb : ra, send = h ? ra : rb;
+                    uint2 got;
+                    got.x = (unsigned)__shfl_xor((int)send.x, 32, 64); got.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
+                    const uint4 out = h ? make_uint4(got.x, got.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, got.x, got.y);
+                    if (q < T) *(uint4*)(dst + 32 * ds + 16 * pr + 8 * h) = out;
+                }
+        }
+}
+
 // QW = 32-query sub-tiles per wave.  QW = 2 halves the LDS fragment reads and the LDS-DMA instructions per
 // MFMA (every K / V^T fragment feeds two MFMAs); the DMA issue is the most expensive instruction of the loop
 // (profiles/r01_mfma_ceiling.md).
@@ -188,68 +244,17 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
     }
     // ---- finalize: 1/l, store ctx[b*Tp + q][head*64 + d]
 #pragma unroll
-    for (int qs = 0; qs < QW; ++qs) {
-        const float l_tot = l_run[qs] + __shfl_xor(l_run[qs], 32, 64);
-        const float inv = 1.0f / l_tot;
-        const int q = q0 + 32 * qs + ql;
-        if constexpr (F8) {
-            // SYLBER_FP8: the context leaves as MXFP8 for the out-projection GEMM.  A 32-wide d block of a head is one
-            // scale block: 16 values in this lane, 16 in lane ^ 32; the halves swap two runs so that each lane stores
-            // 16 contiguous bytes (a whole 32-byte sector per lane pair); the two scales of a (token, head) are the
-            // adjacent pair of the K-pair-major layout
-            uint8_t* dst8 = (uint8_t*)ctx + ((size_t)b * Tp + (q < T ? q : 0)) * SYL_HIDDEN + head * 64;
-#pragma unroll
-            for (int ds = 0; ds < 2; ++ds) {
-                float amax = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(oacc[qs][ds][r] * inv));
-                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-                const unsigned e = mx_e8m0(amax);
-                const float sc = inv * mx_inv_scale(e);
-                unsigned w[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    w[g] = pack_fp8x4(oacc[qs][ds][4 * g + 0] * sc, oacc[qs][ds][4 * g + 1] * sc, oacc[qs][ds][4 * g + 2] * sc, oacc[qs][ds][4 * g + 3] * sc);
-                const unsigned s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];
-                const unsigned g0 = (unsigned)__shfl_xor((int)s0, 32, 64), g1 = (unsigned)__shfl_xor((int)s1, 32, 64);
-                const uint4 out = h ? make_uint4(g0, w[2], g1, w[3]) : make_uint4(w[0], g0, w[1], g1);
-                if (q < T) {
-                    *(uint4*)(dst8 + 32 * ds + 16 * h) = out;
-                    if (h == 0) ctx_scale[mx_scale_index((long)b * Tp + q, 2 * head + ds, scale_rows)] = (uint8_t)e;
-                }
-            }
-        } else {
-            // the store tail is store-ISSUE bound (16 dwordx2 per lane): the lane halves swap one 4-feature run per pair
-            // of runs, so that each lane stores 8 consecutive features = 8 dwordx4 per lane, whole 32-byte sectors per
-            // lane pair (lane h = 0: d = 16p .. 16p+7, lane h = 1: d = 16p+8 .. 16p+15)
-            bf16_t* dst = ctx + ((size_t)b * Tp + (q < T ? q : 0)) * SYL_HIDDEN + head * 64;
-#pragma unroll
-            for (int ds = 0; ds < 2; ++ds)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    uint2 ra, rb;
-                    ra.x = H16<FMT>::pack2(oacc[qs][ds][8 * pr + 0] * inv, oacc[qs][ds][8 * pr + 1] * inv);
-                    ra.y = H16<FMT>::pack2(oacc[qs][ds][8 * pr + 2] * inv, oacc[qs][ds][8 * pr + 3] * inv);
-                    rb.x = H16<FMT>::pack2(oacc[qs][ds][8 * pr + 4] * inv, oacc[qs][ds][8 * pr + 5] * inv);
-                    rb.y = H16<FMT>::pack2(oacc[qs][ds][8 * pr + 6] * inv, oacc[qs][ds][8 * pr + 7] * inv);
-                    const uint2 keep = h ? rb : ra, send = h ? ra : rb;
-                    uint2 got;
-                    got.x = (unsigned)__shfl_xor((int)send.x, 32, 64); got.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
-                    const uint4 out = h ? make_uint4(got.x, got.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, got.x, got.y);
-                    if (q < T) *(uint4*)(dst + 32 * ds + 16 * pr + 8 * h) = out;
-                }
-        }
-    }
+    for (int qs = 0; qs < QW; ++qs) attn_finalize<F8, FMT>(oacc[qs], l_run[qs], ctx, ctx_scale, scale_rows, b, head, q0 + 32 * qs, ql, h, T, Tp);
 }
 
 static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, void* ctx, uint8_t* ctx_scale,
                                 long scale_rows, int B, int T, int Tp, int Tpv, int force_qw, int fmt, hipStream_t s) {
     if (Tpv % 64 != 0 || Tpv < T) { syl_set_error("launch_attention", "Tpv must be a multiple of 64 and >= T"); return 1; }
+    bf16_t* c = (bf16_t*)ctx;
     // 64 queries per wave when there are enough query blocks to fill the chip, else 32
     int qw = ((long)((T + 255) / 256) * SYL_HEADS * B >= 512) ? 2 : 1;
     if (force_qw == 1 || force_qw == 2) qw = force_qw;
     const dim3 grid((qw == 2 ? (T + 255) / 256 : (T + 127) / 128) * SYL_HEADS * B);
-    bf16_t* c = (bf16_t*)ctx;
     if (ctx_scale) {
         if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, ctx_scale, scale_rows);
         else hipLaunchKernelGGL((attention_bf16_kernel<1, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, ctx_scale, scale_rows);

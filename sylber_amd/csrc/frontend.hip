@@ -182,17 +182,26 @@ int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, cons
 
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, D/64 values per lane in registers.
+#ifndef LN_ROWS
+#define LN_ROWS 1
+#endif
 template <int D, bool IN_BF16, int FMT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     constexpr int V = D / 256;   // float4 groups per lane (2 for 512, 3 for 768)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // XCD-aware row order: the rows an XCD normalises are the rows its GEMM tiles produced / will consume
-    const int m = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-    if (m >= a.M) return;
+    // XCD-aware row order: the rows an XCD normalises are the rows its GEMM tiles produced / will consume.
+    // A workgroup handles 4 * LN_ROWS consecutive rows (a wave LN_ROWS of them, interleaved with its siblings).
+    // LN_ROWS = 4 (1024 workgroups, the grid size at which tools/ubench/hbm_bw.hip's copy peaks) measured the same
+    // 0.33 ms per forward as LN_ROWS = 1: the kernel is at what this read + write mix sustains.
+    const int m_first = xcd_remap(blockIdx.x, gridDim.x) * (4 * LN_ROWS) + wave;
+#pragma unroll 1
+    for (int rr = 0; rr < LN_ROWS; ++rr) {
+    const int m = m_first + 4 * rr;
+    if (m >= a.M) break;
     int orow = m;
     if (a.Tp > 0) {
         const int b = m / a.Tp, t = m - b * a.Tp;
-        if (t >= a.T) return;
+        if (t >= a.T) continue;
         orow = b * a.T + t;
     }
     float x[V][4];
@@ -250,6 +259,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
             if ((lane & 7) == 0) a.out_scale[mx_scale_index(m, c >> 5, a.scale_rows)] = (uint8_t)e;
         }
     }
+    }
 }
 
 template <int FMT>
@@ -263,7 +273,7 @@ static bool launch_ln_fmt(const LnArgs& a, dim3 grid, hipStream_t s) {
 }
 
 int launch_layernorm(const LnArgs& a, hipStream_t s) {
-    dim3 grid((a.M + 3) / 4);
+    dim3 grid((a.M + 4 * LN_ROWS - 1) / (4 * LN_ROWS));
     if (a.fmt == FMT_F16 ? launch_ln_fmt<FMT_F16>(a, grid, s) : launch_ln_fmt<FMT_BF16>(a, grid, s)) {}
     else { syl_set_error("launch_layernorm", "D must be 512 or 768"); return 1; }
     HIP_TRY(hipGetLastError());
