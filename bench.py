@@ -59,6 +59,9 @@ def parse_args():
                          "counts VALID audio only -> the padding overhead of the reference's batching contract (not the headline)")
     ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS,
                     help="clip length; 10 = BASELINE configs[1] (default), 60 with --batch 8 = configs[3] (long-form)")
+    ap.add_argument("--exchange-selftest", action="store_true",
+                    help="N = 1 only: run the N>1 code path (one-rank RCCL communicator, scatter / gather to self inside every "
+                         "step) -- the only way to exercise it on a one-GPU box; the line is labelled accordingly")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
     ap.add_argument("--agreement-clips", type=int, default=0,
                     help="also report bf16-vs-fp32 segment agreement on this many synthetic clips (fp32 parity mode as truth)")
@@ -171,6 +174,19 @@ def main():
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
     rccl_ranks = 1
+    selftest = args.exchange_selftest and world == 1
+    if selftest:
+        import datetime
+        import socket
+        with socket.socket() as _s:
+            _s.bind(("127.0.0.1", 0))
+            _port = _s.getsockname()[1]
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(_port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=300))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -296,8 +312,10 @@ def main():
         return evs
 
     # ---- exchange (N > 1 default): root scatter + gather over RCCL inside every step
-    sharded = ShardedSegmenter(encs)
+    sharded = ShardedSegmenter(encs, always_collective=selftest)
     root_batch = None
+    if selftest:
+        root_batch = my_batch
     if world > 1 and rank == 0:
         root_batch = torch.cat([noise_batch(B, clip_samples, seed=1000 + r) for r in range(world)], 0).to(dev)
 
@@ -310,7 +328,7 @@ def main():
             evs.append(ev)
         return evs
 
-    exchange_first = world > 1 and not args.no_exchange
+    exchange_first = (world > 1 and not args.no_exchange) or selftest
     secondary = None
     exchange_error = None
     if exchange_first:
@@ -455,7 +473,8 @@ def main():
                        "global_batch": world * B, "clip_seconds": clip_seconds,
                        "ragged": ("lengths U[2 s, %g s], %.1f valid s of %g padded s per batch" % (clip_seconds, valid_seconds, B * clip_seconds))
                                  if args.ragged else None, "frames_per_clip": T_frames,
-                       "parallelism": "utterance-sharded x%d, %s" % (world, ex_txt if exchange_first else res_txt),
+                       "parallelism": "utterance-sharded x%d, %s%s" % (world, ex_txt if exchange_first else res_txt,
+                                                                        " [one-rank RCCL self-test of the N>1 path]" if selftest else ""),
                        "rccl_ranks": rccl_ranks,
                        "pipelining": "%d batch(es) in flight on independent handles/streams%s" % (
                            NPIPE, "" if (exchange_first or args.no_overlap) else "; segmenter on a side stream"),
@@ -474,10 +493,19 @@ def main():
             line["exchange_error"] = exchange_error
         if agreement is not None:
             line["segment_agreement"] = agreement
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or selftest:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: the communicator is gone, and RCCL's NCCL_DEBUG=VERSION banner (C stdio,
+        # otherwise flushed at exit, i.e. AFTER this line) is pushed out first
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

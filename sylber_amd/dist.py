@@ -126,18 +126,20 @@ class ShardedSegmenter:
                     raise RuntimeError("an utterance has more than max_segments=%d segments" % k)
                 return tuple(t[:btot] for t in parts)
             return wait1
-        outs, works = [], []
+        fulls, works = [], []
         for t in parts:
-            o = [torch.empty_like(t) for _ in range(W)] if self.rank == 0 else None
+            # root receives straight into the slices of ONE [W * Bper, ...] tensor: no concatenation copy afterwards
+            full = torch.empty((W * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) if self.rank == 0 else None
+            o = list(full.view((W, t.shape[0]) + tuple(t.shape[1:])).unbind(0)) if self.rank == 0 else None
             works.append(dist.gather(t, o, dst=0, group=self.group, async_op=True))
-            outs.append(o)
+            fulls.append(full)
 
         def wait():
             for wk in works:
                 wk.wait()
             if self.rank != 0:
                 return None
-            res = tuple(torch.cat(o, 0)[:btot] for o in outs)
+            res = tuple(f[:btot] for f in fulls)
             if int(res[2].max()) > k:
                 raise RuntimeError("an utterance has more than max_segments=%d segments" % k)
             return res
