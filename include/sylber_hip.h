@@ -156,7 +156,9 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *   SYLBER_OPT_GEMM_TILE               tile configuration id of the bf16 GEMM launches (csrc/gemm_bf16.hip launch_t:
  *                                      0 = 256x128, 3 = 128x128, 4 = 128x192, 10 = 256x256 8-wave, 11 = 256x192 8-wave)
  *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   32 or 64
- *   SYLBER_OPT_GEMM_PERSISTENT         k > 0: GEMM launches of k x 256 persistent workgroups walking the tile list */
+ *   SYLBER_OPT_GEMM_PERSISTENT         k > 0: 4-wave GEMM launches of k x 256 persistent workgroups walking the tile list;
+ *                                      k < 0: additionally run the 256x256 kernel one tile per workgroup instead of its
+ *                                      persistent form with cross-tile operand prefetch (A/B switch) */
 enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3 };
 int sylber_set_option(sylber_t h, int32_t key, int32_t value);
 
@@ -187,9 +189,12 @@ int64_t sylber_workspace_bytes(sylber_t h);
 /* C[M,N] (fp32) = A[M,K] (fp32, cast to bf16) x W[N,K]^T (fp32, cast to bf16) + bias[N] (nullable); act: 0 none,
  * 1 gelu (the bf16 path's polynomial), 2 gelu (erf); precision: SYLBER_BF16 or SYLBER_FP8 (K % 128 == 0);
  * tile: -1 = automatic, else the tile configuration id to run (parity tests sweep every configuration), + 1000 k for a
- * persistent launch of k x 256 workgroups */
+ * persistent launch of k x 256 workgroups (9000 + id: never persistent) */
 int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, float* c_dev, int32_t M,
                      int32_t N, int32_t K, int32_t act, int32_t precision, int32_t tile, void* stream);
+/* the same contraction through the 16-bit output epilogue the conv layers and FFN1 use: c16_dev [M,N] bf16 words */
+int sylber_op_linear16(const float* a_dev, const float* w_dev, const float* bias_dev, uint16_t* c16_dev, int32_t M,
+                       int32_t N, int32_t K, int32_t act, int32_t precision, int32_t tile, void* stream);
 /* MXFP8 quantiser used by SYLBER_FP8: x [R,K] fp32 -> data [R,K] e4m3 + E8M0 scales, one per 32 elements along K,
  * stored K-pair-major [K/64, R, 2] (K % 64 == 0; the layout the GEMM's scale fetch wants); the block scale is the
  * smallest power of two 2^e with amax <= 448 * 2^e, elements are x / 2^e rounded to nearest even */

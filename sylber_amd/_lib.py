@@ -53,6 +53,8 @@ EXPORTS = {
     "sylber_workspace_bytes": (c_int64, [c_void_p]),
     "sylber_op_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  c_int32, c_void_p]),
+    "sylber_op_linear16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                   c_int32, c_void_p]),
     "sylber_op_mx_quantize": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "sylber_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "sylber_ingest_num_frames": (c_int64, [c_int64, c_int32]),

@@ -258,7 +258,7 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
     switch (key) {
         case SYLBER_OPT_GEMM_TILE: c->opt_gemm_cfg = value < 0 ? 0 : value + 1; break;     // stored as id + 1, 0 = automatic
         case SYLBER_OPT_ATTN_QUERIES_PER_WAVE: c->opt_attn_qw = value == 32 ? 1 : (value == 64 ? 2 : 0); break;
-        case SYLBER_OPT_GEMM_PERSISTENT: c->opt_gemm_persist = value > 0 ? value : 0; break;
+        case SYLBER_OPT_GEMM_PERSISTENT: c->opt_gemm_persist = value; break;      // < 0: also keep the 256x256 kernel one tile per workgroup
         default: syl_set_error("sylber_set_option", "unknown option key"); return 1;
     }
     if (c->graph_mode) { for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec); c->graphs.clear(); }   // captured launches are stale
@@ -754,8 +754,26 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
     if (launch_f32_to_bf16(w_dev, (bf16_t*)wb.p, (size_t)N * K, s)) return 1;
     GemmArgs g = {};
     g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev; g.act = act;
-    g.out0 = c_dev; g.ld0 = N; g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 1000 ? tile / 1000 : 0;
+    g.out0 = c_dev; g.ld0 = N; g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
     if (launch_gemm_bf16(EPI_F32, g, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// the same GEMM with its 16-bit output epilogue (EPI_BF16: what the conv layers and FFN1 run): C16 = bf16 / fp16 words
+extern "C" int sylber_op_linear16(const float* a_dev, const float* w_dev, const float* bias_dev, uint16_t* c16_dev, int32_t M,
+                                  int32_t N, int32_t K, int32_t act, int32_t precision, int32_t tile, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (precision != SYLBER_BF16 && precision != SYLBER_FP16) { syl_set_error("sylber_op_linear16", "precision must be bf16 or fp16"); return 1; }
+    if (precision == SYLBER_FP16) { syl_set_error("sylber_op_linear16", "fp16 operands are packed by sylber_create only"); return 1; }
+    TmpBuf ab, wb;
+    if (ab.alloc(((size_t)M + 128) * K * 2) || wb.alloc(((size_t)N + 128) * K * 2)) { syl_set_error("sylber_op_linear16", "alloc"); return 1; }
+    if (launch_f32_to_bf16(a_dev, (bf16_t*)ab.p, (size_t)M * K, s)) return 1;
+    if (launch_f32_to_bf16(w_dev, (bf16_t*)wb.p, (size_t)N * K, s)) return 1;
+    GemmArgs g = {};
+    g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev; g.act = act;
+    g.out0 = c16_dev; g.ld0 = N; g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+    if (launch_gemm_bf16(EPI_BF16, g, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
@@ -890,7 +908,7 @@ extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t 
         g.out0 = qkb.p; g.out1 = (char*)qkb.p + (size_t)(M + 512) * 768 * 2; g.out2 = (char*)qkb.p + (size_t)(M + 512) * 768 * 4;
     }
     g.tune_cfg = cfg < 0 ? 0 : (cfg % 1000) + 1;
-    g.tune_persist = cfg >= 1000 ? cfg / 1000 : 0;    // cfg = persist * 1000 + tile
+    g.tune_persist = cfg >= 9000 ? -1 : (cfg >= 1000 ? cfg / 1000 : 0);    // cfg = persist * 1000 + tile (9000 + tile: persist = -1)
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     int rc = 0;

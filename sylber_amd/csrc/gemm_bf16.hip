@@ -405,6 +405,158 @@ __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Persistent form of the 256x256 8-wave kernel for the launches that dominate the forward (conv1-5, FFN1: EPI_BF16,
+// whole tiles only).  256 workgroups walk the tile list; the K loop is the one above.  What changes is the seam
+// between two tiles of a workgroup: the LDS-DMA of the NEXT tile's first two K steps is requested before the epilogue
+// of the current one (into ring slots 2 and 3, which the epilogue's staging area -- the first 36 KB -- does not touch),
+// so the operand latency of a tile's prologue (~5 k of the ~50-85 k cycles of a tile) and the workgroup dispatch
+// disappear under the epilogue.  Every tile therefore runs its ring from slot 2.
+// vmcnt bookkeeping at the seam: VMEM operations of a wave retire in issue order on gfx9 (one counter for loads and
+// stores; the compiler's own waitcnt insertion relies on the same rule), the epilogue issues exactly NST = 16 stores per
+// wave (whole tiles: every store of the staged epilogue executes) and, with a bias, 8 loads that are consumed before
+// the stores.  Issue order per wave: step0' step1' [bias loads] stores x16 step2' | K loop: step3' ...  So
+// "step0' landed" = at most NPW + NST + NPW operations younger than it outstanding, "step1' landed" (step 0 of the
+// new K loop) = NST + NPW; from step 1 on the stores are older than everything that may remain in flight.
+template <int ACT, int FMT>
+__global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
+    constexpr int FM = 4, FN = 2, WM = 2, WN = 4, EPI = EPI_BF16;
+    constexpr int BM = 256, BN = 256, RB = 64;
+    constexpr int XT = BM * RB, WT = BN * RB, STAGE = XT + WT;
+    constexpr int NPW = (BM + BN) / 16 / 8;          // 4 one-KiB pieces per wave and step
+    constexpr int NST = FM * (StagedEpi<FN, EPI>::CH / 2);   // global stores per wave in the staged epilogue: 16
+    static_assert(8 * StagedEpi<FN, EPI>::BYTES <= 2 * STAGE, "staging must stay inside ring slots 0 and 1");
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int group = wave >> 2;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = a.N / BN, tiles_m = a.M / BM;
+    const int ntiles = tiles_m * tiles_n;
+    const int srow = lane >> 2, spos = lane & 3;
+    const int frow = lane & 31;
+    const int swz = (lane >> 2) & 3;
+    const int fhalf = lane >> 5;
+    const int koff0 = (((0 + fhalf) ^ swz) << 4), koff1 = (((2 + fhalf) ^ swz) << 4);
+    const int xrow_off = (wm * 32 * FM + frow) * RB;
+    const int wrow_off = XT + (wn * 32 * FN + frow) * RB;
+    const int nt = a.K / 32;
+
+    int lds_off[NPW];
+    bool isx[NPW];
+    int prow[NPW];                                   // tile-local row of this lane in piece i
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int p = wave + 8 * i;
+        isx[i] = p < BM / 16;
+        const int r = (isx[i] ? p : p - BM / 16) * 16 + srow;
+        prow[i] = r;
+        lds_off[i] = (isx[i] ? 0 : XT) + (isx[i] ? p : p - BM / 16) * 1024;
+    }
+    const int csw = spos;                            // source chunk = spos ^ ((r >> 2) & 3), r-dependent part below
+    auto setup = [&](int tile_id, const bf16_t* (&g)[NPW], int& m0, int& n0) {
+        const int wg = xcd_remap(tile_id, ntiles);
+        m0 = (wg / tiles_n) * BM;
+        n0 = (wg % tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int c = csw ^ ((prow[i] >> 2) & 3);
+            g[i] = isx[i] ? a.X + (size_t)(m0 + prow[i]) * a.ldx + c * 8 : a.W + (size_t)(n0 + prow[i]) * a.K + c * 8;
+        }
+    };
+    auto stage = [&](const bf16_t* const (&g)[NPW], int ks, int slot) {
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) glds16(g[i] + ks * 32, base + lds_off[i]);
+    };
+
+    const bf16_t* gp[NPW];
+    const bf16_t* gn[NPW];
+    int m0, n0, m0n = 0, n0n = 0;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    setup(tile, gp, m0, n0);
+    stage(gp, 0, 2);
+    if (nt > 1) stage(gp, 1, 3);
+    if (nt > 2) stage(gp, 2, 0);
+    if (nt > 2) wait_vmcnt<2 * NPW>(); else if (nt > 1) wait_vmcnt<NPW>(); else wait_vmcnt<0>();
+    bool seam = false;                               // this tile's first K step follows an epilogue (stores in flight)
+    for (;;) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        if (group == 1) __builtin_amdgcn_s_barrier();    // stagger: group 1 runs one barrier behind
+        f32x16_t acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        int slot = 2;
+        for (int s = 0; s < nt; ++s) {
+            const char* sb = smem + slot * STAGE;
+            bf16x8_t xf[2][FM], wf[2][FN];
+            SCHED_FENCE();
+#pragma unroll
+            for (int f = 0; f < FM; ++f) {
+                xf[0][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff0);
+                xf[1][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff1);
+            }
+#pragma unroll
+            for (int f = 0; f < FN; ++f) {
+                wf[0][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff0);
+                wf[1][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff1);
+            }
+            // retire step s+1 (step s+2 may stay in flight; at a seam the epilogue's stores sit between them)
+            if (nt - 2 - s >= 1) { if (seam && s == 0) wait_vmcnt<NST + NPW>(); else wait_vmcnt<NPW>(); }
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+            SCHED_FENCE();
+            const bool dma = s + 3 < nt;
+            char* dbase = smem + ((slot + 3) & 3) * STAGE;
+            constexpr int NMF = 2 * FM * FN;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                const int kk = i / (FM * FN), fm = (i / FN) % FM, fn = i % FN;
+                acc[fm][fn] = H16<FMT>::mfma(wf[kk][fn], xf[kk][fm], acc[fm][fn]);
+                if ((i + 1) % (NMF / NPW) == 0) {
+                    const int q = (i + 1) / (NMF / NPW) - 1;
+                    SCHED_FENCE();
+                    if (dma) glds16(gp[q] + (s + 3) * 32, dbase + lds_off[q]);
+                    SCHED_FENCE();
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            SCHED_FENCE();
+            __builtin_amdgcn_s_barrier();
+            slot = (slot + 1) & 3;
+        }
+        if (group == 0) __builtin_amdgcn_s_barrier();    // pairs with group 1's extra barrier
+        __builtin_amdgcn_s_barrier();                    // every wave is done reading operand tiles
+        const int next = tile + (int)gridDim.x;
+        const bool more = next < ntiles;
+        if (more) {
+            setup(next, gn, m0n, n0n);
+            stage(gn, 0, 2);
+            if (nt > 1) stage(gn, 1, 3);
+        }
+        char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
+        epilogue_staged<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
+        if (!more) break;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // the staging area (ring slots 0, 1) is free again
+        if (nt > 2) stage(gn, 2, 0);
+        // step 0 of the next tile has landed: younger than it are step 1, the NST stores and step 2
+        if (nt > 2) wait_vmcnt<NPW + NST + NPW>(); else if (nt > 1) wait_vmcnt<NPW + NST>(); else wait_vmcnt<NST>();
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) gp[i] = gn[i];
+        m0 = m0n; n0 = n0n; tile = next; seam = true;
+    }
+}
+
 template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT>
 static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
@@ -418,6 +570,19 @@ static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
     int grid = tiles;
     if (a.tune_persist > 0 && tiles > 256) grid = 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int ACT, int FMT>
+static int launch_cfg8p(const GemmArgs& a, hipStream_t s) {
+    constexpr int LDS = 4 * (256 + 256) * 64;
+    static PerDeviceOnce attr_once;
+    auto kern = gemm8p_bf16_kernel<ACT, FMT>;
+    if (attr_once.need()) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    }
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -446,7 +611,13 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     switch (cfg) {
         case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT, FMT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
         case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);   // 128x128, 2 WG/CU
-        case 10: return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);            // 256x256, 8 waves staggered
+        case 10:
+            if constexpr (EPI == EPI_BF16) {
+                // whole tiles, more than one round, at least 3 K steps: the persistent kernel with cross-tile prefetch
+                if (a.tune_persist >= 0 && a.M % 256 == 0 && a.N % 256 == 0 && a.K >= 96 && (long)(a.M / 256) * (a.N / 256) > 256)
+                    return launch_cfg8p<ACT, FMT>(a, s);
+            }
+            return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
         default: return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);  // 128x192, 2 WG/CU
     }

@@ -137,3 +137,26 @@ def test_linear_persistent_grid(lib, per_cu):
     _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 0, 0, 1000 * per_cu + 4, None), "op_linear")
     ref = _bf(a) @ _bf(w).T + b
     assert (c.cpu() - ref).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear_persistent_prefetch_kernel(lib, act):
+    """the persistent 256x256 kernel with cross-tile operand prefetch (whole tiles, more than 256 of them: several tiles
+    per workgroup, seams included) returns bit for bit what the one-tile-per-workgroup kernel returns"""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(21)
+    for (M, N, K) in [(256 * 300, 512, 1536), (256 * 130, 768, 128), (256 * 90, 1024, 256)]:
+        a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+        ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+        outs = []
+        for tile in (10, 9010):                       # 9010 = tile 10, never persistent
+            c = torch.full((M, N), -1, dtype=torch.int16, device="cuda")
+            _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, act, 0, tile, None), "op_linear16")
+            outs.append(c)
+        assert torch.equal(outs[0], outs[1]), (M, N, K)
+        rows = torch.randint(0, M, (512,))
+        got = outs[0][rows.cuda()].view(torch.bfloat16).float().cpu()
+        ref = _bf(a[rows]) @ _bf(w).T + b
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        assert (got - ref).abs().max().item() < 2e-2 and (got - ref).pow(2).mean().sqrt().item() < 3e-3

@@ -8,8 +8,22 @@ half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled here
 calibrated on conv0_gn_gelu's known 1.0486 GB output (reads 1024000 KiB: exact)."""
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+
+def csrc_sha16():
+    """identity of the kernel sources the counters were collected with (bench.py repeats `traffic` only on a match)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "sylber_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(path):
@@ -32,8 +46,8 @@ def main(src, dst):
     gemm = [r for r in rows if "gemm" in r[0]]
     n_gemm = sum(r[1] for r in gemm)
     tot = sum((r[2] + r[3]) * r[1] for r in gemm)
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap (tools/collect_profiles.sh)",
-           "fetch_correction": 2.0, "gemm_family_bytes_per_launch": tot / n_gemm, "gemm_launches_profiled": n_gemm,
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-overlap (tools/collect_profiles.sh)",
+           "csrc_sha16": csrc_sha16(), "fetch_correction": 2.0, "gemm_family_bytes_per_launch": tot / n_gemm, "gemm_launches_profiled": n_gemm,
            "kernels": {r[0]: {"launches": r[1], "fetch_bytes_per_launch": r[2], "write_bytes_per_launch": r[3]} for r in rows}}
     json.dump(out, open(dst + ".json", "w"), indent=1)
     with open(dst + ".md", "w") as fh:
