@@ -227,8 +227,11 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
+    // multi-round launches run as 2 x 256 persistent workgroups (q/k/v: 1536 tiles; same-box A/B -1.4 %); tune_persist
+    // overrides the workgroups per CU, < 0 = one workgroup per tile
     int grid = tiles;
-    if (a.tune_persist > 0 && tiles > a.tune_persist * 256) grid = a.tune_persist * 256;
+    const int per_cu = a.tune_persist > 0 ? a.tune_persist : (a.tune_persist == 0 ? MINB : 0);
+    if (per_cu > 0 && tiles > per_cu * 256) grid = per_cu * 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
