@@ -15,6 +15,7 @@
 // K and V^T tiles (64 keys) are staged with global_load_lds_dwordx4 into a double buffer, XOR-swizzled
 // through the source address so the ds_read_b128 fragment reads are bank-conflict free.
 #include "kernels.h"
+#include <type_traits>
 
 #define AT_QBLK 128      // queries per workgroup (4 waves x 32)
 #define AT_KV 64         // keys per tile
@@ -84,10 +85,11 @@ __device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l
 }
 
 // QW = 32-query sub-tiles per wave.  QW = 2 halves the LDS fragment reads and the LDS-DMA instructions per
-// MFMA (every K / V^T fragment feeds two MFMAs); the DMA issue is the most expensive instruction of the loop
-// (profiles/r01_mfma_ceiling.md).
+// MFMA (every K / V^T fragment feeds two MFMAs) but runs three waves per SIMD instead of four; the kernel is bound by
+// the dependent chain S -> max -> exp -> P.V inside a wave (removing the exps, or either MFMA group, outright buys
+// 10-15 %: tools/ubench/attn_ablate.sh), so the extra resident wave wins.
 template <int QW, bool F8 = false, int FMT = FMT_BF16>
-__global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                 const bf16_t* __restrict__ Vt, const int* __restrict__ valid,
                                                                 bf16_t* __restrict__ ctx, int T, int Tp, int Tpv,
                                                                 uint8_t* __restrict__ ctx_scale, long scale_rows) {
@@ -157,90 +159,102 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
             glds16a(gv[i], smem + AT_TILE + lds_piece + i * 1024);
         }
     }
+    // One 64-key tile, as two 32-key halves: S^T half -> softmax -> P.V half.  The softmax is the bottleneck of this
+    // kernel, not the matrix pipe: per 64 keys a wave issues 32 MFMAs (1024 cycles) against ~64 v_exp_f32 (quarter
+    // rate, 1024 cycles) plus the fma / add / max / convert of every score, so every VALU instruction per score counts:
+    //   * the key-padding mask (compare + select per score) sits behind a real, wave-uniform branch: only the last
+    //     tile of an utterance pays for it (left to itself the compiler if-converts it into selects on every tile);
+    //   * the running maximum is LAZY: scores are exponentiated against a stale maximum as long as the new one exceeds
+    //     it by less than 2^8 (p <= 256: exact in the fp32 sums, in range for bf16 and fp16 P); the rescale of the 32
+    //     accumulator registers per query sub-tile (and the exp of alpha) then runs on the first half-tile and almost
+    //     never again.  O and l carry the same factor, so O / l is unchanged up to rounding; the decision is per query
+    //     (lanes that do not need it keep alpha = 1), so a query's result does not depend on its wave neighbours;
+    //   * 32 keys at a time halves the live score registers (213 -> <= 168 VGPRs): three waves per SIMD, which is what
+    //     makes 32 x 12 x 2 workgroups of the 10 s batch ONE round over the chip instead of one and a half.
+    auto tile = [&](const char* kb, const char* vb, int kv0, const bool TAIL) {
+#pragma unroll 1
+        for (int s2 = 0; s2 < 2; ++s2) {                                 // NOT unrolled: the scheduler would interleave the halves
+            if (TAIL && kv0 + 32 * s2 >= nvalid) break;                  // a half with no valid key (uniform)
+            f32x16_t sacc[QW];
+#pragma unroll
+            for (int qs = 0; qs < QW; ++qs)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[qs][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(kb + s2 * 32 * 128 + frow + (((2 * ks + h) ^ swz) << 4));
+#pragma unroll
+                for (int qs = 0; qs < QW; ++qs) sacc[qs] = H16<FMT>::mfma(kf, qf[qs][ks], sacc[qs]);
+            }
+            bf16x8_t pf[QW][2];
+#pragma unroll
+            for (int qs = 0; qs < QW; ++qs) {
+                if (TAIL) {
+                    asm volatile("; key-padding mask (last tile only)");     // keeps this a real branch: no if-conversion
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + 32 * s2 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (key >= nvalid) sacc[qs][r] = -INFINITY;
+                    }
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qs][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                // first half-tile: m_run = -inf, mx finite (key 0 is always valid) -> need; a fully masked half has
+                // mx = -inf -> no need, p = exp2(-inf) = 0
+                const bool need = (mx - m_run[qs]) * LOG2E > 8.0f;
+                if (__builtin_amdgcn_ballot_w64(need)) {
+                    const float m_new = need ? mx : m_run[qs];
+                    const float alpha = need ? __builtin_amdgcn_exp2f((m_run[qs] - m_new) * LOG2E) : 1.0f;
+                    m_run[qs] = m_new;
+                    l_run[qs] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[qs][i][r] *= alpha;
+                }
+                const float mb = m_run[qs] * LOG2E;
+                float psum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qs][8 * j + e], LOG2E, -mb));
+                        psum += p;
+                        pf[qs][j][e] = __builtin_bit_cast(__bf16, H16<FMT>::cvt(p));
+                    }
+                l_run[qs] += psum;
+            }
+            // O^T += V^T . P^T for these 32 keys (two 16-key groups x two 32-wide d blocks; a V^T fragment feeds QW MFMAs)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ds = 0; ds < 2; ++ds) {
+                    const bf16x8_t vf = *(const bf16x8_t*)(vb + ds * 32 * 128 + frow + (((2 * (2 * s2 + j) + h) ^ swz) << 4));
+#pragma unroll
+                    for (int qs = 0; qs < QW; ++qs) oacc[qs][ds] = H16<FMT>::mfma(vf, pf[qs][j], oacc[qs][ds]);
+                }
+        }
+    };
     for (int t = 0; t < nt; ++t) {
         // LDS-DMA completion is NOT covered by __syncthreads(): retire this wave's pieces of tile t explicitly,
         // then meet the other waves (their pieces are retired the same way) before any fragment read.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) {
-            char* kb = smem + ((t + 1) & 1) * 2 * AT_TILE;
+            char* nb = smem + ((t + 1) & 1) * 2 * AT_TILE;
             const int kv1 = (t + 1) * AT_KV;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int kr = kv1 + krow[i]; kr = kr < Tp ? kr : Tp - 1;
-                glds16a(gk[i] + (size_t)kr * 64, kb + lds_piece + i * 1024);
-                glds16a(gv[i] + kv1, kb + AT_TILE + lds_piece + i * 1024);
+                glds16a(gk[i] + (size_t)kr * 64, nb + lds_piece + i * 1024);
+                glds16a(gv[i] + kv1, nb + AT_TILE + lds_piece + i * 1024);
             }
         }
         const char* kb = smem + (t & 1) * 2 * AT_TILE;
-        const char* vb = kb + AT_TILE;
         const int kv0 = t * AT_KV;
-
-        // ---- S^T = K . Q^T  (two 32-key sub-tiles x QW query sub-tiles; each K fragment feeds QW MFMAs)
-        f32x16_t sacc[QW][2];
-#pragma unroll
-        for (int qs = 0; qs < QW; ++qs)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[qs][s2][r] = 0.f;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(kb + s2 * 32 * 128 + frow + (((2 * ks + h) ^ swz) << 4));
-#pragma unroll
-                for (int qs = 0; qs < QW; ++qs)
-                    sacc[qs][s2] = H16<FMT>::mfma(kf, qf[qs][ks], sacc[qs][s2]);
-            }
-        // ---- mask + online softmax (lane-local; partner lane^32 holds the other 32 keys of this query)
-        const bool tail = kv0 + AT_KV > nvalid;
-        bf16x8_t pf[QW][4];
-#pragma unroll
-        for (int qs = 0; qs < QW; ++qs) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (tail) {
-                        const int key = kv0 + 32 * s2 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (key >= nvalid) sacc[qs][s2][r] = -INFINITY;
-                    }
-                    mx = fmaxf(mx, sacc[qs][s2][r]);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qs], mx);           // finite: key 0 is always valid
-            const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * LOG2E);
-            const float mb = m_new * LOG2E;
-            float psum = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qs][s2][8 * j + e], LOG2E, -mb));
-                        psum += p;
-                        pf[qs][2 * s2 + j][e] = __builtin_bit_cast(__bf16, H16<FMT>::cvt(p));
-                    }
-            l_run[qs] = fmaf(l_run[qs], alpha, psum);
-            m_run[qs] = m_new;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[qs][i][r] *= alpha;
-        }
-        // ---- O^T += V^T . P^T  (four 16-key groups x two 32-wide d blocks; each V^T fragment feeds QW MFMAs)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int ds = 0; ds < 2; ++ds) {
-                const bf16x8_t vf = *(const bf16x8_t*)(vb + ds * 32 * 128 + frow + (((2 * u + h) ^ swz) << 4));
-#pragma unroll
-                for (int qs = 0; qs < QW; ++qs)
-                    oacc[qs][ds] = H16<FMT>::mfma(vf, pf[qs][u], oacc[qs][ds]);
-            }
+        tile(kb, kb + AT_TILE, kv0, kv0 + AT_KV > nvalid);
     }
     // ---- finalize: 1/l, store ctx[b*Tp + q][head*64 + d]
 #pragma unroll
@@ -251,8 +265,9 @@ static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* 
                                 long scale_rows, int B, int T, int Tp, int Tpv, int force_qw, int fmt, hipStream_t s) {
     if (Tpv % 64 != 0 || Tpv < T) { syl_set_error("launch_attention", "Tpv must be a multiple of 64 and >= T"); return 1; }
     bf16_t* c = (bf16_t*)ctx;
-    // 64 queries per wave when there are enough query blocks to fill the chip, else 32
-    int qw = ((long)((T + 255) / 256) * SYL_HEADS * B >= 512) ? 2 : 1;
+    // 32 queries per wave (106 VGPRs, four waves per SIMD) is the faster shape inside the forward at every length
+    // measured (10 s batch 0.409 vs 0.429 ms per forward, 8 x 60 s 2.71 vs 2.95); 64 per wave stays selectable
+    int qw = 1;
     if (force_qw == 1 || force_qw == 2) qw = force_qw;
     const dim3 grid((qw == 2 ? (T + 255) / 256 : (T + 127) / 128) * SYL_HEADS * B);
     if (ctx_scale) {

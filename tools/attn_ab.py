@@ -21,5 +21,5 @@ for B, secs in [(32, 10), (8, 60)]:
         T = e.num_frames(secs * 16000)
         fl = 9 * 4.0 * T * T * 64 * 12 * B
         print("B=%d %ds qw=%s: attention %.3f ms/forward  %.0f TF   max|h - h(default)| %.2e" % (
-            B, secs, qw or "ping-pong", p["attention"] / 5, fl / (p["attention"] / 5 * 1e-3) / 1e12, (h - ref).abs().max().item()))
+            B, secs, qw or "auto", p["attention"] / 5, fl / (p["attention"] / 5 * 1e-3) / 1e12, (h - ref).abs().max().item()))
         del e
