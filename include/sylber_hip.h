@@ -155,10 +155,11 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
 /* Tuning / test overrides, scoped to ONE handle (nothing process-global); value < 0 or 0 restores the automatic choice.
  *   SYLBER_OPT_GEMM_TILE               tile configuration id of the bf16 GEMM launches (csrc/gemm_bf16.hip launch_t:
  *                                      0 = 256x128, 3 = 128x128, 4 = 128x192, 10 = 256x256 8-wave, 11 = 256x192 8-wave)
- *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   32 or 64
- *   SYLBER_OPT_GEMM_PERSISTENT         k > 0: 4-wave GEMM launches of k x 256 persistent workgroups walking the tile list;
- *                                      k < 0: additionally run the 256x256 kernel one tile per workgroup instead of its
- *                                      persistent form with cross-tile operand prefetch (A/B switch) */
+ *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   32 (automatic choice) or 64
+ *   SYLBER_OPT_GEMM_PERSISTENT         0 (automatic): GEMM launches of more than one round run as persistent workgroups
+ *                                      walking the tile list (4-wave kernels: two per CU; the 256x256 kernel: one per CU
+ *                                      with cross-tile operand prefetch); k > 0: k workgroups per CU for the 4-wave
+ *                                      kernels; k < 0: one workgroup per tile everywhere (A/B switch) */
 enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3 };
 int sylber_set_option(sylber_t h, int32_t key, int32_t value);
 
