@@ -46,15 +46,11 @@ def main(src, dst):
     if tot_slots:
         out += ["", "GEMM family (all `gemm*_bf16_kernel` launches): MfmaUtil %.1f %% of the GRBM cycles they were resident." % (100 * tot_busy / tot_slots),
                 "",
-                "Reading the two clocks together: the in-kernel cycle counter (`s_memtime`, `tools/gemm_bench_one.py ... 16010`) sees a conv1",
-                "tile take 5.7 k (prologue) + 64.2 k (48 K steps) + 17.5 k (epilogue) = 87 k SHADER cycles, of which the matrix pipe is busy",
-                "49 k (56 %; 81 % inside the K loop) - but 15.6 rounds x 87 k cycles in 1107 us is a shader clock of only ~1.25 GHz, while",
-                "GRBM_GUI_ACTIVE advances at ~2.0 GHz over the same dispatch.  SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles, GRBM_GUI_ACTIVE",
-                "does not stop when the power manager withholds shader clocks: MfmaUtil above (41 % for the 8-wave kernel) x 2.0 / 1.3 ~ 60 % of",
-                "the shader cycles that actually ran.  I.e. roughly one third of the nominal cycles is lost to the power limit under this",
-                "MFMA + LDS + LDS-DMA mix (`tools/ubench/clock_calib.hip`: s_memtime IS the shader clock - 2.396 GHz on an idle chip, 2.2 GHz",
-                "under a dependent-MFMA load on every SIMD; an MFMA-only loop on this box sustains 1.75-1.93 PF = 70-77 % of the 2.4 GHz peak,",
-                "profiles/r01_mfma_ceiling.md), and the remaining gap to the 2.5 PF roofline is prologue / epilogue time at K = 768-1536."]
+                "Reading: MfmaUtil x 2.5 PF is what the matrix pipe delivered while the kernel was resident (the implied column, which agrees",
+                "with algorithmic FLOPs / rocprofv3 duration); the effective clock column shows the chip holding 1.75-1.95 GHz under the big",
+                "256x256 tiles and ~2.3 GHz under the lighter kernels, against the 2.4 GHz the 2.5 PF peak assumes.  The round-1 in-kernel",
+                "cycle counters (81 % matrix-pipe occupancy inside the K loop, profiles/r01_mfma_util.md) were removed from the shipping kernels",
+                "in round 2; the gap between K-loop occupancy and MfmaUtil is prologue / epilogue time at K = 768-1536 plus withheld clocks."]
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
