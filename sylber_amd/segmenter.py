@@ -312,20 +312,23 @@ class Segmenter:
         hidden, _ = self.encode_batch(batch_wavs)
         seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold)
         # D2H: the hidden states (the bulk) leave asynchronously into pinned memory while the host waits for the
-        # segment counts; segments / features are then trimmed to the batch's largest count and follow the same way
-        hid_pin = self._pinned("hidden", tuple(hidden.shape), torch.float32)
+        # segment counts; segments / features are then trimmed to the batch's largest count and follow the same way.
+        # The pinned blocks come from torch's caching host allocator and are HANDED to the caller (the numpy arrays
+        # below are views that keep them alive; a dropped result returns its block to the cache) -- no second host
+        # copy of the 49 MB of hidden states per 32 x 10 s batch.
+        hid_pin = torch.empty(tuple(hidden.shape), dtype=torch.float32, pin_memory=True)
         hid_pin.copy_(hidden, non_blocking=True)
         nseg_h = nseg.cpu().numpy()
         nmax = int(nseg_h.max()) if len(nseg_h) else 0
         k = max(nmax, 1)
-        seg_pin = self._pinned("seg", (seg.shape[0], k, 2), torch.int64)
-        feat_pin = self._pinned("feat", (feats.shape[0], k, feats.shape[2]), torch.float32)
+        seg_pin = torch.empty((seg.shape[0], k, 2), dtype=torch.int64, pin_memory=True)
+        feat_pin = torch.empty((feats.shape[0], k, feats.shape[2]), dtype=torch.float32, pin_memory=True)
         seg_pin.copy_(seg[:, :k], non_blocking=True)
         feat_pin.copy_(feats[:, :k], non_blocking=True)
         torch.cuda.current_stream(hidden.device).synchronize()
-        hidden_h = hid_pin.numpy().copy()                  # the caller owns its arrays; the staging buffers are reused
-        seg_h = seg_pin.numpy().copy()
-        feats_h = feat_pin.numpy().copy()
+        hidden_h = hid_pin.numpy()
+        seg_h = seg_pin.numpy()
+        feats_h = feat_pin.numpy()
         outputs = []
         for i in range(hidden_h.shape[0]):
             n = int(nseg_h[i])
