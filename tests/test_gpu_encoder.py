@@ -172,3 +172,46 @@ def test_random_ragged_batches_vs_oracle(enc, sd, seed):
     assert got.shape == ref.shape and np.isfinite(got).all()
     for i in range(B):
         assert rel_rms(got[i], ref[i]) < STAGE_TOL["hidden"], (i, lens)
+
+
+def test_more_than_512_utterances_per_batch(enc):
+    """B > 512 (the valid-frame table reaches the device 512 utterances per launch; every grid scales with B): rows of a
+    600-clip ragged batch equal the same clips run in a small batch with the same padded length, bitwise."""
+    B, L = 600, 8000
+    rng = np.random.default_rng(11)
+    x = noise_batch(B, L, seed=12)
+    lengths = [int(v) for v in rng.integers(400, L + 1, size=B)]
+    lengths[0] = L
+    for i, n in enumerate(lengths):
+        x[i, n:] = 0
+    x = x.cuda()
+    full = enc.forward(x, lengths).cpu().numpy()
+    assert np.isfinite(full).all()
+    pick = [0, 1, 511, 512, 513, 599]
+    small = enc.forward(x[pick].contiguous(), [lengths[i] for i in pick]).cpu().numpy()
+    for j, i in enumerate(pick):
+        assert np.array_equal(full[i], small[j]), i
+    seg, nseg, feats = enc.segment(torch.from_numpy(full).cuda(), 2.6, 0.8)
+    seg2, nseg2, _ = enc.segment(torch.from_numpy(small).cuda(), 2.6, 0.8)
+    nseg, nseg2 = nseg.cpu().numpy(), nseg2.cpu().numpy()
+    for j, i in enumerate(pick):
+        assert nseg[i] == nseg2[j]
+        assert torch.equal(seg[i, : nseg[i]], seg2[j, : nseg2[j]])
+
+
+def test_nan_utterance_does_not_leak_into_neighbours(enc):
+    """Utterances are independent units: a NaN waveform poisons its own row only, and the segmenter still terminates on
+    it with the reference's answer for NaN states (every comparison false -> no speech frame -> no segment)."""
+    from oracle import segment_oracle
+    x = noise_batch(3, 16000, seed=21)
+    clean = enc.forward(x.cuda()).cpu().numpy()
+    x[1, 100:200] = float("nan")
+    h = enc.forward(x.cuda()).cpu().numpy()
+    assert np.array_equal(h[0], clean[0]) and np.array_equal(h[2], clean[2])
+    assert np.isnan(h[1]).any()
+    seg, nseg, _ = enc.segment(torch.from_numpy(h).cuda(), 2.6, 0.8)
+    nseg = nseg.cpu().numpy()
+    for i in range(3):
+        ref = segment_oracle.get_segment(np.ascontiguousarray(h[i]), 2.6, 0.8).reshape(-1, 2)
+        assert nseg[i] == len(ref)
+        assert np.array_equal(seg[i, : nseg[i]].cpu().numpy(), ref)
