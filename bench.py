@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--exchange-selftest", action="store_true",
                     help="N = 1 only: run the N>1 code path (one-rank RCCL communicator, scatter / gather to self inside every "
                          "step) -- the only way to exercise it on a one-GPU box; the line is labelled accordingly")
+    ap.add_argument("--exchange-timeout", type=int, default=180,
+                    help="watchdog for the exchange phase (s): on expiry rank 0 prints the resident-shard line with `exchange_error`")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
     ap.add_argument("--agreement-clips", type=int, default=0,
                     help="also report bf16-vs-fp32 segment agreement on this many synthetic clips (fp32 parity mode as truth)")
@@ -328,27 +330,74 @@ def main():
             evs.append(ev)
         return evs
 
-    exchange_first = (world > 1 and not args.no_exchange) or selftest
+    ex_txt = "root scatter + gather over RCCL in every step (run_stream: gather(i) overlapped with compute(i+1))"
+    res_txt = "shards resident per rank, no data-path collective"
+
+    def build_line(value_, elapsed_, med_, exchange_first_, roofline_=None, frontend_=None, cpu_=None, api_=None, kernels_=None,
+                   seg_stats_=None):
+        dtype = {"bf16": "bf16", "fp8": "bf16 + mxfp8 (e4m3, E8M0 block scales) weight GEMMs", "fp32": "f32", "fp16": "f16 (IEEE half operands, f32 accumulate)"}[args.precision]
+        line = {
+            "metric": "audio-sec/s encoded (sylber_base, 16 kHz, batched 10 s clips)",
+            "value": round(value_, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed_ / args.steps, 3),
+            "ms_per_step_median": None if med_ is None else round(med_, 3),
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "Segmenter forward (conv frontend + HuBERT-9L encoder + boundary detection + "
+                                   "segment mean-pool), batch %d x %g s 16 kHz random waveforms per GPU, random-init "
+                                   "sylber_base weights (BASELINE.json configs[1]%s)" % (B, clip_seconds, "; configs[2] sharding" if world > 1 else ""),
+                       "global_batch": world * B, "clip_seconds": clip_seconds,
+                       "ragged": ("lengths U[2 s, %g s], %.1f valid s of %g padded s per batch" % (clip_seconds, valid_seconds, B * clip_seconds))
+                                 if args.ragged else None, "frames_per_clip": T_frames,
+                       "parallelism": "utterance-sharded x%d, %s%s" % (world, ex_txt if exchange_first_ else res_txt,
+                                                                        " [one-rank RCCL self-test of the N>1 path]" if selftest else ""),
+                       "rccl_ranks": rccl_ranks,
+                       "pipelining": "%d batch(es) in flight on independent handles/streams%s" % (
+                           NPIPE, "" if (exchange_first_ or args.no_overlap) else "; segmenter on a side stream"),
+                       "gflop_per_clip": 124.65 if clip_samples == CLIP_SAMPLES else None},
+            "roofline": roofline_, "roofline_frontend": frontend_, "cpu_baseline": cpu_, "api_level": api_,
+            "kernel_ms_per_forward": kernels_ or {},
+            "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2), "segments_per_clip": seg_stats_,
+        }
+        return line
+
+    # Resident shards are ALWAYS measured first; the exchange (the default N > 1 step) is measured after them under a
+    # watchdog: the RCCL path cannot be exercised on the one-GPU development boxes beyond a one-rank group, so if its
+    # first multi-GPU run hangs in a collective, rank 0 still prints a contract-complete line (resident-shard value,
+    # "exchange_error" saying what happened) instead of losing the whole measurement.
+    want_exchange = world > 1 or selftest                      # --no-exchange only swaps which figure is `value`
+    r_elapsed, r_med = timed(resident_steps)
+    total_audio = world * valid_seconds * args.steps           # (ragged: rank 0's draw stands for every rank)
+    elapsed, med_ms = r_elapsed, r_med
+    exchange_first = False
     secondary = None
     exchange_error = None
-    if exchange_first:
+    if want_exchange:
+        import threading
+
+        def on_timeout():
+            if rank == 0:
+                fb = build_line(total_audio / r_elapsed, r_elapsed, r_med, False)
+                fb["exchange_error"] = "exchange phase did not finish within %d s (watchdog); value = resident shards" % args.exchange_timeout
+                sys.stdout.flush()
+                print(json.dumps(fb), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.exchange_timeout + (0 if rank == 0 else 5), on_timeout)
+        dog.daemon = True
+        dog.start()
         try:
-            elapsed, med_ms = timed(exchange_steps)
+            x_elapsed, x_med = timed(exchange_steps)
+            if args.no_exchange and not selftest:
+                secondary = ("exchange", x_elapsed, x_med)
+            else:
+                elapsed, med_ms = x_elapsed, x_med
+                exchange_first = True
+                secondary = ("resident_shards", r_elapsed, r_med)
         except Exception as e:  # noqa: BLE001 - keep a measurable line; the failure is reported in the line itself
             exchange_error = "%s: %s" % (type(e).__name__, e)
-            exchange_first = False
-    if exchange_first:
-        r_elapsed, r_med = timed(resident_steps)
-        secondary = ("resident_shards", r_elapsed, r_med)
-    else:
-        elapsed, med_ms = timed(resident_steps)
-        if world > 1 and exchange_error is None:
-            try:
-                x_elapsed, x_med = timed(exchange_steps)
-                secondary = ("exchange", x_elapsed, x_med)
-            except Exception as e:  # noqa: BLE001
-                exchange_error = "%s: %s" % (type(e).__name__, e)
-    total_audio = world * valid_seconds * args.steps           # (ragged: rank 0's draw stands for every rank)
+        finally:
+            dog.cancel()
     value = total_audio / elapsed
 
     # ---- per-kernel device time with HIP events on the launch stream (separate pass: event records
@@ -459,32 +508,7 @@ def main():
         nn_ = nseg_t.float()
         seg_stats = {"mean": round(float(nn_.mean()), 1), "min": int(nn_.min()), "max": int(nn_.max())}
     if rank == 0:
-        dtype = {"bf16": "bf16", "fp8": "bf16 + mxfp8 (e4m3, E8M0 block scales) weight GEMMs", "fp32": "f32", "fp16": "f16 (IEEE half operands, f32 accumulate)"}[args.precision]
-        ex_txt = "root scatter + gather over RCCL in every step (run_stream: gather(i) overlapped with compute(i+1))"
-        res_txt = "shards resident per rank, no data-path collective"
-        line = {
-            "metric": "audio-sec/s encoded (sylber_base, 16 kHz, batched 10 s clips)",
-            "value": round(value, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "ms_per_step_median": None if med_ms is None else round(med_ms, 3),
-            "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "Segmenter forward (conv frontend + HuBERT-9L encoder + boundary detection + "
-                                   "segment mean-pool), batch %d x %g s 16 kHz random waveforms per GPU, random-init "
-                                   "sylber_base weights (BASELINE.json configs[1]%s)" % (B, clip_seconds, "; configs[2] sharding" if world > 1 else ""),
-                       "global_batch": world * B, "clip_seconds": clip_seconds,
-                       "ragged": ("lengths U[2 s, %g s], %.1f valid s of %g padded s per batch" % (clip_seconds, valid_seconds, B * clip_seconds))
-                                 if args.ragged else None, "frames_per_clip": T_frames,
-                       "parallelism": "utterance-sharded x%d, %s%s" % (world, ex_txt if exchange_first else res_txt,
-                                                                        " [one-rank RCCL self-test of the N>1 path]" if selftest else ""),
-                       "rccl_ranks": rccl_ranks,
-                       "pipelining": "%d batch(es) in flight on independent handles/streams%s" % (
-                           NPIPE, "" if (exchange_first or args.no_overlap) else "; segmenter on a side stream"),
-                       "gflop_per_clip": 124.65 if clip_samples == CLIP_SAMPLES else None},
-            "roofline": roofline, "roofline_frontend": frontend, "cpu_baseline": cpu, "api_level": api,
-            "kernel_ms_per_forward": kernels,
-            "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2), "segments_per_clip": seg_stats,
-        }
+        line = build_line(value, elapsed, med_ms, exchange_first, roofline, frontend, cpu, api, kernels, seg_stats)
         if secondary is not None:
             name, s_el, s_med = secondary
             line[name] = {"value": round(total_audio / s_el, 1), "unit": "audio-sec/s",
