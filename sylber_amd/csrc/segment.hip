@@ -13,7 +13,8 @@
 //   * 1-D cossim uses numpy-scalar `** .5` = glibc powf (powf_half.h); 2-D cossim uses sqrtf.
 //   * mean(0) accumulates rows sequentially from +0, then divides by f32(n).
 // Phase 1 (greedy scan) is inherently sequential over frames and runs on wave 0 with frames prefetched
-// four ahead; norms, phase 2 (means, window similarities, sweep) and the pooling use all 256 threads.
+// four ahead; norms, phase 2 (means, window similarities, sweep) and the pooling use all 256 threads
+// (pooling: one segment per wave).
 #pragma clang fp contract(off)
 #include "kernels.h"
 #include "powf_half.h"
@@ -92,17 +93,24 @@ __device__ float np_sum_thread(const float* a, int n) {
     return 0.0f + val[0];
 }
 
-// states[s:e].mean(0) for dims tid, tid+256, tid+512 -> dst (LDS or global)
-__device__ __forceinline__ void mean_rows3(const float* __restrict__ states, int s, int e, int tid, float* dst) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    const float* p = states + (size_t)s * SEG_D + tid;
-#pragma unroll 4
+// states[s:e].mean(0) -> dst (LDS or global) by a group of NT threads (id 0..NT-1), thread id owning dims id + NT*j:
+// rows accumulated sequentially from +0, then one division by f32(n) -- numpy's mean(0) per element
+template <int NT>
+__device__ __forceinline__ void mean_rows(const float* __restrict__ states, int s, int e, int id, float* dst) {
+    constexpr int ND = SEG_D / NT;
+    float a[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) a[j] = 0.f;
+    const float* p = states + (size_t)s * SEG_D + id;
+#pragma unroll 2
     for (int r = s; r < e; ++r) {
-        a0 = a0 + p[0]; a1 = a1 + p[256]; a2 = a2 + p[512];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) a[j] = a[j] + p[NT * j];
         p += SEG_D;
     }
     const float n = (float)(e - s);
-    dst[tid] = a0 / n; dst[tid + 256] = a1 / n; dst[tid + 512] = a2 / n;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) dst[id + NT * j] = a[j] / n;
 }
 
 // GS = false: all bookkeeping lives in LDS (dynamic, sized by T): the refinement loop is a chain of dependent reads of
@@ -133,12 +141,22 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* states = hidden + (size_t)b * T * SEG_D;
 
-    // ---- phase 0: frame norms
-    for (int i = wave; i < T; i += 4) {
-        float x[12];
-        load_pw(states + (size_t)i * SEG_D, lane, x);
-        const float ss = pw_dot(x, x) + 1e-8f;
-        if (lane == 0) { nsq[i] = sqrtf(ss); npw[i] = powf_half_glibc(ss); }
+    // ---- phase 0: frame norms.  Row sums with four rows per wave in flight; the square root and the ~600-cycle glibc
+    // powf are then evaluated one ROW PER THREAD (as a per-row tail of the loop they ran once per row on a whole wave)
+    for (int i0 = 4 * wave; i0 < T; i0 += 16) {
+        float x[4][12];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load_pw(states + (size_t)(i0 + r < T ? i0 + r : T - 1) * SEG_D, lane, x[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ss = pw_dot(x[r], x[r]) + 1e-8f;
+            if (lane == 0 && i0 + r < T) nsq[i0 + r] = ss;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < T; i += 256) {
+        const float ss = nsq[i];
+        nsq[i] = sqrtf(ss); npw[i] = powf_half_glibc(ss);
     }
     for (int i = tid; i <= T; i += 256) merged[i] = 0;
     __syncthreads();
@@ -149,14 +167,17 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
         float c[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) c[i] = 0.f;
-        float xa[12], xb[12], xc[12], xd[12];
-        // frames are processed in groups of 4 with the next group already in flight
+        // frames are processed in groups of 4 with the next group already in flight (two groups ahead measured slower:
+        // the scan is bound by its dependent arithmetic, not by memory)
+        float g0[4][12], g1[4][12];
         const int T4 = (T + 3) & ~3;
-        auto ld = [&](int i, float (&x)[12]) { load_pw(states + (size_t)(i < T ? i : T - 1) * SEG_D, lane, x); };
-        ld(0, xa); ld(1, xb); ld(2, xc); ld(3, xd);
+        auto ldg = [&](int i, float (&g)[4][12]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) load_pw(states + (size_t)(i + r < T ? i + r : T - 1) * SEG_D, lane, g[r]);
+        };
+        ldg(0, g0);
         for (int i0 = 0; i0 < T4; i0 += 4) {
-            float na[12], nb[12], nc[12], nd[12];
-            ld(i0 + 4, na); ld(i0 + 5, nb); ld(i0 + 6, nc); ld(i0 + 7, nd);
+            ldg(i0 + 4, g1);
             auto step = [&](int i, const float (&x)[12]) {
                 if (i >= T) return;
                 const bool speech = nsq[i] >= norm_thr;
@@ -181,9 +202,32 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
                     else if (est < merge_thr - 1e-4f) merge = false;
                     else merge = (dot / powf_half_glibc(cc) / npw[i]) >= merge_thr;   // also taken for NaN
                     if (merge) {
+                        // c = (c * n + x) / (n + 1), twelve IEEE divisions by the same small integer per frame: ~140 of
+                        // the ~250 instructions of a merge step.  Same quotients, bit for bit, from ONE division:
+                        // r = RN(1 / c1) (IEEE), q0 = a r, then two residual corrections q <- fma(fma(-q, c1, a), r, q)
+                        // (Markstein: with r correctly rounded and q faithful, the corrected quotient is RN(a / c1);
+                        // checked against a / c1 for every divisor <= 8192 x 3.2e8 dividends on the CPU, 0 mismatches).
+                        // Dividends that are zero, below 2^-100 (inexact residuals) or non-finite take the division.
                         const float cf = (float)seg_cnt, c1 = (float)(seg_cnt + 1);
+                        const float r = 1.0f / c1;
+                        float a[12];
+                        float amin = INFINITY, amax = 0.f;
 #pragma unroll
-                        for (int k = 0; k < 12; ++k) c[k] = (c[k] * cf + x[k]) / c1;
+                        for (int k = 0; k < 12; ++k) {
+                            a[k] = c[k] * cf + x[k];
+                            amin = fminf(amin, fabsf(a[k])); amax = fmaxf(amax, fabsf(a[k]));
+                        }
+                        if (__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f) || !(amax <= 0x1p126f))) {
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) c[k] = a[k] / c1;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) {
+                                const float q0 = a[k] * r;
+                                const float q1 = fmaf(fmaf(-q0, c1, a[k]), r, q0);
+                                c[k] = fmaf(fmaf(-q1, c1, a[k]), r, q1);
+                            }
+                        }
                         seg_cnt += 1;
                     } else {
 #pragma unroll
@@ -195,9 +239,11 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
                     }
                 }
             };
-            step(i0, xa); step(i0 + 1, xb); step(i0 + 2, xc); step(i0 + 3, xd);
+            step(i0, g0[0]); step(i0 + 1, g0[1]); step(i0 + 2, g0[2]); step(i0 + 3, g0[3]);
 #pragma unroll
-            for (int k = 0; k < 12; ++k) { xa[k] = na[k]; xb[k] = nb[k]; xc[k] = nc[k]; xd[k] = nd[k]; }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 12; ++k) g0[r][k] = g1[r][k];
         }
         if (s > -1) { if (lane == 0) { seg[2 * nseg] = s; seg[2 * nseg + 1] = T; } ++nseg; }
         if (lane == 0) { sh_i[0] = nseg; sh_i[1] = nmid; }
@@ -211,8 +257,16 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
         if (si >= nseg - 1) continue;
         const int a0 = seg[2 * si], a1 = seg[2 * si + 1];
         const int b0 = seg[2 * si + 2], b1 = seg[2 * si + 3];
-        mean_rows3(states, a0, a1, tid, ca_s);
-        mean_rows3(states, b0, b1, tid, cb_s);
+        // the window of the sweep depends on the segment table only, so this wave's first window row is requested now and
+        // arrives under the centroid means (one global round trip per boundary instead of two)
+        const int la = (a1 - a0) / 2, lb = (b1 - b0) / 2;
+        int ws = bd - (la > 1 ? la : 1); ws = ws < a0 ? a0 : ws;
+        int we = bd + (lb > 1 ? lb : 1); we = we > b1 ? b1 : we;
+        const int w = we - ws;
+        float xw[12];
+        load_pw(states + (size_t)(wave < w ? ws + wave : a0) * SEG_D, lane, xw);
+        if (tid < 128) mean_rows<128>(states, a0, a1, tid, ca_s);          // the two centroids concurrently, one per
+        else mean_rows<128>(states, b0, b1, tid - 128, cb_s);              // half workgroup
         __syncthreads();
         float ca[12], cb[12];
         load_pw(ca_s, lane, ca);
@@ -225,14 +279,13 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
             __syncthreads();
             continue;
         }
-        const int la = (a1 - a0) / 2, lb = (b1 - b0) / 2;
-        int ws = bd - (la > 1 ? la : 1); ws = ws < a0 ? a0 : ws;
-        int we = bd + (lb > 1 ? lb : 1); we = we > b1 ? b1 : we;
-        const int w = we - ws;
         const float nca = sqrtf(saa), ncb = sqrtf(sbb);
         for (int j = wave; j < w; j += 4) {
             float x[12];
-            load_pw(states + (size_t)(ws + j) * SEG_D, lane, x);
+            if (j == wave) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) x[k] = xw[k];
+            } else load_pw(states + (size_t)(ws + j) * SEG_D, lane, x);
             const float nx = nsq[ws + j];
             const float sp = pw_dot(x, ca) / nx / nca;
             const float sn = pw_dot(x, cb) / nx / ncb;
@@ -274,8 +327,8 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
     __syncthreads();
     if (feat_out) {
         const int n = sh_i[2];
-        for (int k = 0; k < n; ++k)
-            mean_rows3(states, mid[2 * k], mid[2 * k + 1], tid, feat_out + ((size_t)b * T + k) * SEG_D);
+        for (int k = wave; k < n; k += 4)                                   // one segment per wave, four in flight
+            mean_rows<64>(states, mid[2 * k], mid[2 * k + 1], lane, feat_out + ((size_t)b * T + k) * SEG_D);
     }
 }
 
