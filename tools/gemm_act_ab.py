@@ -1,4 +1,5 @@
 """Same GEMM launch with and without the GELU epilogue (what the activation costs; development aid)."""
+import ctypes, sys, os
 sys.path.insert(0, os.getcwd())
 from sylber_amd import _lib
 lib = _lib.load()
