@@ -162,3 +162,13 @@ def test_tensor_native_segment_api(S, sd):
     # precomputed features + explicit thresholds; a threshold nobody reaches gives the single zero row
     f2, seg2, avg2 = S.segment(features=feats, normthreshold=1e9, mergethreshold=0.5)
     assert all(s.shape == (0,) for s in seg2) and avg2.shape == (3, 1, 768) and float(avg2.abs().sum()) == 0.0
+
+
+def test_two_and_a_half_minute_utterance(S):
+    """One 150 s utterance (7499 frames): beyond the 78.8 s the segmenter keeps in LDS, far beyond any length the encoder
+    kernels were tuned on; the API contract holds and the segments are the reference algorithm's on the returned states."""
+    x = syllable_wave(150 * 16000, 31)
+    out = S(wav=x, in_second=False)
+    assert out["hidden_states"].shape == (7499, 768) and np.isfinite(out["hidden_states"]).all()
+    assert len(out["segments"]) > 100
+    _segments_consistent(out, S)
