@@ -216,14 +216,23 @@ __global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(co
                 }
                 const float mb = m_run[qs] * LOG2E;
                 float psum = 0.f;
+                // P is converted in PAIRS (one v_cvt_pk per two scores) and, in the fp16 format, without the saturating
+                // clamp every other conversion carries: 0 <= p <= 2^8 by construction of the lazy maximum
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) {
+                    uint32_t pw[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qs][8 * j + e], LOG2E, -mb));
-                        psum += p;
-                        pf[qs][j][e] = __builtin_bit_cast(__bf16, H16<FMT>::cvt(p));
+                    for (int e = 0; e < 8; e += 2) {
+                        const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[qs][8 * j + e], LOG2E, -mb));
+                        const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[qs][8 * j + e + 1], LOG2E, -mb));
+                        psum += p0;
+                        psum += p1;
+                        pw[e >> 1] = H16<FMT>::pack2_bounded(p0, p1);
                     }
+                    typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4)));
+                    const u32x4v_t pv = {pw[0], pw[1], pw[2], pw[3]};
+                    pf[qs][j] = __builtin_bit_cast(bf16x8_t, pv);
+                }
                 l_run[qs] += psum;
             }
             // O^T += V^T . P^T for these 32 keys (two 16-key groups x two 32-wide d blocks; a V^T fragment feeds QW MFMAs)

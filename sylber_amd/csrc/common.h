@@ -52,6 +52,7 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 template <int FMT> struct H16 {
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    static __device__ __forceinline__ uint32_t pack2_bounded(float lo, float hi) { return pack_bf16x2(lo, hi); }   // |x| known < 65504
     static __device__ __forceinline__ bf16_t cvt(float f) { return f2bf_dev(f); }
     static __device__ __forceinline__ float up(bf16_t h) { return bf2f(h); }
     static __device__ __forceinline__ f32x16_t mfma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
@@ -63,6 +64,11 @@ template <> struct H16<FMT_F16> {
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         typedef float f32pair_t __attribute__((ext_vector_type(2)));
         const f32pair_t v = {sat(lo), sat(hi)};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+    }
+    static __device__ __forceinline__ uint32_t pack2_bounded(float lo, float hi) {
+        typedef float f32pair_t __attribute__((ext_vector_type(2)));
+        const f32pair_t v = {lo, hi};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
     }
     static __device__ __forceinline__ bf16_t cvt(float f) { return __builtin_bit_cast(unsigned short, (_Float16)sat(f)); }
