@@ -67,7 +67,8 @@ struct GraphEntry { int B, Lmax, stop_stage; const void* in; void* out; hipGraph
 
 struct sylber_ctx {
     int device = 0, precision = 0, num_layers = 9;
-    int fmt = FMT_BF16;           // 16-bit operand format of the MFMA path
+    int fmt = FMT_BF16;           // 16-bit operand format of the MFMA path (encoder)
+    int fmt_conv = FMT_BF16;      // ... of the conv stack (differs from fmt only for SYLBER_MIXED16)
     // weights
     char* wbase = nullptr; size_t wbytes = 0;
     char* f8base = nullptr; size_t f8bytes = 0;
@@ -111,14 +112,15 @@ struct Packer {
 extern "C" int sylber_create(const SylberWeights* w, int device, int precision, sylber_t* out) {
     if (!w || !out) { syl_set_error("sylber_create", "null argument"); return 1; }
     if (w->num_layers < 1 || w->num_layers > SYLBER_MAX_LAYERS) { syl_set_error("sylber_create", "num_layers out of range"); return 1; }
-    if (precision != SYLBER_BF16 && precision != SYLBER_FP32 && precision != SYLBER_FP8 && precision != SYLBER_FP16) { syl_set_error("sylber_create", "unknown precision"); return 1; }
+    if (precision != SYLBER_BF16 && precision != SYLBER_FP32 && precision != SYLBER_FP8 && precision != SYLBER_FP16 && precision != SYLBER_MIXED16) { syl_set_error("sylber_create", "unknown precision"); return 1; }
     const bool f32 = precision == SYLBER_FP32;
     GUARD_DEVICE(device);
     sylber_ctx* c = new sylber_ctx();
     c->device = device; c->precision = precision; c->num_layers = w->num_layers;
     c->fmt = precision == SYLBER_FP16 ? FMT_F16 : FMT_BF16;
+    c->fmt_conv = (precision == SYLBER_FP16 || precision == SYLBER_MIXED16) ? FMT_F16 : FMT_BF16;
     Packer P;
-    P.fmt = c->fmt;
+    P.fmt = c->fmt_conv;                                 // conv weights first
     size_t o_conv0 = P.add_f32(w->conv_w[0], 512 * 10);
     size_t o_gnw = P.add_f32(w->gn_w, 512), o_gnb = P.add_f32(w->gn_b, 512);
     size_t o_conv[7] = {0};
@@ -132,6 +134,7 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
                 for (int j = 0; j < k; ++j) tmp[((size_t)o * k + j) * 512 + cc] = w->conv_w[i][((size_t)o * 512 + cc) * k + j];
         o_conv[i] = f32 ? P.add_f32(tmp.data(), tmp.size()) : P.add_bf16(tmp.data(), tmp.size());
     }
+    P.fmt = c->fmt;                                      // everything after the conv stack
     size_t o_fplw = P.add_f32(w->fp_ln_w, 512), o_fplb = P.add_f32(w->fp_ln_b, 512);
     size_t o_fpw = f32 ? P.add_f32(w->fp_w, 768 * 512) : P.add_bf16(w->fp_w, 768 * 512), o_fpb = P.add_f32(w->fp_b, 768);
     size_t o_posw;
@@ -436,28 +439,28 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     // ---- conv layer 0 + GroupNorm + GELU
     RUN("conv0_stats", launch_conv0_stats(wav_dev, B, Lmax, p.L[0], part, p.nchunk, s));
     RUN("conv0_finalize", launch_conv0_finalize(part, p.nchunk, c->conv0_w, c->gn_w, c->gn_b, B, p.L[0], ss, s));
-    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s, c->fmt));
+    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s, c->fmt_conv));
     // ---- conv layers 1..6 as implicit GEMM (ping-pong)
     bf16_t* src = bufA; bf16_t* dst = bufB;
     for (int i = 1; i < 7; ++i) {
         GemmArgs a = {};
         a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w[i];
         a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = ACT_GELU_FAST;
-        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.fmt = c->fmt;
+        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.fmt = c->fmt_conv;
         static const char* nm[7] = {"", "gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_conv6"};
         RUN(nm[i], launch_gemm_bf16(EPI_BF16, a, s));
         bf16_t* t = src; src = dst; dst = t;
     }
     bf16_t* feats = src;   // [B*Tp][512]
     if (c->stop_stage == 1) {
-        RUN("copy_out", launch_bf16_to_f32_rows(feats, 512, hidden_dev, B, p.Tp, p.T, 512, s, c->fmt));
+        RUN("copy_out", launch_bf16_to_f32_rows(feats, 512, hidden_dev, B, p.Tp, p.T, 512, s, c->fmt_conv));
         return 0;
     }
     // ---- feature projection: LN(512) -> Linear(512->768), zero padded frames
     {
         LnArgs a = {};
         a.in = feats; a.in_bf16 = 1; a.ld_in = 512; a.gamma = c->fp_ln_w; a.beta = c->fp_ln_b;
-        a.out_bf16 = ln512; a.ld_bf16 = 512; a.M = M; a.D = 512; a.fmt = c->fmt;
+        a.out_bf16 = ln512; a.ld_bf16 = 512; a.M = M; a.D = 512; a.fmt = c->fmt; a.fmt_in = c->fmt_conv;
         RUN("ln512", launch_layernorm(a, s));
         GemmArgs g = {};
         g.X = ln512; g.ldx = 512; g.W = c->fp_w; g.M = M; g.N = 768; g.K = 512; g.bias = c->fp_b;
@@ -475,7 +478,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     uint8_t* ffn8 = (uint8_t*)ffn; uint8_t* ffn8s = ffn8 + (((size_t)M * 3072 + 255) & ~(size_t)255);  // 96 Mp bytes
     auto run_ln = [&](const float* gam, const float* bet, bool last, bool to_fp8 = false) -> int {
         LnArgs a = {};
-        a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = M; a.D = 768; a.fmt = c->fmt;
+        a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = M; a.D = 768; a.fmt = c->fmt; a.fmt_in = c->fmt;
         if (last) { a.out_f32 = hidden_dev; a.ld_f32 = 768; a.Tp = p.Tp; a.T = p.T; }
         else if (to_fp8) { a.out_fp8 = h8; a.ld_fp8 = 768; a.out_scale = h8s; a.scale_rows = Mp; a.out_stats = stats; }
         else { a.out_bf16 = hbf; a.ld_bf16 = 768; a.out_stats = stats; }   // no fp32 copy: see EPI_F32_RESLN

@@ -185,7 +185,7 @@ int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, cons
 #ifndef LN_ROWS
 #define LN_ROWS 1
 #endif
-template <int D, bool IN_BF16, int FMT>
+template <int D, bool IN_BF16, int FMT, int FMT_IN = FMT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     constexpr int V = D / 256;   // float4 groups per lane (2 for 512, 3 for 768)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
         const int c = i * 256 + lane * 4;
         if constexpr (IN_BF16) {
             const uint2 raw = *(const uint2*)((const bf16_t*)a.in + (size_t)m * a.ld_in + c);
-            x[i][0] = H16<FMT>::up((bf16_t)(raw.x & 0xffff)); x[i][1] = H16<FMT>::up((bf16_t)(raw.x >> 16));
-            x[i][2] = H16<FMT>::up((bf16_t)(raw.y & 0xffff)); x[i][3] = H16<FMT>::up((bf16_t)(raw.y >> 16));
+            x[i][0] = H16<FMT_IN>::up((bf16_t)(raw.x & 0xffff)); x[i][1] = H16<FMT_IN>::up((bf16_t)(raw.x >> 16));
+            x[i][2] = H16<FMT_IN>::up((bf16_t)(raw.y & 0xffff)); x[i][3] = H16<FMT_IN>::up((bf16_t)(raw.y >> 16));
         } else {
             const float4 v = *(const float4*)((const float*)a.in + (size_t)m * a.ld_in + c);
             x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
@@ -274,6 +274,13 @@ static bool launch_ln_fmt(const LnArgs& a, dim3 grid, hipStream_t s) {
 
 int launch_layernorm(const LnArgs& a, hipStream_t s) {
     dim3 grid((a.M + 4 * LN_ROWS - 1) / (4 * LN_ROWS));
+    if (a.in_bf16 && a.fmt_in != a.fmt) {
+        // SYLBER_MIXED16: the one hand-over between the fp16 conv stack and the bf16 encoder (feature-projection LayerNorm)
+        if (a.D != 512 || a.fmt_in != FMT_F16 || a.fmt != FMT_BF16) { syl_set_error("launch_layernorm", "unsupported format pair"); return 1; }
+        hipLaunchKernelGGL((layernorm_kernel<512, true, FMT_BF16, FMT_F16>), grid, dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (a.fmt == FMT_F16 ? launch_ln_fmt<FMT_F16>(a, grid, s) : launch_ln_fmt<FMT_BF16>(a, grid, s)) {}
     else { syl_set_error("launch_layernorm", "D must be 512 or 768"); return 1; }
     HIP_TRY(hipGetLastError());

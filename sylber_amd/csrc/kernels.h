@@ -89,6 +89,7 @@ int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, cons
 struct LnArgs {
     const void* in; int in_bf16; long ld_in;     // in_bf16: the input rows are 16-bit words of format `fmt`
     int fmt;                                      // FMT_BF16 / FMT_F16: format of a 16-bit input and of out_bf16
+    int fmt_in;                                   // format of a 16-bit input when it differs from fmt (set = fmt otherwise)
     const float* res; long ld_res;
     const float* gamma; const float* beta;
     float* out_f32; long ld_f32;

@@ -65,3 +65,26 @@ def test_fp16_conversions_saturate_instead_of_overflowing():
     conv = e16.forward(x, None, stop_stage=1)
     assert bool(torch.isfinite(conv).all())
     assert bool(torch.isfinite(e16.forward(x, None)).all())
+
+
+def test_mixed16_conv_stack_fp16_encoder_bf16(engines, golden_dir):
+    """precision="mixed16" (SYLBER_MIXED16): the conv stack is bit-identical to the fp16 mode's, the encoder stages are
+    within the bf16 tolerance of the reference goldens, and the hidden states are closer to fp32 than bf16's (about half
+    the error: the bf16 encoder contributes the other half, which is why the mode buys little -- DESIGN.md)."""
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.agreement import segment_agreement
+    e16, e32, ebf = engines
+    sd = synthetic_state_dict(0)
+    em = HubertEncoderHIP(sd, precision="mixed16")
+    g = np.load(os.path.join(golden_dir, "encoder_stages.npz"))
+    wav = torch.from_numpy(g["wav"]).cuda()
+    lengths = [int(x) for x in g["lengths"]]
+    assert torch.equal(em.forward(wav, lengths, stop_stage=1), e16.forward(wav, lengths, stop_stage=1))
+    assert rel(em.forward(wav, lengths, stop_stage=2).cpu().numpy(), g["enc_in"]) < 1.0e-2
+    h = em.forward(wav, lengths)
+    assert rel(h.cpu().numpy(), g["layer8"]) < 2.0e-2
+    assert torch.equal(h, em.forward(wav, lengths))
+    am = segment_agreement(sd, em, 32, clip_samples=80000, truth=e32)
+    abf = segment_agreement(sd, ebf, 32, clip_samples=80000, truth=e32)
+    assert am["hidden_rel_rms_vs_fp32"] < 0.75 * abf["hidden_rel_rms_vs_fp32"]
+    assert am["boundary_recall"] > 0.98 and am["boundary_precision"] > 0.98
