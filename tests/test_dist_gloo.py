@@ -70,7 +70,15 @@ def _worker(rank, world, port, q):
             batches.append(b)
     sync = [S.step(b, l) for b, l in zip(batches, lens)]
     streamed = list(S.run_stream(batches, lens, max_segments=64))
+    # a LIST of engines (what bench.py passes: one handle per batch in flight) takes the steps round-robin: same results
+    S2 = ShardedSegmenter([S.engine, OracleEngine(sd)], norm_threshold=2.6, merge_threshold=0.8)
+    streamed2 = list(S2.run_stream(batches, lens, max_segments=64))
     ok = True
+    if rank == 0:
+        for b, c in zip(streamed, streamed2):
+            ok &= all(torch.equal(x, y) for x, y in zip(b, c))
+    else:
+        assert all(x is None for x in streamed2)
     if rank == 0:
         for a, b in zip(sync, streamed):
             k = b[1].shape[1]
