@@ -91,3 +91,32 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "GPU" in r.stderr and '"n_gpus"' not in r.stdout
+
+
+def test_bench_two_rank_control_flow_on_one_gpu():
+    """bench.py's N > 1 path end to end (launcher env, rank-0-only buffers, exchange as the default step with the
+    resident-shard figure next to it, watchdog, ONE JSON line) with two ranks SHARING this box's GPU over gloo
+    (SYLBER_DIST_BACKEND=gloo, a development aid: RCCL refuses two ranks on one device).  The numbers mean nothing; the
+    control flow and the collectives' argument shapes on ranks 0 and 1 are what a one-GPU box cannot otherwise reach."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env["SYLBER_DIST_BACKEND"] = "gloo"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "4", "--clip-seconds", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8
+    assert "exchange_error" not in line
+    assert "root scatter + gather" in line["config"]["parallelism"]
+    assert line["resident_shards"]["value"] > 0 and line["value"] > 0
