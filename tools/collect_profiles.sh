@@ -1,7 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): the bench lines, rocprofv3 kernel traces and PMC passes that profiles/ is built
 # from.  Everything lands in gpurun_out/; tools/rocprof_summary.py / tools/pmc_traffic.py turn it into profiles/.
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'      then, here:  bash tools/publish_profiles.sh r02
+# The PMC passes run AFTER the bench lines, so the bench lines of this call cannot carry `roofline.traffic` yet: commit the
+# published profiles/rNN_hbm_traffic.json and run `python bench.py --agreement-clips 256` once more for the headline line.
 set -u
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/final
