@@ -103,20 +103,18 @@ __host__ __forceinline__ bf16_t f2h_host(float f) {
 // ---- GELU --------------------------------------------------------------------------------------
 // exact erf form (reference: transformers activations "gelu" = 0.5 x (1 + erf(x / sqrt 2)))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-// bf16-path GELU without transcendentals.  gelu(x) = x/2 + E(x), E(x) = (x/2) erf(x/sqrt 2) is EVEN:
-// E(x) = x^2 Q(x^2) with a degree-8 polynomial Q on |x| <= 4.2 (Chebyshev fit, max |error| 6.4e-5 over the
-// whole real line, gelu(0) = 0 exactly) and E(x) = |x|/2 beyond (erf = 1 to 2.7e-5).  10 FMA/MUL + a select,
-// all of them packable (v_pk_fma_f32), against ~13 + v_rcp + v_exp for the Abramowitz-Stegun form: the GELU
-// of a 256x256 tile was ~13 k of the 29 k epilogue cycles of the FFN1 GEMM.  The result is rounded to bf16
-// (half-ulp 2e-3 at |y| = 1) right after; the fp32 parity mode uses erff (gelu_erf).
+// 16-bit-path GELU without transcendentals.  gelu(x) = x Phi(x), Phi(x) - 1/2 = erf(x / sqrt 2) / 2 is ODD:
+// Phi(x) = 1/2 + x Q(x^2) with a degree-8 polynomial Q on |x| <= 4.2 (Chebyshev fit of x^2 Q(x^2) to the even part of
+// gelu: max |error| of gelu 6.4e-5 over the whole real line, gelu(0) = 0 exactly); beyond, x is clamped inside Phi only:
+// Phi(+-4.2) = 1 - 2.7e-5 / 2.7e-5, i.e. gelu = 0.99997 x resp. 2.7e-5 x.  12 VALU instructions (clamp, square, 8 FMA,
+// one FMA for Phi, one multiply), no compare / select (a v_cmp + v_cndmask form of the range split returned the PREVIOUS
+// compare's result in lanes 48-63 when the wave shared its SIMD with MFMA waves of another kernel,
+// profiles/r02_packed_f32_hazard.md), all scalar fp32 (packed fp32 is banned, build.py).  The GELU of a 256x256 tile
+// costs about as much VALU issue as a K = 768 tile costs matrix-pipe time.  The result is rounded to a 16-bit operand
+// (half-ulp 2e-3 resp. 2.4e-4 at |y| = 1) right after; the fp32 parity mode uses erff (gelu_erf).
 __device__ __forceinline__ float gelu_fast(float x) {
-    // select-free: xa = min(|x|, 4.2); E = Q(xa^2) * (|x| * xa).  For |x| <= 4.2 that is Q(x^2) x^2 bit for bit; beyond,
-    // Q(17.64) * 4.2 |x| = (E(4.2) / 4.2) |x| = |x|/2 * erf(2.97) = |x|/2 (1 - 2.7e-5).  No v_cmp / v_cndmask pair: the
-    // compare-into-VCC + select form of this function returned the PREVIOUS compare's result in lanes 48-63 when the
-    // wave shared its SIMD with MFMA waves of another kernel (profiles/r02_vcc_hazard.md).
-    const float ax = fabsf(x);
-    const float xa = fminf(ax, 4.2f);
-    const float u = xa * xa;
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.2f, 4.2f);
+    const float u = xc * xc;
     float q = fmaf(6.949803233e-11f, u, -6.356798643e-09f);
     q = fmaf(q, u, 2.570604920e-07f);
     q = fmaf(q, u, -6.139445304e-06f);
@@ -125,7 +123,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
     q = fmaf(q, u, 9.886963293e-03f);
     q = fmaf(q, u, -6.643489748e-02f);
     q = fmaf(q, u, 3.989362717e-01f);
-    return fmaf(q, ax * xa, 0.5f * x);
+    return x * fmaf(xc, q, 0.5f);
 }
 
 // two values of one run.  (This used to go through the packed-fp32 VALU -- v_pk_fma_f32 carries two lanes' worth of

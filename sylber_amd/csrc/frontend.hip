@@ -114,6 +114,13 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
         for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
         sa[i] = scale_shift[((size_t)b * SYL_CONV + c0 + i) * 2 + 0];
         sb[i] = scale_shift[((size_t)b * SYL_CONV + c0 + i) * 2 + 1];
+        if constexpr (!OUT_F32) {
+            // 16-bit modes: the GroupNorm scale goes into the tap weights once per (utterance, channel) -- the affine
+            // then costs nothing per value (the accumulation starts from the shift); the fp32 parity instantiation keeps the
+            // reference's order (conv, then scale and shift)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) w[i][j] *= sa[i];
+        }
     }
     __syncthreads();
     const int lbase = l_blk + wave * (C0_ROWS / 4);
@@ -129,10 +136,10 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             for (int j = 0; j < 10; ++j) xv[j] = xr[j];          // LDS broadcast
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float v = 0.f;
+                float v = OUT_F32 ? 0.f : sb[i];
 #pragma unroll
                 for (int j = 0; j < 10; ++j) v = fmaf(w[i][j], xv[j], v);
-                v = fmaf(v, sa[i], sb[i]);
+                if constexpr (OUT_F32) v = fmaf(v, sa[i], sb[i]);
                 y[i] = ERF ? gelu_erf(v) : gelu_fast(v);
             }
         } else {
