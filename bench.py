@@ -64,6 +64,10 @@ def parse_args():
                          "step) -- the only way to exercise it on a one-GPU box; the line is labelled accordingly")
     ap.add_argument("--exchange-timeout", type=int, default=180,
                     help="watchdog for the exchange phase (s): on expiry rank 0 prints the resident-shard line with `exchange_error`")
+    ap.add_argument("--ingest", choices=["scatter", "per-rank"], default="scatter",
+                    help="N>1 exchange step: 'scatter' = the job's clips live on rank 0 and are scattered over RCCL every step "
+                         "(default, BASELINE configs[2]); 'per-rank' = every rank's shard lives in its own page-locked host memory "
+                         "and crosses that GPU's own PCIe link every step (SURVEY.md §8(e)), gather unchanged")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
     ap.add_argument("--agreement-clips", type=int, default=0,
                     help="also report bf16-vs-fp32 segment agreement on this many synthetic clips (fp32 parity mode as truth)")
@@ -258,15 +262,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(run_steps):
+    def all_ranks(x):
+        """[x of rank 0, x of rank 1, ...] on every rank"""
+        if world == 1:
+            return [float(x)]
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if on_cpu_group else dev)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    per_rank = {}
+
+    def timed(run_steps, warmup=None):
         """contract: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize, MAX over ranks.
         run_steps(n) returns one timing-enabled event per step (recorded where the step's last kernel was issued)."""
-        run_steps(args.warmup)
+        run_steps(args.warmup if warmup is None else warmup)
         barrier()
         t0 = time.perf_counter()
         evs = run_steps(args.steps)
+        torch.cuda.synchronize(dev)
+        mine = time.perf_counter() - t0                  # this rank's own K steps (before the closing barrier)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        per_rank["last"] = [round(1e3 * x / args.steps, 3) for x in all_ranks(mine)]
         # per-step time from the completion events: with P batches in flight completions arrive in bursts, so a step's
         # time is the distance to the completion P steps later, divided by P
         P = max(1, NPIPE)
@@ -321,24 +339,46 @@ def main():
     if world > 1 and rank == 0:
         root_batch = torch.cat([noise_batch(B, clip_samples, seed=1000 + r) for r in range(world)], 0).to(dev)
 
+    host_shard = None
+    if (world > 1 or selftest) and args.ingest == "per-rank":
+        host_shard = torch.empty(B, clip_samples, dtype=torch.float32, pin_memory=True)
+        host_shard.copy_(my_batch)
+        torch.cuda.synchronize(dev)
+
     def exchange_steps(n):
         evs = []
         src = [root_batch] * n if rank == 0 else [None] * n
-        for _o in sharded.run_stream(src, None, max_segments=min(T_frames, 192)):
+        for _o in sharded.run_stream(src, None, max_segments=min(T_frames, 192), ingest=args.ingest,
+                                     host_shards=[host_shard] * n if host_shard is not None else None):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream(dev))
             evs.append(ev)
         return evs
 
-    ex_txt = "root scatter + gather over RCCL in every step (run_stream: gather(i) overlapped with compute(i+1))"
+    ex_txt = ("root scatter + gather over RCCL in every step (run_stream: gather(i) overlapped with compute(i+1))"
+              if args.ingest == "scatter" else
+              "per-rank H2D ingest over each GPU's own PCIe link + gather over RCCL in every step (run_stream: gather(i) "
+              "overlapped with compute(i+1))")
     res_txt = "shards resident per rank, no data-path collective"
 
     def build_line(value_, elapsed_, med_, exchange_first_, roofline_=None, frontend_=None, cpu_=None, api_=None, kernels_=None,
                    seg_stats_=None):
         dtype = {"bf16": "bf16", "fp8": "bf16 + mxfp8 (e4m3, E8M0 block scales) weight GEMMs", "fp32": "f32", "fp16": "f16 (IEEE half operands, f32 accumulate)",
                  "mixed16": "f16 conv stack + bf16 encoder (f32 accumulate)"}[args.precision]
+        # which BASELINE.json configuration this run IS (the label follows the arguments, not the default)
+        is10 = clip_samples == CLIP_SAMPLES and not args.ragged
+        if is10 and B == BATCH_PER_GPU and args.precision == "bf16":
+            cfg_name = "BASELINE.json configs[1]" if world == 1 else "BASELINE.json configs[2]: configs[1] sharded over %d GPUs" % world
+        elif is10 and B == BATCH_PER_GPU and args.precision == "fp8":
+            cfg_name = "BASELINE.json configs[4] (fp8) on the configs[1] batch"
+        elif abs(clip_seconds - 60.0) < 1e-9 and B == 8 and not args.ragged:
+            cfg_name = "BASELINE.json configs[3] (long-form)" + ("" if args.precision == "bf16" else ", precision %s" % args.precision)
+        else:
+            cfg_name = "not a BASELINE.json configuration: batch %d x %g s%s, precision %s" % (
+                B, clip_seconds, " ragged" if args.ragged else "", args.precision)
+        clips_txt = ("batched %g s clips" % clip_seconds) if not args.ragged else ("ragged clips up to %g s" % clip_seconds)
         line = {
-            "metric": "audio-sec/s encoded (sylber_base, 16 kHz, batched 10 s clips)",
+            "metric": "audio-sec/s encoded (sylber_base, 16 kHz, %s)" % clips_txt,
             "value": round(value_, 1), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed_ / args.steps, 3),
             "ms_per_step_median": None if med_ is None else round(med_, 3),
@@ -346,7 +386,7 @@ def main():
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "Segmenter forward (conv frontend + HuBERT-9L encoder + boundary detection + "
                                    "segment mean-pool), batch %d x %g s 16 kHz random waveforms per GPU, random-init "
-                                   "sylber_base weights (BASELINE.json configs[1]%s)" % (B, clip_seconds, "; configs[2] sharding" if world > 1 else ""),
+                                   "sylber_base weights (%s)" % (B, clip_seconds, cfg_name),
                        "global_batch": world * B, "clip_seconds": clip_seconds,
                        "ragged": ("lengths U[2 s, %g s], %.1f valid s of %g padded s per batch" % (clip_seconds, valid_seconds, B * clip_seconds))
                                  if args.ragged else None, "frames_per_clip": T_frames,
@@ -368,6 +408,8 @@ def main():
     # "exchange_error" saying what happened) instead of losing the whole measurement.
     want_exchange = world > 1 or selftest                      # --no-exchange only swaps which figure is `value`
     r_elapsed, r_med = timed(resident_steps)
+    r_per_rank = per_rank.get("last")
+    x_info = None
     total_audio = world * valid_seconds * args.steps           # (ragged: rank 0's draw stands for every rank)
     elapsed, med_ms = r_elapsed, r_med
     exchange_first = False
@@ -388,7 +430,17 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            x_elapsed, x_med = timed(exchange_steps)
+            exchange_steps(args.warmup)                  # (its own warm-up, so that the counters below cover K steps only)
+            sharded.reset_stats()
+            x_elapsed, x_med = timed(exchange_steps, warmup=0)
+            st_ = sharded.stats
+            x_info = {"per_rank_ms_per_step": per_rank.get("last"),
+                      "root_wait_ms_per_step": round(1e3 * st_["wait_s"] / max(st_["steps"], 1), 3),
+                      "wait_ms_per_step_by_rank": [round(1e3 * x / max(st_["steps"], 1), 3) for x in all_ranks(st_["wait_s"])],
+                      "scatter_bytes_per_step_root": st_["scatter_bytes"] // max(st_["steps"], 1),
+                      "gather_bytes_per_step_root": st_["gather_bytes"] // max(st_["steps"], 1),
+                      "h2d_bytes_per_step_rank0": st_["h2d_bytes"] // max(st_["steps"], 1),
+                      "ingest": args.ingest}
             if args.no_exchange and not selftest:
                 secondary = ("exchange", x_elapsed, x_med)
             else:
@@ -479,8 +531,11 @@ def main():
         host_wavs = [w[None, :].clone() for w in noise_batch(B, clip_samples, seed=1000)]
         seg_api(wav=host_wavs, in_second=True)
         torch.cuda.synchronize(dev)
-        n_api = 5
+        seg_api(wav=host_wavs, in_second=True)                  # second warm-up: the output pool reaches its steady state
+        torch.cuda.synchronize(dev)
+        n_api = 20
         t_api = []
+        allocs0 = seg_api.out_pool.allocations
         for _ in range(n_api):
             t0 = time.perf_counter()
             seg_api(wav=host_wavs, in_second=True)
@@ -489,8 +544,11 @@ def main():
             sys.stderr.write("api call times (ms): %s\n" % [round(x * 1e3, 1) for x in t_api])
         dt = statistics.median(t_api)
         api = {"value": round(B * clip_seconds / dt, 1), "unit": "audio-sec/s", "ms_per_call": round(dt * 1e3, 2),
-               "what": "Segmenter.__call__(wav=[%d host tensors]) -> list of numpy dicts: one batched H2D, forward + "
-                       "segmentation, D2H of hidden states / segments / features, per-utterance slicing" % B}
+               "ms_min": round(min(t_api) * 1e3, 2), "ms_median": round(dt * 1e3, 2), "ms_max": round(max(t_api) * 1e3, 2),
+               "calls": n_api, "pinned_allocations_during_timing": seg_api.out_pool.allocations - allocs0,
+               "what": "Segmenter.__call__(wav=[%d host tensors]) -> list of numpy dicts: one batched H2D from a pinned staging "
+                       "ring, forward + segmentation, D2H of hidden states / segments / features into a leased page-locked "
+                       "block (PinnedOutputPool), per-utterance slicing; %d back-to-back calls" % (B, n_api)}
         del seg_api
 
     cpu = None
@@ -516,6 +574,9 @@ def main():
                           "ms_per_step": round(1e3 * s_el / args.steps, 3),
                           "ms_per_step_median": None if s_med is None else round(s_med, 3),
                           "parallelism": res_txt if name == "resident_shards" else ex_txt}
+        if x_info is not None:
+            line["exchange_detail"] = x_info
+        line["resident_per_rank_ms_per_step"] = r_per_rank
         if exchange_error is not None:
             line["exchange_error"] = exchange_error
         if agreement is not None:

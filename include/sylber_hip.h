@@ -154,7 +154,8 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
                      void* stream);
 
 /* ---- per-handle options ------------------------------------------------------------------------ */
-/* Tuning / test overrides, scoped to ONE handle (nothing process-global); value < 0 or 0 restores the automatic choice.
+/* Tuning / test overrides, scoped to ONE handle (nothing process-global).  SYLBER_OPT_GEMM_TILE: value < 0 restores the
+ * automatic choice (0 is a tile id); the other keys: 0 = automatic.
  *   SYLBER_OPT_GEMM_TILE               tile configuration id of the bf16 GEMM launches (csrc/gemm_bf16.hip launch_t:
  *                                      0 = 256x128, 3 = 128x128, 4 = 128x192, 10 = 256x256 8-wave, 11 = 256x192 8-wave)
  *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   32 (automatic choice) or 64

@@ -126,6 +126,7 @@ int launch_posconv(const bf16_t* xpad, const bf16_t* wpk, const float* bias, con
         HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<2, FMT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<1, FMT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
     }
+    if (fmt == FMT_F16 && act == 2) { syl_set_error("launch_posconv", "the erf GELU (act 2) has no fp16 instantiation"); return 1; }
     if (fmt == FMT_F16) hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_F16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
     else if (act == 2) hipLaunchKernelGGL((posconv_bf16_kernel<2, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
     else hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);

@@ -43,6 +43,23 @@ class ShardedSegmenter:
         self._coll = self.world > 1 or (always_collective and dist.is_initialized())
         self._cuda = torch.device(self.device).type == "cuda"
         self._streams = [torch.cuda.Stream(device=self.device) for _ in self.engines] if self._cuda else None
+        self.reset_stats()
+
+    def reset_stats(self) -> None:
+        """counters of ``run_stream`` (what the N > 1 bench line reports): host seconds this rank spent blocked in the
+        gather hand-over, bytes it sent / received through the communicator, H2D bytes of the per-rank ingest"""
+        self.stats = {"steps": 0, "wait_s": 0.0, "scatter_bytes": 0, "gather_bytes": 0, "h2d_bytes": 0}
+
+    def _hand_over(self, tensors):
+        """results were produced (and allocated) under an engine's side stream; the caller consumes them on ITS current
+        stream: tell the caching allocator, or a dropped result's block could be reused by compute(i + E) while the
+        caller's queued work still reads it"""
+        if self._cuda:
+            cur = torch.cuda.current_stream(self.device)
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(cur)
+        return tensors
 
     # ---- device-level step (what bench.py times) -------------------------------------------------
     def scatter(self, batch_root: Optional[torch.Tensor], lengths_root: Optional[Sequence[int]]):
@@ -106,13 +123,18 @@ class ShardedSegmenter:
         return self.gather(hidden, seg, nseg, feats, btot)
 
     # ---- overlapped stream of batches --------------------------------------------------------------
-    def gather_async(self, hidden, seg, nseg, feats, btot: int, max_segments: int):
+    def gather_async(self, hidden, seg, nseg, feats, btot: int, max_segments: int, check: bool = True):
         """Like ``gather`` but with asynchronous collectives and WITHOUT the host round trip that trims the pooled
-        features to the global max segment count: the first ``max_segments`` slots are exchanged instead (root
-        raises if an utterance has more).  Returns a zero-argument ``wait`` function."""
+        features to the global max segment count: the first ``max_segments`` slots are exchanged instead.  Returns a
+        zero-argument ``wait`` function.  An utterance with more segments than that is an error: with ``check`` the
+        ``wait`` raises (one blocking D2H read on root); ``run_stream`` passes ``check=False`` and tests the largest
+        count ONCE after its loop (``wait.nmax`` = device scalar), so that no step contains a host synchronisation."""
         W = self.world
         k = max(1, min(int(max_segments), seg.shape[1]))
         parts = [hidden.contiguous(), seg[:, :k].contiguous(), nseg.contiguous(), feats[:, :k].contiguous()]
+
+        def too_many(n):
+            return RuntimeError("an utterance has %d segments, more than max_segments=%d" % (n, k))
         if not self._coll:
             done = None
             if self._cuda:
@@ -122,9 +144,10 @@ class ShardedSegmenter:
             def wait1():
                 if done is not None:
                     torch.cuda.current_stream(self.device).wait_event(done)
-                if int(nseg[:btot].max()) > k:
-                    raise RuntimeError("an utterance has more than max_segments=%d segments" % k)
-                return tuple(t[:btot] for t in parts)
+                if check and int(nseg[:btot].max()) > k:
+                    raise too_many(int(nseg[:btot].max()))
+                return self._hand_over(tuple(t[:btot] for t in parts))
+            wait1.nmax = nseg[:btot].max()
             return wait1
         fulls, works = [], []
         for t in parts:
@@ -133,6 +156,8 @@ class ShardedSegmenter:
             o = list(full.view((W, t.shape[0]) + tuple(t.shape[1:])).unbind(0)) if self.rank == 0 else None
             works.append(dist.gather(t, o, dst=0, group=self.group, async_op=True))
             fulls.append(full)
+            nb = t.numel() * t.element_size()
+            self.stats["gather_bytes"] += nb * (W - 1) if self.rank == 0 else nb
 
         def wait():
             for wk in works:
@@ -140,21 +165,31 @@ class ShardedSegmenter:
             if self.rank != 0:
                 return None
             res = tuple(f[:btot] for f in fulls)
-            if int(res[2].max()) > k:
-                raise RuntimeError("an utterance has more than max_segments=%d segments" % k)
-            return res
+            wait.nmax = res[2].max()
+            if check and int(wait.nmax) > k:
+                raise too_many(int(wait.nmax))
+            return self._hand_over(res)
+        wait.nmax = None
         _keep = parts                                      # the sources must outlive the collectives
         wait.keep = _keep
         return wait
 
-    def run_stream(self, batches_root, lengths_root=None, max_segments: int = 128):
+    def run_stream(self, batches_root, lengths_root=None, max_segments: int = 128, ingest: str = "scatter",
+                   host_shards=None):
         """Generator over a sequence of root batches (``[Btot, Lmax]`` tensors on root, ``None`` elsewhere; every rank
         must pass a sequence of the same length).  Software pipeline over ONE communicator, whose collectives
         execute in issue order: the scatter of batch i+1 is issued BEFORE the compute of batch i, and the gather of
         batch i after it, asynchronously — so gather(i) travels over xGMI while compute(i+1) runs, and scatter(i+2)
         queues behind gather(i) without anybody waiting for it yet.  All shapes and lengths are broadcast ONCE up
         front, so no step contains a host round trip.  Yields the gathered result of each batch in order (root:
-        tensors, other ranks: None)."""
+        tensors, other ranks: None).
+
+        ``ingest="per-rank"`` (inputs that originate on the host): no scatter; ``host_shards[i]`` is THIS
+        rank's ``[Bper, Lmax]`` block of batch i in page-locked host memory and crosses this GPU's own PCIe link
+        (asynchronous H2D on the consuming engine's stream); ``batches_root[i]`` then only supplies the shape on root.
+        The gather is unchanged.  The overflow test of ``max_segments`` runs once, after the last step."""
+        if ingest not in ("scatter", "per-rank"):
+            raise ValueError("ingest must be 'scatter' or 'per-rank'")
         batches = list(batches_root)
         n = len(batches)
         if n == 0:
@@ -182,9 +217,16 @@ class ShardedSegmenter:
             btot, lmax = int(shapes_h[i][0]), int(shapes_h[i][1])
             bper = (btot + W - 1) // W
             mine = (lens_h[i][:btot] + [lmax] * (bper * W - btot))[self.rank * bper:(self.rank + 1) * bper]
+            if ingest == "per-rank":
+                src = host_shards[i]
+                my_wav = torch.empty(bper, lmax, dtype=torch.float32, device=self.device)
+                my_wav.copy_(src, non_blocking=True)
+                self.stats["h2d_bytes"] += my_wav.numel() * 4
+                return my_wav, mine, btot
             if not self._coll:
                 return batches[i], mine, btot
             my_wav = torch.empty(bper, lmax, dtype=torch.float32, device=self.device)
+            self.stats["scatter_bytes"] += my_wav.numel() * 4 * ((W - 1) if self.rank == 0 else 1)
             chunks = None
             if self.rank == 0:
                 pad = bper * W - btot
@@ -207,9 +249,21 @@ class ShardedSegmenter:
             cur = torch.cuda.current_stream(self.device)
             for st in self._streams:
                 st.wait_stream(cur)                                      # the root batches were produced on `cur`
+        import time as _time
         with on(0):
             nxt = scatter_known(0)
         pending = None
+        worst = None                                                     # device scalar: largest segment count seen (root)
+
+        def collect(wait_fn):
+            nonlocal worst
+            t0 = _time.perf_counter()
+            out = wait_fn()
+            self.stats["wait_s"] += _time.perf_counter() - t0
+            self.stats["steps"] += 1
+            if wait_fn.nmax is not None:
+                worst = wait_fn.nmax if worst is None else torch.maximum(worst, wait_fn.nmax)
+            return out
         for i in range(n):
             k = i % E
             my_wav, my_lens, btot = nxt
@@ -218,14 +272,19 @@ class ShardedSegmenter:
                     nxt = scatter_known(i + 1)                           # prefetch the next input
             with on(k):
                 hidden, seg, nseg, feats = self.compute(my_wav, my_lens, k)
-                wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments)
+                wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False)
             if pending is not None:
-                yield pending()
+                yield collect(pending)
             pending = wait
-        yield pending()
+        last = collect(pending)
         if self._cuda:
             for st in self._streams:
                 torch.cuda.current_stream(self.device).wait_stream(st)
+        # the ONE host synchronisation of the stream of batches: did any utterance overflow the exchanged slots?
+        k = max(1, min(int(max_segments), 1 << 30))
+        if worst is not None and int(worst) > k:
+            raise RuntimeError("an utterance has %d segments, more than max_segments=%d" % (int(worst), k))
+        yield last
 
     # ---- reference-shaped API on root ------------------------------------------------------------
     def __call__(self, wav: Optional[List[torch.Tensor]] = None, in_second: bool = True):

@@ -5,7 +5,8 @@ from __future__ import annotations
 
 import ctypes
 import os
-import wave as _wave
+import threading
+import weakref
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence, Union
 
@@ -47,6 +48,59 @@ def load_wav_file(path: str) -> torch.Tensor:
         v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
         x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
     return torch.from_numpy(x.reshape(-1, pcm.channels).T.copy())
+
+
+class PinnedOutputPool:
+    """Persistent page-locked host blocks for the results of ``Segmenter.__call__`` (reference: the D2H of
+    sylber.py:122-138, where ``.cpu().numpy()`` lands in pageable memory).
+
+    Page-locking is the expensive part of a pinned allocation (tens to hundreds of ms for the 49 MB of hidden states of
+    a 32 x 10 s batch), so blocks are allocated once and LEASED: a call's numpy results are views of one block, and the
+    block returns to the pool when the last of those views is garbage collected (a finalizer on the owning ndarray --
+    every numpy view of it keeps that owner alive through ``.base``).  Nothing is ever overwritten while a caller can
+    still see it.  At most ``max_leased`` blocks are out at a time: beyond that (a corpus loop that keeps every result)
+    ``lease`` returns None and the caller falls back to pageable per-utterance copies, so retained results never pin
+    more than ``max_leased`` batches of host memory."""
+
+    GRANULE = 1 << 20
+
+    def __init__(self, max_leased: int = 4):
+        self.max_leased = int(max_leased)
+        self._free: List[torch.Tensor] = []
+        self._leased = 0
+        self._lock = threading.Lock()
+        self.allocations = 0                      # page-locking events so far (tests / bench: must stop growing)
+
+    def _release(self, blk: torch.Tensor) -> None:
+        with self._lock:
+            self._leased -= 1
+            self._free.append(blk)
+
+    def lease(self, nbytes: int):
+        """-> (owner ndarray uint8 [cap], block tensor) or None when ``max_leased`` blocks are already out"""
+        with self._lock:
+            if self._leased >= self.max_leased:
+                return None
+            pick = None
+            for i, b in enumerate(self._free):
+                if b.numel() >= nbytes and (pick is None or b.numel() < self._free[pick].numel()):
+                    pick = i
+            blk = self._free.pop(pick) if pick is not None else None
+            if blk is None and len(self._free) + self._leased >= self.max_leased and self._free:
+                self._free.pop(0)                 # too small for this batch shape: let it go instead of hoarding
+            self._leased += 1
+        if blk is None:
+            cap = (int(nbytes) + self.GRANULE - 1) // self.GRANULE * self.GRANULE
+            try:
+                blk = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            except BaseException:
+                with self._lock:
+                    self._leased -= 1
+                raise
+            self.allocations += 1
+        owner = blk.numpy()
+        weakref.finalize(owner, self._release, blk)
+        return owner, blk
 
 
 class HubertEncoderHIP:
@@ -211,6 +265,13 @@ class Segmenter:
         self.device = str(self.speech_model.device)
         self.norm_threshold = norm_threshold
         self.merge_threshold = merge_threshold
+        # where __call__'s numpy results live: "pinned" (default) = views of leased page-locked blocks, at most
+        # `max_pinned_batches` batches outstanding, pageable copies beyond that; "pageable" = always ordinary arrays
+        # (what the reference returns).  See PinnedOutputPool.
+        self.output_memory = kwargs.get("output_memory", "pinned")
+        if self.output_memory not in ("pinned", "pageable"):
+            raise ValueError("output_memory must be 'pinned' or 'pageable'")
+        self.out_pool = PinnedOutputPool(max_leased=int(kwargs.get("max_pinned_batches", 4)))
 
     @staticmethod
     def _load_state_dict(model_ckpt, encoding_layer):
@@ -255,14 +316,17 @@ class Segmenter:
         lmax = max(lengths)
         dev = self.speech_model.device
         if all(not r.is_cuda for r in rows):
-            # host inputs: pad on the host into ONE pinned staging buffer and cross PCIe once (a row-by-row copy
-            # loop costs a host round trip per utterance)
-            stage = self._pinned("wav", (len(rows), lmax), torch.float32)
+            # host inputs: pad on the host into a pinned staging buffer and cross PCIe once (a row-by-row copy loop
+            # costs a host round trip per utterance).  Two buffers rotate, each with the event of the H2D copy that last
+            # read it: encode_batch returns without synchronising, so the host must not refill a buffer whose copy is
+            # still queued behind an earlier forward.
+            stage, slot = self._stage_buffer((len(rows), lmax))
             for i, r in enumerate(rows):
                 stage[i, : lengths[i]] = r
                 stage[i, lengths[i]:] = 0.0
             batch = torch.empty(len(rows), lmax, dtype=torch.float32, device=dev)
             batch.copy_(stage, non_blocking=True)
+            slot["event"].record(torch.cuda.current_stream(dev))
         else:
             batch = torch.zeros(len(rows), lmax, dtype=torch.float32, device=dev)
             for i, r in enumerate(rows):
@@ -270,17 +334,22 @@ class Segmenter:
         hidden = self.speech_model.forward(batch, lengths)
         return hidden, lengths
 
-    def _pinned(self, name: str, shape, dtype) -> torch.Tensor:
-        """grow-only pinned host staging buffers (allocating pinned memory per call costs more than the copy)"""
-        pool = self.__dict__.setdefault("_pin_pool", {})
+    def _stage_buffer(self, shape):
+        """next of two grow-only pinned H2D staging buffers; waits (host side) for the copy that last read it"""
+        ring = self.__dict__.setdefault("_stage_ring", [{"buf": None, "event": None}, {"buf": None, "event": None}])
+        k = self.__dict__.get("_stage_next", 0)
+        self._stage_next = (k + 1) % len(ring)
+        slot = ring[k]
         n = 1
         for d in shape:
             n *= int(d)
-        buf = pool.get(name)
-        if buf is None or buf.numel() < n or buf.dtype != dtype:
-            buf = torch.empty(max(n, 1), dtype=dtype).pin_memory()
-            pool[name] = buf
-        return buf[:n].view(*shape)
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        else:
+            slot["event"] = torch.cuda.Event()
+        if slot["buf"] is None or slot["buf"].numel() < n:
+            slot["buf"] = torch.empty(max(n, 1), dtype=torch.float32, pin_memory=True)
+        return slot["buf"][:n].view(*shape), slot
 
     def segment(self, input_values=None, features=None, attention_mask=None, mergethreshold=None, normthreshold=None,
                 **kwargs):
@@ -311,31 +380,61 @@ class Segmenter:
         batch_wavs, is_batch = self._collect(wav_file, wav)
         hidden, _ = self.encode_batch(batch_wavs)
         seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold)
-        # D2H: the hidden states (the bulk) leave asynchronously into pinned memory while the host waits for the
-        # segment counts; segments / features are then trimmed to the batch's largest count and follow the same way.
-        # The pinned blocks come from torch's caching host allocator and are HANDED to the caller (the numpy arrays
-        # below are views that keep them alive; a dropped result returns its block to the cache) -- no second host
-        # copy of the 49 MB of hidden states per 32 x 10 s batch.
-        hid_pin = torch.empty(tuple(hidden.shape), dtype=torch.float32, pin_memory=True)
-        hid_pin.copy_(hidden, non_blocking=True)
-        nseg_h = nseg.cpu().numpy()
+        # D2H (sylber.py:122-138's .cpu().numpy()): the host waits for the segment counts only, trims segments /
+        # features to the batch's largest count and sends everything asynchronously into ONE leased page-locked block
+        # (PinnedOutputPool: persistent blocks, no page-locking per call).  The numpy results are views of that block --
+        # no second host copy of the 49 MB of hidden states per 32 x 10 s batch -- and the block goes back to the pool
+        # when the caller drops them.
+        dev = hidden.device
+        cur = torch.cuda.current_stream(dev)
+        B, T, D = hidden.shape
+        nseg_pin = self._nseg_pinned(B)
+        nseg_pin.copy_(nseg, non_blocking=True)
+        counted = self.__dict__.setdefault("_ev_counts", torch.cuda.Event())
+        counted.record(cur)
+        counted.synchronize()                                # the counts are on the host
+        nseg_h = nseg_pin.numpy().copy()
         nmax = int(nseg_h.max()) if len(nseg_h) else 0
         k = max(nmax, 1)
-        seg_pin = torch.empty((seg.shape[0], k, 2), dtype=torch.int64, pin_memory=True)
-        feat_pin = torch.empty((feats.shape[0], k, feats.shape[2]), dtype=torch.float32, pin_memory=True)
-        seg_pin.copy_(seg[:, :k], non_blocking=True)
-        feat_pin.copy_(feats[:, :k], non_blocking=True)
-        torch.cuda.current_stream(hidden.device).synchronize()
-        hidden_h = hid_pin.numpy()
-        seg_h = seg_pin.numpy()
-        feats_h = feat_pin.numpy()
+        kcap = min(T, (k + 63) & ~63)                        # block sizes repeat from call to call -> the pool reuses them
+
+        def al(n):
+            return (n + 255) & ~255
+        hid_bytes = al(B * T * D * 4)
+        o_seg, o_feat = hid_bytes, hid_bytes + al(B * kcap * 2 * 8)
+        need = o_feat + al(B * kcap * D * 4)
+        lease = self.out_pool.lease(need) if self.output_memory == "pinned" else None
+        handed = lease is not None
+        owner, blk = lease if handed else self._scratch_block(need)
+        blk[:B * T * D * 4].view(torch.float32).view(B, T, D).copy_(hidden, non_blocking=True)
+        blk[o_seg:o_seg + B * k * 2 * 8].view(torch.int64).view(B, k, 2).copy_(seg[:, :k], non_blocking=True)
+        blk[o_feat:o_feat + B * k * D * 4].view(torch.float32).view(B, k, D).copy_(feats[:, :k], non_blocking=True)
+        cur.synchronize()
+        hidden_h = owner[:B * T * D * 4].view(np.float32).reshape(B, T, D)
+        seg_h = owner[o_seg:o_seg + B * k * 2 * 8].view(np.int64).reshape(B, k, 2)
+        feats_h = owner[o_feat:o_feat + B * k * D * 4].view(np.float32).reshape(B, k, D)
         outputs = []
-        for i in range(hidden_h.shape[0]):
+        for i in range(B):
             n = int(nseg_h[i])
             segments = seg_h[i, :n].copy() if n > 0 else np.array([])
             outputs.append({
                 "segments": segments * 1.0 / FRAME_RATE if in_second else segments,
                 "segment_features": feats_h[i, :n].copy() if n > 0 else np.array([]),
-                "hidden_states": hidden_h[i],
+                "hidden_states": hidden_h[i] if handed else hidden_h[i].copy(),
             })
         return outputs if is_batch else outputs[0]
+
+    def _nseg_pinned(self, B: int) -> torch.Tensor:
+        buf = self.__dict__.get("_nseg_pin")
+        if buf is None or buf.numel() < B:
+            buf = torch.empty(max(B, 64), dtype=torch.int32, pin_memory=True)
+            self._nseg_pin = buf
+        return buf[:B]
+
+    def _scratch_block(self, nbytes: int):
+        """one private pinned block for the pageable-output mode (results are COPIED out of it, so it is reused)"""
+        blk = self.__dict__.get("_scratch_pin")
+        if blk is None or blk.numel() < nbytes:
+            blk = torch.empty((nbytes + (1 << 20) - 1) >> 20 << 20, dtype=torch.uint8, pin_memory=True)
+            self._scratch_pin = blk
+        return blk.numpy(), blk

@@ -82,4 +82,6 @@ def test_no_packed_fp32_valu_in_the_library(lib):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_isa
     from sylber_amd import _lib
+    text = check_isa.device_disassembly(_lib.LIB_PATH)                  # raises unless it really is the library's ISA
+    assert len(re.findall(r"\bv_mfma_", text)) > 1000 and len(re.findall(r"\bglobal_load_lds_dwordx4\b", text)) > 1000
     assert check_isa.banned_instructions(_lib.LIB_PATH) == {}

@@ -74,6 +74,32 @@ def _worker(rank, world, port, q):
     S2 = ShardedSegmenter([S.engine, OracleEngine(sd)], norm_threshold=2.6, merge_threshold=0.8)
     streamed2 = list(S2.run_stream(batches, lens, max_segments=64))
     ok = True
+    # counters of the stream of batches (what the N > 1 bench line reports): three steps, both directions counted
+    st = S.stats
+    ok &= st["steps"] >= 3 and st["wait_s"] >= 0.0 and st["gather_bytes"] > 0 and st["scatter_bytes"] > 0
+    # per-rank ingest: every rank feeds its own block of each batch from host memory, no scatter; same results on root
+    sets_all = [LENS, LENS[1:4], LENS[::-1]]
+    shards = []
+    for j, ls in enumerate(sets_all):
+        bper = (len(ls) + world - 1) // world
+        blk = torch.zeros(bper, max(ls))
+        for i, n in enumerate(ls):
+            if rank * bper <= i < (rank + 1) * bper:
+                blk[i - rank * bper, :n] = syllable_wave(n, 80 + 10 * j + i)[0]
+        shards.append(blk)
+    S.reset_stats()
+    streamed3 = list(S.run_stream(batches, lens, max_segments=64, ingest="per-rank", host_shards=shards))
+    ok &= S.stats["scatter_bytes"] == 0 and S.stats["steps"] == 3
+    if rank == 0:
+        for b, c in zip(streamed, streamed3):
+            ok &= all(torch.equal(x, y) for x, y in zip(b, c))
+    # an utterance with more segments than the exchanged slots: ONE error, after the loop (no per-step host check)
+    raised = False
+    try:
+        list(S.run_stream(batches, lens, max_segments=1))
+    except RuntimeError as e:
+        raised = "max_segments=1" in str(e)
+    ok &= raised if rank == 0 else True
     if rank == 0:
         for b, c in zip(streamed, streamed2):
             ok &= all(torch.equal(x, y) for x, y in zip(b, c))

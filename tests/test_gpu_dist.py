@@ -93,11 +93,7 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert r.returncode != 0 and "GPU" in r.stderr and '"n_gpus"' not in r.stdout
 
 
-def test_bench_two_rank_control_flow_on_one_gpu():
-    """bench.py's N > 1 path end to end (launcher env, rank-0-only buffers, exchange as the default step with the
-    resident-shard figure next to it, watchdog, ONE JSON line) with two ranks SHARING this box's GPU over gloo
-    (SYLBER_DIST_BACKEND=gloo, a development aid: RCCL refuses two ranks on one device).  The numbers mean nothing; the
-    control flow and the collectives' argument shapes on ranks 0 and 1 are what a one-GPU box cannot otherwise reach."""
+def _two_rank_bench(extra):
     import json
     import socket
     import subprocess
@@ -112,11 +108,41 @@ def test_bench_two_rank_control_flow_on_one_gpu():
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "4", "--clip-seconds", "2", "--no-cpu-baseline"]
+           "--batch", "4", "--clip-seconds", "2", "--no-cpu-baseline"] + list(extra)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_two_rank_control_flow_on_one_gpu():
+    """bench.py's N > 1 path end to end (launcher env, rank-0-only buffers, exchange as the default step with the
+    resident-shard figure next to it, watchdog, ONE JSON line) with two ranks SHARING this box's GPU over gloo
+    (SYLBER_DIST_BACKEND=gloo, a development aid: RCCL refuses two ranks on one device).  The numbers mean nothing; the
+    control flow and the collectives' argument shapes on ranks 0 and 1 are what a one-GPU box cannot otherwise reach."""
+    line = _two_rank_bench([])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8
     assert "exchange_error" not in line
     assert "root scatter + gather" in line["config"]["parallelism"]
     assert line["resident_shards"]["value"] > 0 and line["value"] > 0
+    assert "not a BASELINE.json configuration" in line["config"]["workload"]         # 4 x 2 s is no BASELINE config
+    assert "2 s clips" in line["metric"]
+    # what a first real multi-GPU run needs in order to explain itself (VERDICT r2 item 6)
+    d = line["exchange_detail"]
+    assert d["ingest"] == "scatter"
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in d["per_rank_ms_per_step"])
+    assert len(d["wait_ms_per_step_by_rank"]) == 2 and d["root_wait_ms_per_step"] >= 0
+    assert d["scatter_bytes_per_step_root"] == 4 * 32000 * 4                         # one peer's 4 x 2 s block
+    hid = 4 * 99 * 768 * 4
+    assert d["gather_bytes_per_step_root"] >= hid                                    # at least the peer's hidden states
+    assert len(line["resident_per_rank_ms_per_step"]) == 2
+
+
+def test_bench_two_rank_per_rank_ingest():
+    """--ingest per-rank: no scatter, every rank H2Ds its own page-locked shard; the gather is unchanged"""
+    line = _two_rank_bench(["--ingest", "per-rank"])
+    assert "exchange_error" not in line
+    assert "per-rank H2D ingest" in line["config"]["parallelism"]
+    d = line["exchange_detail"]
+    assert d["ingest"] == "per-rank" and d["scatter_bytes_per_step_root"] == 0
+    assert d["h2d_bytes_per_step_rank0"] == 4 * 32000 * 4
+    assert d["gather_bytes_per_step_root"] > 0 and line["value"] > 0

@@ -119,7 +119,7 @@ def test_long_form_config(enc, sd):
     seg, nseg, feats = enc.segment(out, 2.6, 0.8)
     torch.cuda.synchronize()
     out_h, seg_h, nseg_h, feats_h = out.cpu().numpy(), seg.cpu().numpy(), nseg.cpu().numpy(), feats.cpu().numpy()
-    for i in (0, 7):
+    for i in range(8):                                            # every row of the batch
         exp = segment_oracle.get_segment(out_h[i], 2.6, 0.8).reshape(-1, 2)
         assert nseg_h[i] == len(exp) and np.array_equal(seg_h[i, :nseg_h[i]], exp)
         if len(exp):

@@ -23,9 +23,14 @@ def device_disassembly(lib_path: str) -> str:
         out = []
         for f in sorted(os.listdir(tmp)):
             if "amdgcn" in f:
-                r = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", os.path.join(tmp, f)], capture_output=True, text=True)
+                r = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", os.path.join(tmp, f)], capture_output=True, text=True,
+                                   check=True)
                 out.append(r.stdout)
-        return "\n".join(out)
+        text = "\n".join(out)
+        # an empty disassembly (changed tool output naming, missing tool, other ROCm layout) must not read as "clean"
+        if len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", text)) < 100 or "s_endpgm" not in text:
+            raise RuntimeError("check_isa: the gfx950 code objects of %s were not disassembled (no MFMA / s_endpgm found)" % lib_path)
+        return text
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
