@@ -47,7 +47,11 @@ __device__ __forceinline__ bf16_t f2bf_dev(float f) { return __builtin_bit_cast(
 // mantissa bits = 8x finer rounding of every activation / weight hand-over at the SAME matrix-pipe rate
 // (v_mfma_f32_32x32x16_f16); conversions saturate at +-65504 instead of overflowing to infinity.  Buffers hold raw 16-bit
 // words either way (bf16_t = unsigned short), so layouts, LDS images and LDS-DMA staging are identical.
-enum { FMT_BF16 = 0, FMT_F16 = 1 };
+// FMT_SPLIT (precision "split16"): every 16-bit operand is a PAIR of IEEE halves (hi = half(x), lo = half(x - hi):
+// 22 significand bits) kept as two planes of the same buffer; a contraction runs three MFMA passes into one fp32
+// accumulator, hi.hi + lo.hi + hi.lo (the lo.lo term is below 2^-22 relative), i.e. fp32-grade products at three
+// times the fp16 MFMA work instead of the sixteen times of the f32 MFMA.
+enum { FMT_BF16 = 0, FMT_F16 = 1, FMT_SPLIT = 2 };
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 template <int FMT> struct H16 {
@@ -77,6 +81,14 @@ template <> struct H16<FMT_F16> {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
 };
+template <> struct H16<FMT_SPLIT> : H16<FMT_F16> {
+    // the lo halves of two values whose packed hi halves are `hi2`
+    static __device__ __forceinline__ uint32_t pack2_lo(float lo, float hi, uint32_t hi2) {
+        const f16x2_t h = __builtin_bit_cast(f16x2_t, hi2);
+        return H16<FMT_F16>::pack2_bounded(lo - (float)h[0], hi - (float)h[1]);
+    }
+    static __device__ __forceinline__ bf16_t cvt_lo(float f, bf16_t hi) { return H16<FMT_F16>::cvt(f - H16<FMT_F16>::up(hi)); }
+};
 // host: float -> IEEE half, round to nearest even, saturating (weights packed at sylber_create)
 __host__ __forceinline__ bf16_t f2h_host(float f) {
     union { float f; uint32_t u; } v; v.f = f;
@@ -99,6 +111,23 @@ __host__ __forceinline__ bf16_t f2h_host(float f) {
     return (bf16_t)(sign | (a >> 13));
 }
 
+
+__host__ __forceinline__ float h2f_host(bf16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    union { float f; uint32_t u; } v;
+    if (e == 0) {
+        if (m == 0) { v.u = sign; return v.f; }
+        int sh = 0;
+        while (!(m & 0x400u)) { m <<= 1; ++sh; }
+        m &= 0x3ffu; e = 1 - sh;
+        v.u = sign | ((uint32_t)(e + 112) << 23) | (m << 13);
+        return v.f;
+    }
+    if (e == 31) { v.u = sign | 0x7f800000u | (m << 13); return v.f; }
+    v.u = sign | ((e + 112) << 23) | (m << 13);
+    return v.f;
+}
 
 // ---- GELU --------------------------------------------------------------------------------------
 // exact erf form (reference: transformers activations "gelu" = 0.5 x (1 + erf(x / sqrt 2)))

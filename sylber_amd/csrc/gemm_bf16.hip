@@ -59,10 +59,12 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     const int srow = lane / CPR, spos = lane % CPR;
     const bf16_t* gp[NPW];
     int lds_off[NPW];
+    long pl[NPW]; int sg[NPW];                               // FMT_SPLIT: lo-plane offset of piece i and the K segment that reads it
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         const int p = wave + 4 * i;
         const bool isx = p < BM / RPP;
+        pl[i] = isx ? a.x_lo : a.w_lo; sg[i] = isx ? 1 : 2;
         const int r = (isx ? p : p - BM / RPP) * RPP + srow;   // tile-local row
         // source chunk landing at LDS position spos (bank swizzle through the source address)
         const int c = spos ^ (BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3));
@@ -70,10 +72,20 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
         else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; gp[i] = a.W + (size_t)wr * a.K + c * 8; }
         lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / RPP) * 1024;
     }
+    // FMT_SPLIT: the K loop runs three segments over the same K range -- X.hi W.hi, X.lo W.hi, X.hi W.lo -- into one
+    // accumulator; a k-tile index beyond K / BK selects the plane through the source address only
+    const int ntk = a.K / BK;
+    auto ksrc = [&](int kt, int i) -> const bf16_t* {
+        if constexpr (FMT != FMT_SPLIT) return gp[i] + kt * BK;
+        else {
+            const int seg = (kt >= ntk ? 1 : 0) + (kt >= 2 * ntk ? 1 : 0);
+            return gp[i] + (kt - seg * ntk) * BK + (seg == sg[i] ? pl[i] : 0L);
+        }
+    };
     auto stage = [&](int kt, int slot) {
         char* base = smem + slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) glds16(gp[i] + kt * BK, base + lds_off[i]);
+        for (int i = 0; i < NPW; ++i) glds16(ksrc(kt, i), base + lds_off[i]);
     };
 
     // ---- fragment read addresses (bytes within a stage)
@@ -128,7 +140,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
                 const int np = p1 - p0;
                 if (p >= p0 && p < p1 && ((p - p0 + 1) * NM + np - 1) / np - 1 == i) {
                     SCHED_FENCE();
-                    if (on) glds16(gp[p] + kt * BK, base + lds_off[p]);
+                    if (on) glds16(ksrc(kt, p), base + lds_off[p]);
                     SCHED_FENCE();
                 }
             }
@@ -137,7 +149,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     };
 
     // ---- NSTAGE-slot ring: tiles t+1 .. t+NSTAGE-1 in flight while tile t is consumed
-    const int nt = a.K / BK;
+    const int nt = FMT == FMT_SPLIT ? 3 * ntk : ntk;
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     if constexpr (NSTAGE > 2) { if (nt > 2) stage(2, 2); }
@@ -248,7 +260,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 // Hazards: a step's DMA is retired (vmcnt) two program barriers before its first ds_read (one more than
 // usual because the groups are staggered); fragment reads complete (lgkmcnt(0)) before the barrier that
 // lets the other group refill that slot.
-template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT>
+// VAR (K-loop schedule, A/B'd with tools/gemm_bench.py): 0 = the LDS-DMA of step s+3 interleaved with the MFMAs of phase B;
+// 1 = issued at the head of phase A (B is MFMAs only); 2 = at the tail of phase A, behind the fragment reads;
+// 3 = half at the tail of A, half inside B
+template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT, int VAR = 0>
 __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int tile_id, char* smem) {
     // K step 32 (64-byte LDS rows), 4-slot ring: the DMA of step s+3 is issued in step s and retired with
     // counted vmcnt, never 0 in the steady state.  (A 2-slot ring of 64-wide stages measured 5-12 % slower.)
@@ -273,22 +288,32 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     const int srow = lane >> 2, spos = lane & 3;
     const bf16_t* gp[NPW_HI];
     int lds_off[NPW_HI];
+    long pl[NPW_HI]; int sg[NPW_HI];                 // FMT_SPLIT: lo-plane offset of piece i and the K segment that reads it
 #pragma unroll
     for (int i = 0; i < NPW_HI; ++i) {
         int p = wave + 8 * i;
         p = p < NP ? p : NP - 1;                     // (unused slot of a "lo" wave; never issued)
         const bool isx = p < BM / 16;
+        pl[i] = isx ? a.x_lo : a.w_lo; sg[i] = isx ? 1 : 2;
         const int r = (isx ? p : p - BM / 16) * 16 + srow;
         const int c = spos ^ ((r >> 2) & 3);
         if (isx) { int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1; gp[i] = a.X + (size_t)xm * a.ldx + c * 8; }
         else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; gp[i] = a.W + (size_t)wr * a.K + c * 8; }
         lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / 16) * 1024;
     }
+    const int ntk = a.K / 32;                        // FMT_SPLIT: three K segments, see gemm_bf16_tile
+    auto ksrc = [&](int ks, int i) -> const bf16_t* {
+        if constexpr (FMT != FMT_SPLIT) return gp[i] + ks * 32;
+        else {
+            const int seg = (ks >= ntk ? 1 : 0) + (ks >= 2 * ntk ? 1 : 0);
+            return gp[i] + (ks - seg * ntk) * 32 + (seg == sg[i] ? pl[i] : 0L);
+        }
+    };
     auto stage = [&](int ks, int slot) {
         char* base = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < NPW_HI; ++i)
-            if (i < NPW_LO || hi) glds16(gp[i] + ks * 32, base + lds_off[i]);
+            if (i < NPW_LO || hi) glds16(ksrc(ks, i), base + lds_off[i]);
     };
     auto wait_steps = [&](int nsteps_in_flight) {    // leave that many of MY steps' pieces outstanding
         if (hi) {
@@ -313,7 +338,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nt = a.K / 32;
+    const int nt = FMT == FMT_SPLIT ? 3 * ntk : ntk;
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     if (nt > 2) stage(2, 2);
@@ -326,7 +351,15 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         const char* sb = smem + slot * STAGE;
         bf16x8_t xf[2][FM], wf[2][FN];
         // ---- A: fragments of step s, DMA of step s+3, retire step s+1
+        const bool dma = s + 3 < nt;
+        char* dbase = smem + ((slot + 3) & 3) * STAGE;     // slot of step s-1: every wave left A(s-1) >= two program barriers ago
+        auto dma_pieces = [&](int q0, int q1) {
+#pragma unroll
+            for (int q = q0; q < q1; ++q)
+                if (dma && q < NPW_HI && (q < NPW_LO || hi)) glds16(ksrc(s + 3, q), dbase + lds_off[q]);
+        };
         SCHED_FENCE();
+        if constexpr (VAR == 1) { dma_pieces(0, NPW_HI); SCHED_FENCE(); }
 #pragma unroll
         for (int f = 0; f < FM; ++f) {
             xf[0][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff0);
@@ -337,24 +370,29 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
             wf[0][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff0);
             wf[1][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff1);
         }
+        if constexpr (VAR == 2) { SCHED_FENCE(); dma_pieces(0, NPW_HI); SCHED_FENCE(); }
+        if constexpr (VAR == 3) { SCHED_FENCE(); dma_pieces(0, NPW_HI / 2); SCHED_FENCE(); }
         {
-            // step s+3's DMA is issued in phase B below (between the MFMAs), so at this point the steps
-            // issued after step s+1 are at most {s+2}
-            const int after = nt - 2 - s;
-            wait_steps(after >= 1 ? 1 : 0);
+            // retire step s+1.  VAR 0: step s+3's DMA is issued in phase B below, so the steps issued after s+1 are at
+            // most {s+2}; VAR 1 / 2: {s+2, s+3} are both in flight here; VAR 3: s+2 and the first half of s+3 (counted
+            // as a whole step: NPW_HI / 2 pieces fewer outstanding than the bound allows -> conservative)
+            const int after2 = (s + 2 < nt ? 1 : 0);
+            const int after3 = (s + 3 < nt ? 1 : 0);
+            if constexpr (VAR == 0) wait_steps(after2);
+            else if constexpr (VAR == 3) {
+                if (after3) { if (hi) wait_vmcnt<NPW_HI + NPW_HI / 2>(); else wait_vmcnt<NPW_LO + NPW_HI / 2>(); }
+                else wait_steps(after2);
+            }
+            else wait_steps(after2 + after3);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SCHED_FENCE();
         __builtin_amdgcn_s_barrier();
         SCHED_FENCE();
         // ---- B: MFMAs of step s
-        // The LDS-DMA of step s+3 is spread between the MFMAs (one 1-KiB piece per quarter of the MFMAs):
-        // a DMA instruction costs ~70-100 issue cycles because the CU's texture path moves 64 B/clk, and
-        // issued in a burst in phase A it made A the longer phase (measured 623 vs 517 cycles).  Here it
-        // issues under MFMAs that are already executing.  Target slot = slot of step s-1: every wave has
-        // left A(s-1) at least two program barriers ago.
-        const bool dma = s + 3 < nt;
-        char* dbase = smem + ((slot + 3) & 3) * STAGE;
+        // VAR 0: the LDS-DMA of step s+3 is spread between the MFMAs (one 1-KiB piece per quarter of the MFMAs): a DMA
+        // instruction costs ~70-100 issue cycles because the CU's texture path moves 64 B/clk, and issued in a burst in
+        // phase A it made A the longer phase (measured 623 vs 517 cycles).
         constexpr int NMF = 2 * FM * FN;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -362,11 +400,15 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
             const int kk = i / (FM * FN), fm = (i / FN) % FM, fn = i % FN;
             acc[fm][fn] = H16<FMT>::mfma(wf[kk][fn], xf[kk][fm], acc[fm][fn]);
             // after MFMA number (q+1)*NMF/NPW_HI - 1 issue piece q
-            if ((i + 1) % (NMF / NPW_HI) == 0) {
-                const int q = (i + 1) / (NMF / NPW_HI) - 1;
-                SCHED_FENCE();
-                if (dma && q < NPW_HI && (q < NPW_LO || hi)) glds16(gp[q] + (s + 3) * 32, dbase + lds_off[q]);
-                SCHED_FENCE();
+            if constexpr (VAR == 0 || VAR == 3) {
+                if ((i + 1) % (NMF / NPW_HI) == 0) {
+                    const int q = (i + 1) / (NMF / NPW_HI) - 1;
+                    if (VAR == 0 || q >= NPW_HI / 2) {
+                        SCHED_FENCE();
+                        if (dma && q < NPW_HI && (q < NPW_LO || hi)) glds16(ksrc(s + 3, q), dbase + lds_off[q]);
+                        SCHED_FENCE();
+                    }
+                }
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -393,13 +435,13 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
 // workgroup's tiles all map to its own XCD's chunk).  Measured with rocprofv3 PMC (profiles/r01_mfma_util.md): the
 // one-tile-per-workgroup launch keeps the matrix pipe busy only 41 % of its resident cycles although the K loop alone
 // is at 81 % — every tile boundary costs a workgroup dispatch on a CU that holds nothing else.
-template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT>
+template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        gemm8_bf16_tile<FM, FN, WM, WN, EPI, ACT, FMT>(a, tile, smem);
+        gemm8_bf16_tile<FM, FN, WM, WN, EPI, ACT, FMT, VAR>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) {
             // the ring is reused: this tile's epilogue staging reads and its stores' source data are done with LDS
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -427,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
     constexpr int BM = 256, BN = 256, RB = 64;
     constexpr int XT = BM * RB, WT = BN * RB, STAGE = XT + WT;
     constexpr int NPW = (BM + BN) / 16 / 8;          // 4 one-KiB pieces per wave and step
-    constexpr int NST = FM * (StagedEpi<FN, EPI>::CH / 2);   // global stores per wave in the staged epilogue: 16
+    constexpr int NST = FM * (StagedEpi<FN, EPI>::CH / 2) * (FMT == FMT_SPLIT ? 2 : 1);   // global stores per wave in the staged epilogue: 16 (two planes: 32)
     static_assert(8 * StagedEpi<FN, EPI>::BYTES <= 2 * STAGE, "staging must stay inside ring slots 0 and 1");
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x;
@@ -443,7 +485,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
     const int koff0 = (((0 + fhalf) ^ swz) << 4), koff1 = (((2 + fhalf) ^ swz) << 4);
     const int xrow_off = (wm * 32 * FM + frow) * RB;
     const int wrow_off = XT + (wn * 32 * FN + frow) * RB;
-    const int nt = a.K / 32;
+    const int ntk = a.K / 32;
+    const int nt = FMT == FMT_SPLIT ? 3 * ntk : ntk;
 
     int lds_off[NPW];
     bool isx[NPW];
@@ -467,10 +510,17 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
             g[i] = isx[i] ? a.X + (size_t)(m0 + prow[i]) * a.ldx + c * 8 : a.W + (size_t)(n0 + prow[i]) * a.K + c * 8;
         }
     };
+    auto ksrc = [&](const bf16_t* const (&g)[NPW], int ks, int i) -> const bf16_t* {
+        if constexpr (FMT != FMT_SPLIT) return g[i] + ks * 32;
+        else {
+            const int seg = (ks >= ntk ? 1 : 0) + (ks >= 2 * ntk ? 1 : 0);
+            return g[i] + (ks - seg * ntk) * 32 + (seg == (isx[i] ? 1 : 2) ? (isx[i] ? a.x_lo : a.w_lo) : 0L);
+        }
+    };
     auto stage = [&](const bf16_t* const (&g)[NPW], int ks, int slot) {
         char* base = smem + slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) glds16(g[i] + ks * 32, base + lds_off[i]);
+        for (int i = 0; i < NPW; ++i) glds16(ksrc(g, ks, i), base + lds_off[i]);
     };
 
     const bf16_t* gp[NPW];
@@ -528,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
                 if ((i + 1) % (NMF / NPW) == 0) {
                     const int q = (i + 1) / (NMF / NPW) - 1;
                     SCHED_FENCE();
-                    if (dma) glds16(gp[q] + (s + 3) * 32, dbase + lds_off[q]);
+                    if (dma) glds16(ksrc(gp, s + 3, q), dbase + lds_off[q]);
                     SCHED_FENCE();
                 }
             }
@@ -560,13 +610,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
     }
 }
 
-template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT>
+template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT, int VAR = 0>
 static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDS = 4 * (BM + BN) * 64;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static PerDeviceOnce attr_once;
-    auto kern = gemm8_bf16_kernel<FM, FN, WM, WN, EPI, ACT, FMT>;
+    auto kern = gemm8_bf16_kernel<FM, FN, WM, WN, EPI, ACT, FMT, VAR>;
     if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
@@ -611,6 +661,18 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     }
     int cfg = cfgs[best].id;
     if (a.tune_cfg > 0) cfg = a.tune_cfg - 1;            // per-call override (sylber_set_option / parity tests)
+    if constexpr (FMT == FMT_SPLIT) {
+        // the split-operand mode instantiates the three tile shapes the cost model picks (and nothing else)
+        if (cfg == 3) return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);
+        if (cfg == 10) {
+            if constexpr (EPI == EPI_BF16) {
+                if (a.tune_persist >= 0 && a.M % 256 == 0 && a.N % 256 == 0 && a.K >= 96 && (long)(a.M / 256) * (a.N / 256) > 256)
+                    return launch_cfg8p<ACT, FMT>(a, s);
+            }
+            return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);
+        }
+        return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);
+    } else
     switch (cfg) {
         case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT, FMT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
         case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);   // 128x128, 2 WG/CU
@@ -622,13 +684,25 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
             }
             return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
-        default: return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);  // 128x192, 2 WG/CU
+        case 20: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 1>(a, s); break;   // K-loop schedule A/B
+        case 21: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 2>(a, s); break;
+        case 22: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 3>(a, s); break;
+        default: break;
     }
+    return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);              // 128x192, 2 WG/CU
 }
 
 // operand format (GemmArgs::fmt): the fp16 instantiations exist for the epilogues the fp16 forward uses
 template <int EPI, int ACT>
 static int launch_t(const GemmArgs& a, hipStream_t s) {
+    if (a.fmt == FMT_SPLIT) {
+        // what the split16 forward launches: erf-GELU 16-bit outputs (convs, FFN1), the projection, q/k/v, the residual
+        // GEMMs, and the plain fp32 output of the op-level test entry point
+        if constexpr ((EPI == EPI_BF16 && ACT == ACT_GELU_ERF) || (EPI == EPI_F32 && ACT == ACT_NONE) || EPI == EPI_F32_RESLN ||
+                      EPI == EPI_QK || EPI == EPI_PROJ)
+            return launch_f<EPI, ACT, FMT_SPLIT>(a, s);
+        else { syl_set_error("launch_gemm_bf16", "this epilogue has no split16 instantiation"); return 1; }
+    }
     if (a.fmt == FMT_F16) return launch_f<EPI, ACT, FMT_F16>(a, s);
     return launch_f<EPI, ACT, FMT_BF16>(a, s);
 }

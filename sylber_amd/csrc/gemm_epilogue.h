@@ -98,6 +98,10 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& a, const f32x16_
                     apply_act4<ACT>(v0, v1, v2, v3);
                     uint2 pk; pk.x = H16<FMT>::pack2(v0, v1); pk.y = H16<FMT>::pack2(v2, v3);
                     if (ok) *(uint2*)((bf16_t*)a.out0 + o) = pk;
+                    if constexpr (FMT == FMT_SPLIT) {
+                        uint2 lo; lo.x = H16<FMT>::pack2_lo(v0, v1, pk.x); lo.y = H16<FMT>::pack2_lo(v2, v3, pk.y);
+                        if (ok) *(uint2*)((bf16_t*)a.out0 + a.out_lo + o) = lo;
+                    }
                 } else if constexpr (EPI == EPI_F32) {
                     apply_act4<ACT>(v0, v1, v2, v3);
                     if (ok) *(float4*)((float*)a.out0 + o) = make_float4(v0, v1, v2, v3);
@@ -139,7 +143,9 @@ struct StagedEpi {
 // contiguous (and bits 2/3 of the key index swapped, see attention.hip).  The wave transposes its 32 tokens x 32 FN
 // features through its private LDS region (ds_write_b16 at [feature][pos(token)], 64-byte rows) and stores 16-byte
 // chunks = 8 keys of one feature row; a 32-token block never straddles utterances because Tp % 32 == 0.
-template <int FN, int FMT = FMT_BF16>
+// PLANE = -1: acc + bias, one plane.  FMT_SPLIT: acc already holds the final values (bias is zero); PLANE 0 stores their hi
+// halves, PLANE 1 the lo halves into the plane a.out_lo elements further on.
+template <int FN, int FMT = FMT_BF16, int PLANE = -1>
 __device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x16_t (&acc)[FN], const float4 (&bias)[FN][4], int mrow0,
                                                    int ncol0, char* lds, int lane) {
     const int ml = lane & 31, h = lane >> 5;
@@ -150,10 +156,13 @@ __device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x
         for (int g = 0; g < 4; ++g) {
             const int nl = 32 * fn + 8 * g + 4 * h;
             const float4 bb = bias[fn][g];
-            *(bf16_t*)(lds + (nl + 0) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 0] + bb.x);
-            *(bf16_t*)(lds + (nl + 1) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 1] + bb.y);
-            *(bf16_t*)(lds + (nl + 2) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 2] + bb.z);
-            *(bf16_t*)(lds + (nl + 3) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 3] + bb.w);
+            const float v[4] = {acc[fn][4 * g + 0] + bb.x, acc[fn][4 * g + 1] + bb.y, acc[fn][4 * g + 2] + bb.z, acc[fn][4 * g + 3] + bb.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bf16_t w = H16<FMT>::cvt(v[e]);
+                if constexpr (PLANE == 1) w = H16<FMT_SPLIT>::cvt_lo(v[e], w);
+                *(bf16_t*)(lds + (nl + e) * 64 + pos * 2) = w;
+            }
         }
     if (mrow0 >= a.M) return;
     const int b = mrow0 / a.Tp, t0 = mrow0 - b * a.Tp;
@@ -164,7 +173,7 @@ __device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x
         const int n = ncol0 + f;
         if (n >= a.N) continue;
         const uint4 raw = *(const uint4*)(lds + f * 64 + c * 16);
-        bf16_t* dst = (bf16_t*)a.out2 + ((size_t)b * SYL_HIDDEN + (n - 2 * SYL_HIDDEN)) * a.Tpv + t0 + 8 * c;
+        bf16_t* dst = (bf16_t*)a.out2 + (PLANE == 1 ? a.out_lo : 0L) + ((size_t)b * SYL_HIDDEN + (n - 2 * SYL_HIDDEN)) * a.Tpv + t0 + 8 * c;
         *(uint4*)dst = raw;
         // the key tail [Tp, Tpv) (0 or 32 keys: Tp % 32 == 0, Tpv % 64 == 0) is read by the attention kernel's last
         // tile with P = 0; it must stay finite although the region is shared with the FFN intermediate
@@ -173,15 +182,16 @@ __device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x
 }
 
 // one 32-row block of a wave's tile; `bias` = load_colvec(a.bias, ncol0, ...) of the wave (loaded once per tile)
-template <int FN, int EPI, int ACT, int FMT = FMT_BF16>
+template <int FN, int EPI, int ACT, int FMT = FMT_BF16, int PLANE = -1>
 __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_t (&acc)[FN], const float4 (&bias)[FN][4], int mrow0,
                                                 int ncol0, char* lds, int lane) {
     using S = StagedEpi<FN, EPI>;
+    const long plane_off = PLANE == 1 ? a.out_lo : 0L;
     if constexpr (EPI == EPI_QK) {
         // one launch for q, k and v (N = 2304): the V third leaves through the transposing epilogue (wave-uniform:
         // every wave's column range lies inside one third, 768 being a multiple of every wave width in use)
         static_assert(FN * 32 * 64 <= S::BYTES, "V^T staging must fit the wave's region");
-        if (ncol0 >= 2 * SYL_HIDDEN) { epilogue_vt_rows32<FN, FMT>(a, acc, bias, mrow0, ncol0, lds, lane); return; }
+        if (ncol0 >= 2 * SYL_HIDDEN) { epilogue_vt_rows32<FN, FMT, PLANE>(a, acc, bias, mrow0, ncol0, lds, lane); return; }
     }
     const int ml = lane & 31, h = lane >> 5;
     const int m = mrow0 + ml;
@@ -193,7 +203,7 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
         const int nv = a.valid[b] < a.T ? a.valid[b] : a.T;
         zero_row = t >= nv;                              // TP:428-431 zero padded frames (and rows beyond T)
     }
-    const float qs = (EPI == EPI_QK && ncol0 < SYL_HIDDEN) ? 0.125f : 1.0f;     // q third pre-scaled by 64^-0.5 (exact)
+    const float qs = (EPI == EPI_QK && ncol0 < SYL_HIDDEN && PLANE < 0) ? 0.125f : 1.0f;     // q third pre-scaled by 64^-0.5 (exact)
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
@@ -201,7 +211,7 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
             const int nl = 32 * fn + 8 * g + 4 * h;
             const float4 bb = bias[fn][g];
             float v0 = acc[fn][4 * g + 0] + bb.x, v1 = acc[fn][4 * g + 1] + bb.y, v2 = acc[fn][4 * g + 2] + bb.z, v3 = acc[fn][4 * g + 3] + bb.w;
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_F32) {
+            if constexpr ((EPI == EPI_BF16 || EPI == EPI_F32) && PLANE < 0) {
                 apply_act4<ACT>(v0, v1, v2, v3);
             }
             if constexpr (EPI == EPI_QK) { v0 *= qs; v1 *= qs; v2 *= qs; v3 *= qs; }
@@ -210,6 +220,7 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
                 *(float4*)(lds + ml * S::RS + nl * 4) = make_float4(v0, v1, v2, v3);
             } else {
                 uint2 pk; pk.x = H16<FMT>::pack2(v0, v1); pk.y = H16<FMT>::pack2(v2, v3);
+                if constexpr (PLANE == 1) { pk.x = H16<FMT_SPLIT>::pack2_lo(v0, v1, pk.x); pk.y = H16<FMT_SPLIT>::pack2_lo(v2, v3, pk.y); }
                 *(uint2*)(lds + ml * S::RS + nl * 2) = pk;
             }
         }
@@ -223,7 +234,7 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
         if (mo >= a.M || n >= a.N) continue;
         const uint4 raw = *(const uint4*)(lds + r * S::RS + c * 16);
         if constexpr (EPI == EPI_BF16) {
-            *(uint4*)((bf16_t*)a.out0 + (size_t)mo * a.ld0 + n) = raw;
+            *(uint4*)((bf16_t*)a.out0 + plane_off + (size_t)mo * a.ld0 + n) = raw;
         } else if constexpr (EPI == EPI_F32) {
             *(uint4*)((float*)a.out0 + (size_t)mo * a.ld0 + n) = raw;
         } else if constexpr (EPI == EPI_QK) {
@@ -231,13 +242,17 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
             const int nn = n - which * SYL_HIDDEN;
             const int head = nn >> 6, d = nn & 63;
             const int b = mo / a.Tp, t = mo - b * a.Tp;
-            *(uint4*)((bf16_t*)(which ? a.out1 : a.out0) + (((size_t)b * SYL_HEADS + head) * a.Tp + t) * 64 + d) = raw;
+            *(uint4*)((bf16_t*)(which ? a.out1 : a.out0) + plane_off + (((size_t)b * SYL_HEADS + head) * a.Tp + t) * 64 + d) = raw;
         } else if constexpr (EPI == EPI_PROJ) {
             const float4 v = __builtin_bit_cast(float4, raw);
             *(float4*)((float*)a.out0 + (size_t)mo * a.ld0 + n) = v;
             const int b = mo / a.Tp, t = mo - b * a.Tp;
             uint2 pk; pk.x = H16<FMT>::pack2(v.x, v.y); pk.y = H16<FMT>::pack2(v.z, v.w);
             *(uint2*)((bf16_t*)a.out1 + ((size_t)b * a.xpad_rows + 64 + t) * SYL_HIDDEN + n) = pk;
+            if constexpr (FMT == FMT_SPLIT) {
+                uint2 lo; lo.x = H16<FMT>::pack2_lo(v.x, v.y, pk.x); lo.y = H16<FMT>::pack2_lo(v.z, v.w, pk.y);
+                *(uint2*)((bf16_t*)a.out1 + a.out_lo + ((size_t)b * a.xpad_rows + 64 + t) * SYL_HIDDEN + n) = lo;
+            }
         }
     }
 }
@@ -247,6 +262,34 @@ template <int FM, int FN, int EPI, int ACT, int FMT = FMT_BF16>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& a, const f32x16_t (&acc)[FM][FN], int mrow0, int ncol0, char* lds, int lane) {
     float4 bias[FN][4];
     load_colvec<FN>(a.bias, ncol0, lane >> 5, a.N, bias);
+    if constexpr (FMT == FMT_SPLIT && !StagedEpi<FN, EPI>::F32OUT) {
+        // two planes: the final fp32 values (bias, activation, q scaling) are formed ONCE, in place of the accumulators,
+        // then their hi halves and their lo halves go through the wave's staging region one after the other (LDS
+        // operations of one wave execute in order, so pass 1 may overwrite what pass 0 has read)
+        f32x16_t v[FM][FN];
+        const float qs = (EPI == EPI_QK && ncol0 < SYL_HIDDEN) ? 0.125f : 1.0f;
 #pragma unroll
-    for (int fm = 0; fm < FM; ++fm) epilogue_rows32<FN, EPI, ACT, FMT>(a, acc[fm], bias, mrow0 + fm * 32, ncol0, lds, lane);
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v0 = acc[fm][fn][4 * g + 0] + bias[fn][g].x, v1 = acc[fm][fn][4 * g + 1] + bias[fn][g].y;
+                    float v2 = acc[fm][fn][4 * g + 2] + bias[fn][g].z, v3 = acc[fm][fn][4 * g + 3] + bias[fn][g].w;
+                    if constexpr (EPI == EPI_BF16) apply_act4<ACT>(v0, v1, v2, v3);
+                    v[fm][fn][4 * g + 0] = v0 * qs; v[fm][fn][4 * g + 1] = v1 * qs; v[fm][fn][4 * g + 2] = v2 * qs; v[fm][fn][4 * g + 3] = v3 * qs;
+                }
+        float4 zero[FN][4];
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) zero[fn][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) epilogue_rows32<FN, EPI, ACT, FMT, 0>(a, v[fm], zero, mrow0 + fm * 32, ncol0, lds, lane);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) epilogue_rows32<FN, EPI, ACT, FMT, 1>(a, v[fm], zero, mrow0 + fm * 32, ncol0, lds, lane);
+    } else {
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) epilogue_rows32<FN, EPI, ACT, FMT>(a, acc[fm], bias, mrow0 + fm * 32, ncol0, lds, lane);
+    }
 }

@@ -35,7 +35,9 @@ struct GemmArgs {
     int xpad_rows;                // rows per utterance of the zero-padded pos-conv input (EPI_PROJ)
     const float* ln_stats;        // [M][2] (mean, rstd) of the rows of `res` (EPI_F32_RESLN)
     const float* ln_gamma; const float* ln_beta;
-    int fmt;                      // FMT_BF16 (0) or FMT_F16: 16-bit format of X, W and of bf16-typed outputs
+    int fmt;                      // FMT_BF16 (0), FMT_F16 or FMT_SPLIT: 16-bit format of X, W and of bf16-typed outputs
+    long x_lo, w_lo;              // FMT_SPLIT: element offsets of the lo planes of X and W (hi plane at the pointer)
+    long out_lo;                  // FMT_SPLIT: element offset of the lo plane of every 16-bit output (out0 / out1 / out2)
     int tune_cfg;                 // 0 = tile shape chosen by the cost model; k > 0 forces tile configuration k - 1
     int tune_persist;             // > 0: persistent launch (that many workgroups per CU walk the tile list)
 };

@@ -321,9 +321,14 @@ class Segmenter:
             # read it: encode_batch returns without synchronising, so the host must not refill a buffer whose copy is
             # still queued behind an earlier forward.
             stage, slot = self._stage_buffer((len(rows), lmax))
+            # the padding runs through numpy views, NOT torch CPU ops: on a many-core host every small torch op wakes
+            # the intra-op thread pool (128 threads on the MI355X boxes), which made one call cost anything from 10 ms
+            # to 1.8 s (tools/api_profile.py: 9.4-9.9 ms with one thread, 9.8-188 ms with the default pool)
+            stage_np = stage.numpy()
             for i, r in enumerate(rows):
-                stage[i, : lengths[i]] = r
-                stage[i, lengths[i]:] = 0.0
+                src = r.detach()
+                stage_np[i, : lengths[i]] = (src if src.dtype == torch.float32 else src.to(torch.float32)).numpy()
+                stage_np[i, lengths[i]:] = 0.0
             batch = torch.empty(len(rows), lmax, dtype=torch.float32, device=dev)
             batch.copy_(stage, non_blocking=True)
             slot["event"].record(torch.cuda.current_stream(dev))

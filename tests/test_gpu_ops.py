@@ -86,7 +86,7 @@ def test_attention(lib, B, T, valid, qw):
     assert (o.cpu() - ref).pow(2).mean().sqrt().item() < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11])
+@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11, 20, 21, 22])
 def test_linear_every_tile_config(lib, cfg):
     """every GEMM tile configuration (4-wave 2/3-slot rings, 8-wave staggered big tiles) gives the same
     result, including ragged M / N tails and a strided (overlapping-row) activation operand"""
@@ -101,6 +101,22 @@ def test_linear_every_tile_config(lib, cfg):
         _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 1, 0, cfg, None), "op_linear")
         ref = torch.nn.functional.gelu(_bf(a) @ _bf(w).T + b)
         assert (c.cpu() - ref).abs().max().item() < 2e-3, (cfg, M, N, K)
+
+
+@pytest.mark.parametrize("cfg", [20, 21, 22])
+def test_gemm8_schedule_variants_bitwise(lib, cfg):
+    """the K-loop schedule variants of the 8-wave kernel (where the LDS-DMA of step s+3 is issued) contract in the same
+    order: bit-identical to the default schedule on a full-size launch, run to run (a hand-off race would show here)"""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(23)
+    M, N, K = 16384, 3072, 768
+    ad = torch.randn(M, K, generator=g).cuda(); wd = (torch.randn(N, K, generator=g) / K ** 0.5).cuda(); bd = torch.randn(N, generator=g).cuda()
+    ref = torch.empty(M, N, device="cuda")
+    _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(ref), M, N, K, 1, 0, 9010, None), "op_linear")
+    for _ in range(3):
+        c = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 1, 0, 9000 + cfg, None), "op_linear")
+        assert torch.equal(c, ref), cfg
 
 
 def test_attention_full_batch_no_race(lib):
