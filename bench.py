@@ -50,7 +50,7 @@ def parse_args():
                     help="N>1: time resident shards (no data-path collective) as `value`; the exchange figure moves to `exchange`")
     ap.add_argument("--no-overlap", action="store_true", help="one batch in flight, segmenter on the forward stream")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight (independent handles/streams)")
-    ap.add_argument("--precision", choices=["bf16", "fp8", "fp32", "fp16", "mixed16"], default="bf16",
+    ap.add_argument("--precision", choices=["bf16", "fp8", "fp32", "fp16", "mixed16", "split16"], default="bf16",
                     help="bf16 = BASELINE configs[1] (the headline); fp8 = configs[4] (MXFP8 weight GEMMs); fp32 = the exact "
                          "parity mode (f32 MFMA), reported so that its cost is a number")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph (small, launch-bound batches)")
@@ -364,7 +364,8 @@ def main():
     def build_line(value_, elapsed_, med_, exchange_first_, roofline_=None, frontend_=None, cpu_=None, api_=None, kernels_=None,
                    seg_stats_=None):
         dtype = {"bf16": "bf16", "fp8": "bf16 + mxfp8 (e4m3, E8M0 block scales) weight GEMMs", "fp32": "f32", "fp16": "f16 (IEEE half operands, f32 accumulate)",
-                 "mixed16": "f16 conv stack + bf16 encoder (f32 accumulate)"}[args.precision]
+                 "mixed16": "f16 conv stack + bf16 encoder (f32 accumulate)",
+                 "split16": "f16 hi/lo operand pairs, three MFMA passes per contraction (f32 accumulate, erf GELU)"}[args.precision]
         # which BASELINE.json configuration this run IS (the label follows the arguments, not the default)
         is10 = clip_samples == CLIP_SAMPLES and not args.ragged
         if is10 and B == BATCH_PER_GPU and args.precision == "bf16":

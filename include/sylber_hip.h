@@ -42,7 +42,11 @@ typedef struct sylber_ctx* sylber_t;
  * with the fp32 reference: DESIGN.md) */
 /* SYLBER_MIXED16: the conv stack as SYLBER_FP16 (that is where the bf16 mode makes its error: 13 hand-overs of O(1)
  * activations), the encoder as SYLBER_BF16; the feature-projection LayerNorm converts (measured cost / agreement: DESIGN.md) */
-enum { SYLBER_BF16 = 0, SYLBER_FP32 = 1, SYLBER_FP8 = 2, SYLBER_FP16 = 3, SYLBER_MIXED16 = 4 };
+/* SYLBER_SPLIT16: every MFMA operand (activations and weights) is a PAIR of IEEE halves, hi = half(x) and lo = half(x - hi)
+ * (22 significand bits), and every contraction is three fp16 MFMA passes into one fp32 accumulator (hi.hi + lo.hi + hi.lo);
+ * erf GELU, fp32 residual stream / statistics as everywhere.  fp32-grade decisions (segment tables as the fp32 mode's)
+ * at about three times the fp16 step instead of the fourteen times of SYLBER_FP32's f32 MFMA. */
+enum { SYLBER_BF16 = 0, SYLBER_FP32 = 1, SYLBER_FP8 = 2, SYLBER_FP16 = 3, SYLBER_MIXED16 = 4, SYLBER_SPLIT16 = 5 };
 
 /* HOST pointers to fp32 weights in the layout of HubertModel.state_dict().
  * Replaces the state_dict hand-over at sylber.py:51-54. */

@@ -14,6 +14,10 @@ extern "C" {
  * cfg in [100, 200): the MXFP8 GEMM with tile configuration cfg - 100 */
 int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
                             int32_t iters, float* ms_out);
+/* the same launch through the TRACE instantiation of the 8-wave 256x256 kernel (s_memtime stamps around the phases of its K
+ * loop): out20 = 2 x 10 shader-cycle counters of workgroup 0's waves 0 and 4 (csrc/api.hip sylber_debug_gemm_trace) */
+int sylber_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, unsigned long long* out20,
+                            float* ms_out);
 #ifdef __cplusplus
 }
 #endif

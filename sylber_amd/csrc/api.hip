@@ -101,6 +101,13 @@ struct Packer {
     size_t add_f32(const float* src, size_t n) { size_t o = add(n * 4); memcpy(host.data() + o, src, n * 4); return o; }
     int fmt = FMT_BF16;           // 16-bit format of the MFMA operands (FMT_F16 for SYLBER_FP16)
     size_t add_bf16(const float* src, size_t n) {
+        if (fmt == FMT_SPLIT) {
+            // two half planes: hi = half(w) at [0, n), lo = half(w - hi) at [n, 2n)
+            size_t o = add(n * 4);
+            bf16_t* d = (bf16_t*)(host.data() + o);
+            for (size_t i = 0; i < n; ++i) { d[i] = f2h_host(src[i]); d[n + i] = f2h_host(src[i] - h2f_host(d[i])); }
+            return o;
+        }
         size_t o = add(n * 2);
         bf16_t* d = (bf16_t*)(host.data() + o);
         if (fmt == FMT_F16) for (size_t i = 0; i < n; ++i) d[i] = f2h_host(src[i]);
@@ -112,13 +119,13 @@ struct Packer {
 extern "C" int sylber_create(const SylberWeights* w, int device, int precision, sylber_t* out) {
     if (!w || !out) { syl_set_error("sylber_create", "null argument"); return 1; }
     if (w->num_layers < 1 || w->num_layers > SYLBER_MAX_LAYERS) { syl_set_error("sylber_create", "num_layers out of range"); return 1; }
-    if (precision != SYLBER_BF16 && precision != SYLBER_FP32 && precision != SYLBER_FP8 && precision != SYLBER_FP16 && precision != SYLBER_MIXED16) { syl_set_error("sylber_create", "unknown precision"); return 1; }
+    if (precision != SYLBER_BF16 && precision != SYLBER_FP32 && precision != SYLBER_FP8 && precision != SYLBER_FP16 && precision != SYLBER_MIXED16 && precision != SYLBER_SPLIT16) { syl_set_error("sylber_create", "unknown precision"); return 1; }
     const bool f32 = precision == SYLBER_FP32;
     GUARD_DEVICE(device);
     sylber_ctx* c = new sylber_ctx();
     c->device = device; c->precision = precision; c->num_layers = w->num_layers;
-    c->fmt = precision == SYLBER_FP16 ? FMT_F16 : FMT_BF16;
-    c->fmt_conv = (precision == SYLBER_FP16 || precision == SYLBER_MIXED16) ? FMT_F16 : FMT_BF16;
+    c->fmt = precision == SYLBER_FP16 ? FMT_F16 : (precision == SYLBER_SPLIT16 ? FMT_SPLIT : FMT_BF16);
+    c->fmt_conv = (precision == SYLBER_FP16 || precision == SYLBER_MIXED16) ? FMT_F16 : (precision == SYLBER_SPLIT16 ? FMT_SPLIT : FMT_BF16);
     Packer P;
     P.fmt = c->fmt_conv;                                 // conv weights first
     size_t o_conv0 = P.add_f32(w->conv_w[0], 512 * 10);
@@ -285,9 +292,11 @@ struct Plan {
         total;
     int nchunk;
     bool zero_all = false;        // fp32 parity plan: its own offsets, zero everything on a layout change
+    // SYLBER_SPLIT16: every 16-bit buffer holds two half planes; element offsets of the lo planes (0 otherwise)
+    long lo_bufA = 0, lo_bufB = 0, lo_ln512 = 0, lo_xpad = 0, lo_hbf = 0, lo_qk = 0, lo_vt = 0, lo_ctx = 0, lo_ffn = 0;
 };
 
-static void make_plan(int B, int Lmax, Plan& p) {
+static void make_plan(int B, int Lmax, Plan& p, int planes = 1) {
     p.B = B; p.Lmax = Lmax;
     int n = Lmax;
     for (int i = 0; i < 7; ++i) { n = (n - CK[i]) / CS[i] + 1; p.L[i] = n; }
@@ -298,25 +307,33 @@ static void make_plan(int B, int Lmax, Plan& p) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t M = (size_t)B * p.Tp;
-    p.o_bufA = take(((size_t)B * p.R[0] + 8) * 512 * 2);
-    p.o_bufB = take(((size_t)B * p.R[1] + 8) * 512 * 2);
-    p.o_ln512 = take(M * 512 * 2);
+    const size_t P = (size_t)planes;
+    p.o_bufA = take(((size_t)B * p.R[0] + 8) * 512 * 2 * P);
+    p.o_bufB = take(((size_t)B * p.R[1] + 8) * 512 * 2 * P);
+    p.o_ln512 = take(M * 512 * 2 * P);
     p.o_xf32 = take(M * 768 * 4);
-    p.o_xpad = take((size_t)B * (p.Tp + 128) * 768 * 2);
+    p.o_xpad = take((size_t)B * (p.Tp + 128) * 768 * 2 * P);
     p.o_pre = take(M * 768 * 4);
     p.o_stats = take(M * 2 * 4);
-    p.o_hbf16 = take((M + 128) * 768 * 2);
+    p.o_hbf16 = take((M + 128) * 768 * 2 * P);
+    if (planes == 2) {
+        p.lo_bufA = (long)(((size_t)B * p.R[0] + 8) * 512); p.lo_bufB = (long)(((size_t)B * p.R[1] + 8) * 512);
+        p.lo_ln512 = (long)(M * 512); p.lo_xpad = (long)((size_t)B * (p.Tp + 128) * 768); p.lo_hbf = (long)((M + 128) * 768);
+        p.lo_qk = (long)(M * 768); p.lo_vt = (long)((size_t)B * 12 * 64 * p.Tpv); p.lo_ctx = (long)((M + 128) * 768);
+        p.lo_ffn = (long)((M + 128) * 3072);
+        p.zero_all = true;        // pad regions of both planes: zero the workspace on a layout change
+    }
     // q, k, V^T and the attention context are dead by the time FFN1 writes its intermediate, and that is dead before the
     // next layer's q/k/v projection: the FFN intermediate ALIASES them, which keeps a layer's working set
     // (residual stream + bf16 copy + this region + weights = ~190 MB at 32 x 10 s) inside the 256 MB Infinity Cache
     const size_t attn_begin = off;
-    p.o_q = take(M * 768 * 2);
-    p.o_k = take(M * 768 * 2);
-    p.o_vt = take((size_t)B * 12 * 64 * p.Tpv * 2);
-    p.o_ctx = take((M + 128) * 768 * 2);
+    p.o_q = take(M * 768 * 2 * P);
+    p.o_k = take(M * 768 * 2 * P);
+    p.o_vt = take((size_t)B * 12 * 64 * p.Tpv * 2 * P);
+    p.o_ctx = take((M + 128) * 768 * 2 * P);
     p.o_ffn = attn_begin;
     {
-        const size_t need = (M + 128) * 3072 * 2;
+        const size_t need = (M + 128) * 3072 * 2 * P;
         if (off - attn_begin < need) take(need - (off - attn_begin));
     }
     p.nchunk = (p.L[0] + 2047) / 2048;
@@ -439,21 +456,26 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     // ---- conv layer 0 + GroupNorm + GELU
     RUN("conv0_stats", launch_conv0_stats(wav_dev, B, Lmax, p.L[0], part, p.nchunk, s));
     RUN("conv0_finalize", launch_conv0_finalize(part, p.nchunk, c->conv0_w, c->gn_w, c->gn_b, B, p.L[0], ss, s));
-    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s, c->fmt_conv));
+    const bool split = c->precision == SYLBER_SPLIT16;      // hi / lo half planes, erf GELU (fp32-grade decisions)
+    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s, c->fmt_conv, p.lo_bufA));
     // ---- conv layers 1..6 as implicit GEMM (ping-pong)
     bf16_t* src = bufA; bf16_t* dst = bufB;
+    long src_lo = p.lo_bufA, dst_lo = p.lo_bufB;
     for (int i = 1; i < 7; ++i) {
         GemmArgs a = {};
         a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w[i];
-        a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = ACT_GELU_FAST;
+        a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = split ? ACT_GELU_ERF7 : ACT_GELU_FAST;
         a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.fmt = c->fmt_conv;
+        a.x_lo = src_lo; a.w_lo = (long)512 * CK[i] * 512; a.out_lo = dst_lo;
         static const char* nm[7] = {"", "gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_conv6"};
         RUN(nm[i], launch_gemm_bf16(EPI_BF16, a, s));
         bf16_t* t = src; src = dst; dst = t;
+        const long tl = src_lo; src_lo = dst_lo; dst_lo = tl;
     }
     bf16_t* feats = src;   // [B*Tp][512]
+    const long feats_lo = src_lo;
     if (c->stop_stage == 1) {
-        RUN("copy_out", launch_bf16_to_f32_rows(feats, 512, hidden_dev, B, p.Tp, p.T, 512, s, c->fmt_conv));
+        RUN("copy_out", launch_bf16_to_f32_rows(feats, 512, hidden_dev, B, p.Tp, p.T, 512, s, c->fmt_conv, feats_lo));
         return 0;
     }
     // ---- feature projection: LN(512) -> Linear(512->768), zero padded frames
@@ -461,14 +483,16 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         LnArgs a = {};
         a.in = feats; a.in_bf16 = 1; a.ld_in = 512; a.gamma = c->fp_ln_w; a.beta = c->fp_ln_b;
         a.out_bf16 = ln512; a.ld_bf16 = 512; a.M = M; a.D = 512; a.fmt = c->fmt; a.fmt_in = c->fmt_conv;
+        a.in_lo = feats_lo; a.out_lo = p.lo_ln512;
         RUN("ln512", launch_layernorm(a, s));
         GemmArgs g = {};
         g.X = ln512; g.ldx = 512; g.W = c->fp_w; g.M = M; g.N = 768; g.K = 512; g.bias = c->fp_b;
         g.out0 = xf32; g.ld0 = 768; g.out1 = xpad; g.Tp = p.Tp; g.T = p.T; g.valid = valid; g.xpad_rows = p.Tp + 128; g.fmt = c->fmt;
+        g.x_lo = p.lo_ln512; g.w_lo = (long)768 * 512; g.out_lo = p.lo_xpad;
         RUN("gemm_proj", launch_gemm_bf16(EPI_PROJ, g, s));
     }
     // ---- positional conv + residual, encoder LayerNorm
-    RUN("posconv", launch_posconv(xpad, c->pos_w, c->pos_b, xf32, pre, B, p.Tp, 1, s, c->fmt));
+    RUN("posconv", launch_posconv(xpad, c->pos_w, c->pos_b, xf32, pre, B, p.Tp, split ? 2 : 1, s, c->fmt, p.lo_xpad, (long)16 * 128 * 64 * 56));
     // SYLBER_FP8: the FFN runs on MXFP8 operands; the LayerNorm in front of it then emits e4m3 + E8M0 block scales
     // instead of bf16 (into the same buffer), and FFN1 leaves its GELU output as MXFP8 for FFN2
     const bool f8 = c->precision == SYLBER_FP8;
@@ -481,7 +505,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         a.in = pre; a.in_bf16 = 0; a.ld_in = 768; a.gamma = gam; a.beta = bet; a.M = M; a.D = 768; a.fmt = c->fmt; a.fmt_in = c->fmt;
         if (last) { a.out_f32 = hidden_dev; a.ld_f32 = 768; a.Tp = p.Tp; a.T = p.T; }
         else if (to_fp8) { a.out_fp8 = h8; a.ld_fp8 = 768; a.out_scale = h8s; a.scale_rows = Mp; a.out_stats = stats; }
-        else { a.out_bf16 = hbf; a.ld_bf16 = 768; a.out_stats = stats; }   // no fp32 copy: see EPI_F32_RESLN
+        else { a.out_bf16 = hbf; a.ld_bf16 = 768; a.out_stats = stats; a.out_lo = p.lo_hbf; }   // no fp32 copy: see EPI_F32_RESLN
         return launch_layernorm(a, s);
     };
     RUN("layernorm", run_ln(c->enc_ln_w, c->enc_ln_b, c->stop_stage == 2, f8));
@@ -505,6 +529,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 2304; g.K = 768; g.bias = d.bqkv;
             g.out0 = q; g.out1 = k; g.out2 = vt; g.Tp = p.Tp; g.Tpv = p.Tpv; g.T = p.T;
             g.tune_cfg = c->opt_gemm_cfg; g.tune_persist = c->opt_gemm_persist; g.fmt = c->fmt;
+            g.x_lo = p.lo_hbf; g.w_lo = (long)2304 * 768; g.out_lo = p.lo_qk; g.out2_lo = p.lo_vt;
             RUN("gemm_qkv", launch_gemm_bf16(EPI_QK, g, s));
         }
         if (f8) {
@@ -515,11 +540,12 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             o.X8 = ctx8; o.ldx8 = 768; o.XS = ctx8s; o.xs_rows = Mp; o.W8 = d.woq; o.WS = d.wos; o.ws_rows = 768;
             RUN("gemm_out", launch_gemm_mxfp8(EPI_F32_RESLN, o, s));
         } else {
-        RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, c->opt_attn_qw, s, c->fmt));
+        RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, c->opt_attn_qw, s, c->fmt, p.lo_qk, p.lo_vt, p.lo_ctx));
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
         o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
         o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist; o.fmt = c->fmt;
+        o.x_lo = p.lo_ctx; o.w_lo = (long)768 * 768;
         RUN("gemm_out", launch_gemm_bf16(EPI_F32_RESLN, o, s));
         }
         RUN("layernorm", run_ln(d.ln1w, d.ln1b, false, f8));
@@ -535,13 +561,15 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             RUN("gemm_ffn2", launch_gemm_mxfp8(EPI_F32_RESLN, f2, s));
         } else {
         GemmArgs f1 = {};
-        f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = 1;
+        f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = split ? ACT_GELU_ERF7 : ACT_GELU_FAST;
         f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist; f1.fmt = c->fmt;
+        f1.x_lo = p.lo_hbf; f1.w_lo = (long)3072 * 768; f1.out_lo = p.lo_ffn;
         RUN("gemm_ffn1", launch_gemm_bf16(EPI_BF16, f1, s));
         GemmArgs f2 = {};
         f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
         f2.out0 = pre; f2.ld0 = 768; f2.res = pre; f2.ldres = 768; f2.ln_stats = stats; f2.ln_gamma = d.ln1w; f2.ln_beta = d.ln1b;
         f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist; f2.fmt = c->fmt;
+        f2.x_lo = p.lo_ffn; f2.w_lo = (long)768 * 3072;
         RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RESLN, f2, s));
         }
         RUN("layernorm", run_ln(d.ln2w, d.ln2b, last, f8));
@@ -575,7 +603,7 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
     hipStream_t s = (hipStream_t)stream;
     GUARD_DEVICE(c->device);
     Plan p;
-    make_plan(B, Lmax, p);
+    make_plan(B, Lmax, p, c->precision == SYLBER_SPLIT16 ? 2 : 1);
     char* ws_before = c->ws;
     if (ensure_workspace(c, p, s)) return 1;
     if (c->ws != ws_before) graphs_clear(c);           // captured graphs hold workspace addresses
@@ -750,7 +778,23 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
         HIP_TRY(hipStreamSynchronize(s));
         return 0;
     }
-    if (precision != SYLBER_BF16) { syl_set_error("sylber_op_linear", "precision must be bf16 or fp8"); return 1; }
+    if (precision == SYLBER_SPLIT16) {
+        // both operands as hi / lo half planes, three MFMA passes into one fp32 accumulator
+        TmpBuf ab, wb;
+        const long xp = (((long)M + 128) * K + 255) & ~255L, wp = (((long)N + 128) * K + 255) & ~255L;
+        if (ab.alloc((size_t)xp * 4) || wb.alloc((size_t)wp * 4)) { syl_set_error("sylber_op_linear", "alloc"); return 1; }
+        HIP_TRY(hipMemsetAsync(ab.p, 0, (size_t)xp * 4, s)); HIP_TRY(hipMemsetAsync(wb.p, 0, (size_t)wp * 4, s));
+        if (launch_f32_to_split16(a_dev, (bf16_t*)ab.p, xp, (size_t)M * K, s)) return 1;
+        if (launch_f32_to_split16(w_dev, (bf16_t*)wb.p, wp, (size_t)N * K, s)) return 1;
+        GemmArgs g = {};
+        g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev; g.act = act;
+        g.out0 = c_dev; g.ld0 = N; g.fmt = FMT_SPLIT; g.x_lo = xp; g.w_lo = wp;
+        g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+        if (launch_gemm_bf16(EPI_F32, g, s)) return 1;
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }
+    if (precision != SYLBER_BF16) { syl_set_error("sylber_op_linear", "precision must be bf16, fp8 or split16"); return 1; }
     TmpBuf ab, wb;
     if (ab.alloc(((size_t)M + 128) * K * 2) || wb.alloc(((size_t)N + 128) * K * 2)) { syl_set_error("sylber_op_linear", "alloc"); return 1; }
     if (launch_f32_to_bf16(a_dev, (bf16_t*)ab.p, (size_t)M * K, s)) return 1;
@@ -884,8 +928,8 @@ static int gemm_bench_f8(int M, int N, int K, int epi, int act, int cfg, int ite
     return rc;
 }
 
-extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
-                                       int32_t iters, float* ms_out) {
+static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg, int32_t iters,
+                           float* ms_out, unsigned long long* g_gemm_trace_out) {
     if (cfg >= 100 && cfg < 200) return gemm_bench_f8(M, N, K, epi, act, cfg - 100, iters, ms_out);
     TmpBuf xb, wb, ob, rb, bb;
     const size_t xn = (size_t)(M + 8) * ldx + K, wn = (size_t)N * K;
@@ -912,6 +956,16 @@ extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t 
     }
     g.tune_cfg = cfg < 0 ? 0 : (cfg % 1000) + 1;
     g.tune_persist = cfg >= 9000 ? -1 : (cfg >= 1000 ? cfg / 1000 : 0);    // cfg = persist * 1000 + tile (9000 + tile: persist = -1)
+    TmpBuf trb;
+    if (g_gemm_trace_out) {
+        if (trb.alloc(20 * 8)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }
+        HIP_TRY(hipMemset(trb.p, 0, 20 * 8));
+        g.trace = (unsigned long long*)trb.p;
+    }
+    struct TraceFetch {
+        TmpBuf& b; unsigned long long* dst;
+        ~TraceFetch() { if (dst && b.p) { hipDeviceSynchronize(); hipMemcpy(dst, b.p, 20 * 8, hipMemcpyDeviceToHost); } }
+    } trace_fetch{trb, g_gemm_trace_out};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     int rc = 0;
@@ -925,4 +979,19 @@ extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t 
     *ms_out = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
     return rc;
+}
+
+extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
+                                       int32_t iters, float* ms_out) {
+    return gemm_bench_impl(M, N, K, ldx, epi, act, cfg, iters, ms_out, nullptr);
+}
+
+// the trace instantiation of the 8-wave kernel (tile id 30: s_memtime stamps around the phases of the K loop): one
+// launch series, then the 2 x 10 cycle counters of workgroup 0's waves 0 (group 0) and 4 (group 1):
+// [0] sum A (loop top -> fragments landed), [1] sum barrier after A, [2] sum B (MFMA + DMA issue), [3] sum barrier after B,
+// [4] K loop total, [5] steps, [6] cost of one stamp, [7] epilogue, [8] prologue, [9] tile total
+extern "C" int sylber_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act,
+                                       unsigned long long* out20, float* ms_out) {
+    if (!out20 || !ms_out) { syl_set_error("sylber_debug_gemm_trace", "null argument"); return 1; }
+    return gemm_bench_impl(M, N, K, ldx, epi, act, 9030, 3, ms_out, out20);
 }

@@ -31,7 +31,7 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 // 1/l and the store of one 32-query sub-tile: ctx[b*Tp + q][head*64 + d] (or its MXFP8 form)
 template <bool F8, int FMT>
 __device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l_run, bf16_t* __restrict__ ctx, uint8_t* __restrict__ ctx_scale,
-                                              long scale_rows, int b, int head, int q_first, int ql, int h, int T, int Tp) {
+                                              long scale_rows, int b, int head, int q_first, int ql, int h, int T, int Tp, long lo_ctx = 0) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         const int q = q_first + ql;
@@ -80,6 +80,19 @@ __device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l
                     got.x = (unsigned)__shfl_xor((int)send.x, 32, 64); got.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
                     const uint4 out = h ? make_uint4(got.x, got.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, got.x, got.y);
                     if (q < T) *(uint4*)(dst + 32 * ds + 16 * pr + 8 * h) = out;
+                    if constexpr (FMT == FMT_SPLIT) {
+                        // the lo halves of the same eight values, exchanged the same way
+                        uint2 la, lb;
+                        la.x = H16<FMT>::pack2_lo(oacc[ds][8 * pr + 0] * inv, oacc[ds][8 * pr + 1] * inv, ra.x);
+                        la.y = H16<FMT>::pack2_lo(oacc[ds][8 * pr + 2] * inv, oacc[ds][8 * pr + 3] * inv, ra.y);
+                        lb.x = H16<FMT>::pack2_lo(oacc[ds][8 * pr + 4] * inv, oacc[ds][8 * pr + 5] * inv, rb.x);
+                        lb.y = H16<FMT>::pack2_lo(oacc[ds][8 * pr + 6] * inv, oacc[ds][8 * pr + 7] * inv, rb.y);
+                        const uint2 keepl = h ? lb : la, sendl = h ? la : lb;
+                        uint2 gl;
+                        gl.x = (unsigned)__shfl_xor((int)sendl.x, 32, 64); gl.y = (unsigned)__shfl_xor((int)sendl.y, 32, 64);
+                        const uint4 outl = h ? make_uint4(gl.x, gl.y, keepl.x, keepl.y) : make_uint4(keepl.x, keepl.y, gl.x, gl.y);
+                        if (q < T) *(uint4*)(dst + lo_ctx + 32 * ds + 16 * pr + 8 * h) = outl;
+                    }
                 }
         }
 }
@@ -88,11 +101,16 @@ __device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l
 // MFMA (every K / V^T fragment feeds two MFMAs) but runs three waves per SIMD instead of four; the kernel is bound by
 // the dependent chain S -> max -> exp -> P.V inside a wave (removing the exps, or either MFMA group, outright buys
 // 10-15 %: tools/ubench/attn_ablate.sh), so the extra resident wave wins.
+// FMT_SPLIT: q, k, V^T and the probabilities are hi / lo half pairs; S^T and O^T take three MFMA passes each
+// (hi.hi + lo.hi + hi.lo); the K / V^T stage holds four tiles (two planes); lo planes lo_qk / lo_vt / lo_ctx elements on.
 template <int QW, bool F8 = false, int FMT = FMT_BF16>
-__global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, FMT == FMT_SPLIT ? 2 : (QW == 2 ? 3 : 4)) void attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                 const bf16_t* __restrict__ Vt, const int* __restrict__ valid,
                                                                 bf16_t* __restrict__ ctx, int T, int Tp, int Tpv,
-                                                                uint8_t* __restrict__ ctx_scale, long scale_rows) {
+                                                                uint8_t* __restrict__ ctx_scale, long scale_rows,
+                                                                long lo_qk, long lo_vt, long lo_ctx) {
+    constexpr bool SP = FMT == FMT_SPLIT;
+    constexpr int STG = (SP ? 4 : 2) * AT_TILE;      // bytes of one stage: K, V^T (and their lo planes)
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // 1-D launch, XCD-aware: workgroup i runs on XCD i % 8; xcd_remap hands every XCD a contiguous run of
@@ -113,12 +131,15 @@ __global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(co
     const bf16_t* Vb = Vt + bh * 64 * Tpv;
 
     // Q fragments (B operand): lane (q, h) holds d = 16 ks + 8 h .. +8
-    bf16x8_t qf[QW][4];
+    bf16x8_t qf[QW][4], qfl[SP ? QW : 1][4];
 #pragma unroll
     for (int qs = 0; qs < QW; ++qs) {
         int qr = q0 + 32 * qs + ql; qr = qr < Tp ? qr : Tp - 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[qs][ks] = *(const bf16x8_t*)(Qb + (size_t)qr * 64 + ks * 16 + h * 8);
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[qs][ks] = *(const bf16x8_t*)(Qb + (size_t)qr * 64 + ks * 16 + h * 8);
+            if constexpr (SP) qfl[qs][ks] = *(const bf16x8_t*)(Qb + lo_qk + (size_t)qr * 64 + ks * 16 + h * 8);
+        }
     }
     // staging: wave w fills rows [16w, 16w+16) of the K tile and of the V^T tile, 8 rows per instruction
     const int srow = lane >> 3, spos = lane & 7;
@@ -157,6 +178,10 @@ __global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(co
             int kr = krow[i]; kr = kr < Tp ? kr : Tp - 1;
             glds16a(gk[i] + (size_t)kr * 64, smem + lds_piece + i * 1024);
             glds16a(gv[i], smem + AT_TILE + lds_piece + i * 1024);
+            if constexpr (SP) {
+                glds16a(gk[i] + lo_qk + (size_t)kr * 64, smem + 2 * AT_TILE + lds_piece + i * 1024);
+                glds16a(gv[i] + lo_vt, smem + 3 * AT_TILE + lds_piece + i * 1024);
+            }
         }
     }
     // One 64-key tile, as two 32-key halves: S^T half -> softmax -> P.V half.  The softmax is the bottleneck of this
@@ -185,8 +210,16 @@ __global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(co
                 const bf16x8_t kf = *(const bf16x8_t*)(kb + s2 * 32 * 128 + frow + (((2 * ks + h) ^ swz) << 4));
 #pragma unroll
                 for (int qs = 0; qs < QW; ++qs) sacc[qs] = H16<FMT>::mfma(kf, qf[qs][ks], sacc[qs]);
+                if constexpr (SP) {
+                    const bf16x8_t kfl = *(const bf16x8_t*)(kb + 2 * AT_TILE + s2 * 32 * 128 + frow + (((2 * ks + h) ^ swz) << 4));
+#pragma unroll
+                    for (int qs = 0; qs < QW; ++qs) {
+                        sacc[qs] = H16<FMT>::mfma(kfl, qf[qs][ks], sacc[qs]);
+                        sacc[qs] = H16<FMT>::mfma(kf, qfl[qs][ks], sacc[qs]);
+                    }
+                }
             }
-            bf16x8_t pf[QW][2];
+            bf16x8_t pf[QW][2], pfl[SP ? QW : 1][2];
 #pragma unroll
             for (int qs = 0; qs < QW; ++qs) {
                 if (TAIL) {
@@ -220,7 +253,7 @@ __global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(co
                 // clamp every other conversion carries: 0 <= p <= 2^8 by construction of the lazy maximum
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    uint32_t pw[4];
+                    uint32_t pw[4], pwl[4];
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[qs][8 * j + e], LOG2E, -mb));
@@ -228,10 +261,15 @@ __global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(co
                         psum += p0;
                         psum += p1;
                         pw[e >> 1] = H16<FMT>::pack2_bounded(p0, p1);
+                        if constexpr (SP) pwl[e >> 1] = H16<FMT_SPLIT>::pack2_lo(p0, p1, pw[e >> 1]);
                     }
                     typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4)));
                     const u32x4v_t pv = {pw[0], pw[1], pw[2], pw[3]};
                     pf[qs][j] = __builtin_bit_cast(bf16x8_t, pv);
+                    if constexpr (SP) {
+                        const u32x4v_t pl = {pwl[0], pwl[1], pwl[2], pwl[3]};
+                        pfl[qs][j] = __builtin_bit_cast(bf16x8_t, pl);
+                    }
                 }
                 l_run[qs] += psum;
             }
@@ -243,6 +281,14 @@ __global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(co
                     const bf16x8_t vf = *(const bf16x8_t*)(vb + ds * 32 * 128 + frow + (((2 * (2 * s2 + j) + h) ^ swz) << 4));
 #pragma unroll
                     for (int qs = 0; qs < QW; ++qs) oacc[qs][ds] = H16<FMT>::mfma(vf, pf[qs][j], oacc[qs][ds]);
+                    if constexpr (SP) {
+                        const bf16x8_t vfl = *(const bf16x8_t*)(vb + 2 * AT_TILE + ds * 32 * 128 + frow + (((2 * (2 * s2 + j) + h) ^ swz) << 4));
+#pragma unroll
+                        for (int qs = 0; qs < QW; ++qs) {
+                            oacc[qs][ds] = H16<FMT>::mfma(vfl, pf[qs][j], oacc[qs][ds]);
+                            oacc[qs][ds] = H16<FMT>::mfma(vf, pfl[qs][j], oacc[qs][ds]);
+                        }
+                    }
                 }
         }
     };
@@ -252,50 +298,64 @@ __global__ __launch_bounds__(256, QW == 2 ? 3 : 4) void attention_bf16_kernel(co
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) {
-            char* nb = smem + ((t + 1) & 1) * 2 * AT_TILE;
+            char* nb = smem + ((t + 1) & 1) * STG;
             const int kv1 = (t + 1) * AT_KV;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int kr = kv1 + krow[i]; kr = kr < Tp ? kr : Tp - 1;
                 glds16a(gk[i] + (size_t)kr * 64, nb + lds_piece + i * 1024);
                 glds16a(gv[i] + kv1, nb + AT_TILE + lds_piece + i * 1024);
+                if constexpr (SP) {
+                    glds16a(gk[i] + lo_qk + (size_t)kr * 64, nb + 2 * AT_TILE + lds_piece + i * 1024);
+                    glds16a(gv[i] + lo_vt + kv1, nb + 3 * AT_TILE + lds_piece + i * 1024);
+                }
             }
         }
-        const char* kb = smem + (t & 1) * 2 * AT_TILE;
+        const char* kb = smem + (t & 1) * STG;
         const int kv0 = t * AT_KV;
         tile(kb, kb + AT_TILE, kv0, kv0 + AT_KV > nvalid);
     }
     // ---- finalize: 1/l, store ctx[b*Tp + q][head*64 + d]
 #pragma unroll
-    for (int qs = 0; qs < QW; ++qs) attn_finalize<F8, FMT>(oacc[qs], l_run[qs], ctx, ctx_scale, scale_rows, b, head, q0 + 32 * qs, ql, h, T, Tp);
+    for (int qs = 0; qs < QW; ++qs) attn_finalize<F8, FMT>(oacc[qs], l_run[qs], ctx, ctx_scale, scale_rows, b, head, q0 + 32 * qs, ql, h, T, Tp, lo_ctx);
 }
 
 static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, void* ctx, uint8_t* ctx_scale,
-                                long scale_rows, int B, int T, int Tp, int Tpv, int force_qw, int fmt, hipStream_t s) {
+                                long scale_rows, int B, int T, int Tp, int Tpv, int force_qw, int fmt, hipStream_t s,
+                                long lo_qk = 0, long lo_vt = 0, long lo_ctx = 0) {
     if (Tpv % 64 != 0 || Tpv < T) { syl_set_error("launch_attention", "Tpv must be a multiple of 64 and >= T"); return 1; }
     bf16_t* c = (bf16_t*)ctx;
     // 32 queries per wave (106 VGPRs, four waves per SIMD) is the faster shape inside the forward at every length
     // measured (10 s batch 0.409 vs 0.429 ms per forward, 8 x 60 s 2.71 vs 2.95); 64 per wave stays selectable
     int qw = 1;
     if (force_qw == 1 || force_qw == 2) qw = force_qw;
+    if (fmt == FMT_SPLIT) qw = 1;
     const dim3 grid((qw == 2 ? (T + 255) / 256 : (T + 127) / 128) * SYL_HEADS * B);
+    if (fmt == FMT_SPLIT) {
+        static PerDeviceOnce attr_once;
+        auto kern = attention_bf16_kernel<1, false, FMT_SPLIT>;
+        if (attr_once.need()) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_LDS));
+        hipLaunchKernelGGL(kern, grid, dim3(256), 2 * AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L, lo_qk, lo_vt, lo_ctx);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (ctx_scale) {
-        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, ctx_scale, scale_rows);
-        else hipLaunchKernelGGL((attention_bf16_kernel<1, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, ctx_scale, scale_rows);
+        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, ctx_scale, scale_rows, 0L, 0L, 0L);
+        else hipLaunchKernelGGL((attention_bf16_kernel<1, true>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, ctx_scale, scale_rows, 0L, 0L, 0L);
     } else if (fmt == FMT_F16) {
-        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, false, FMT_F16>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
-        else hipLaunchKernelGGL((attention_bf16_kernel<1, false, FMT_F16>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
+        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, false, FMT_F16>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L, 0L, 0L, 0L);
+        else hipLaunchKernelGGL((attention_bf16_kernel<1, false, FMT_F16>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L, 0L, 0L, 0L);
     } else {
-        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
-        else hipLaunchKernelGGL((attention_bf16_kernel<1, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
+        if (qw == 2) hipLaunchKernelGGL((attention_bf16_kernel<2, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L, 0L, 0L, 0L);
+        else hipLaunchKernelGGL((attention_bf16_kernel<1, false>), grid, dim3(256), AT_LDS, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L, 0L, 0L, 0L);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T, int Tp,
-                     int Tpv, int qw, hipStream_t s, int fmt) {
-    return launch_attention_any(q, k, vt, valid, ctx, nullptr, 0, B, T, Tp, Tpv, qw, fmt, s);
+                     int Tpv, int qw, hipStream_t s, int fmt, long lo_qk, long lo_vt, long lo_ctx) {
+    return launch_attention_any(q, k, vt, valid, ctx, nullptr, 0, B, T, Tp, Tpv, qw, fmt, s, lo_qk, lo_vt, lo_ctx);
 }
 
 // same attention, context written as MXFP8 ([B*Tp][768] e4m3 + K-pair-major E8M0 scales with row pitch scale_rows)

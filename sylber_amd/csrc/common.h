@@ -131,7 +131,32 @@ __host__ __forceinline__ float h2f_host(bf16_t h) {
 
 // ---- GELU --------------------------------------------------------------------------------------
 // exact erf form (reference: transformers activations "gelu" = 0.5 x (1 + erf(x / sqrt 2)))
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// written with an explicit fma: left to -ffp-contract the same expression compiled to different roundings in different
+// kernels (direct vs staged epilogue, 4- vs 8-wave), which made the split16 mode's results depend on the tile shape the
+// cost model picked, i.e. on the batch size (bf16 / fp16 outputs hide a last-bit difference, 22-bit planes do not)
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float hx = 0.5f * x;
+    return __builtin_fmaf(hx, erff(x * 0.70710678118654752f), hx);
+}
+// erf-form GELU for the split16 mode: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-grade: erff's own
+// error is 6e-8) in ~15 VALU + 2 transcendental instructions; ocml's erff costs several times that and made the GELU
+// epilogues of the split16 GEMMs as long as their (three-pass) K loops.  Explicit fma everywhere: bit-identical in every
+// kernel it is inlined into.
+__device__ __forceinline__ float gelu_erf7(float x) {
+    const float z = x * 0.70710678118654752f;
+    const float az = __builtin_fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, az, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    p = p * t;
+    const float e = __builtin_amdgcn_exp2f(az * az * -1.44269504088896341f);
+    const float erf_abs = __builtin_fmaf(-p, e, 1.0f);
+    const float erf = __builtin_copysignf(erf_abs, z);
+    const float hx = 0.5f * x;
+    return __builtin_fmaf(hx, erf, hx);
+}
 // 16-bit-path GELU without transcendentals.  gelu(x) = x Phi(x), Phi(x) - 1/2 = erf(x / sqrt 2) / 2 is ODD:
 // Phi(x) = 1/2 + x Q(x^2) with a degree-8 polynomial Q on |x| <= 4.2 (Chebyshev fit of x^2 Q(x^2) to the even part of
 // gelu: max |error| of gelu 6.4e-5 over the whole real line, gelu(0) = 0 exactly); beyond, x is clamped inside Phi only:

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512) void conv0_finalize_kernel(const double* __res
 template <bool OUT_F32, bool ERF, int FMT>
 __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int Lmax, int L0, int R0,
                                                             const float* __restrict__ w0,
-                                                            const float* __restrict__ scale_shift, void* __restrict__ out) {
+                                                            const float* __restrict__ scale_shift, void* __restrict__ out, long out_lo) {
     __shared__ float xs[C0_ROWS * 5 + 16];
     const int b = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
         for (int j = 0; j < 10; ++j) w[i][j] = w0[(c0 + i) * 10 + j];
         sa[i] = scale_shift[((size_t)b * SYL_CONV + c0 + i) * 2 + 0];
         sb[i] = scale_shift[((size_t)b * SYL_CONV + c0 + i) * 2 + 1];
-        if constexpr (!OUT_F32) {
+        if constexpr (!OUT_F32 && FMT != FMT_SPLIT) {
             // 16-bit modes: the GroupNorm scale goes into the tap weights once per (utterance, channel) -- the affine
             // then costs nothing per value (the accumulation starts from the shift); the fp32 parity instantiation keeps the
             // reference's order (conv, then scale and shift)
@@ -136,11 +136,12 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             for (int j = 0; j < 10; ++j) xv[j] = xr[j];          // LDS broadcast
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float v = OUT_F32 ? 0.f : sb[i];
+                constexpr bool REF_ORDER = OUT_F32 || FMT == FMT_SPLIT;   // conv, then scale and shift (as the fp32 parity mode)
+                float v = REF_ORDER ? 0.f : sb[i];
 #pragma unroll
                 for (int j = 0; j < 10; ++j) v = fmaf(w[i][j], xv[j], v);
-                if constexpr (OUT_F32) v = fmaf(v, sa[i], sb[i]);
-                y[i] = ERF ? gelu_erf(v) : gelu_fast(v);
+                if constexpr (REF_ORDER) v = fmaf(v, sa[i], sb[i]);
+                y[i] = ERF ? (FMT == FMT_SPLIT ? gelu_erf7(v) : gelu_erf(v)) : gelu_fast(v);
             }
         } else {
 #pragma unroll
@@ -158,6 +159,12 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             pk[0] = H16<FMT>::pack2(y[0], y[1]); pk[1] = H16<FMT>::pack2(y[2], y[3]);
             pk[2] = H16<FMT>::pack2(y[4], y[5]); pk[3] = H16<FMT>::pack2(y[6], y[7]);
             __builtin_nontemporal_store(pk, (u32x4_t*)((bf16_t*)out + o));
+            if constexpr (FMT == FMT_SPLIT) {
+                u32x4_t lo;
+                lo[0] = H16<FMT>::pack2_lo(y[0], y[1], pk[0]); lo[1] = H16<FMT>::pack2_lo(y[2], y[3], pk[1]);
+                lo[2] = H16<FMT>::pack2_lo(y[4], y[5], pk[2]); lo[3] = H16<FMT>::pack2_lo(y[6], y[7], pk[3]);
+                __builtin_nontemporal_store(lo, (u32x4_t*)((bf16_t*)out + out_lo + o));
+            }
         }
     }
 }
@@ -175,14 +182,16 @@ int launch_conv0_finalize(const double* partials, int nchunk, const float* w0, c
     return 0;
 }
 int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, const float* w0, const float* scale_shift,
-                         void* out, int out_f32, hipStream_t s, int fmt) {
+                         void* out, int out_f32, hipStream_t s, int fmt, long out_lo) {
     dim3 grid((R0 + C0_ROWS - 1) / C0_ROWS, B);
     if (out_f32)
-        hipLaunchKernelGGL((conv0_gn_gelu_kernel<true, true, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<true, true, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
+    else if (fmt == FMT_SPLIT)      // erf GELU in the reference's order (conv, then scale and shift), two half planes out
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, true, FMT_SPLIT>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, out_lo);
     else if (fmt == FMT_F16)
-        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_F16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_F16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
     else
-        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out);
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -219,6 +228,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
             const uint2 raw = *(const uint2*)((const bf16_t*)a.in + (size_t)m * a.ld_in + c);
             x[i][0] = H16<FMT_IN>::up((bf16_t)(raw.x & 0xffff)); x[i][1] = H16<FMT_IN>::up((bf16_t)(raw.x >> 16));
             x[i][2] = H16<FMT_IN>::up((bf16_t)(raw.y & 0xffff)); x[i][3] = H16<FMT_IN>::up((bf16_t)(raw.y >> 16));
+            if constexpr (FMT_IN == FMT_SPLIT) {
+                const uint2 lo = *(const uint2*)((const bf16_t*)a.in + a.in_lo + (size_t)m * a.ld_in + c);
+                x[i][0] += H16<FMT_IN>::up((bf16_t)(lo.x & 0xffff)); x[i][1] += H16<FMT_IN>::up((bf16_t)(lo.x >> 16));
+                x[i][2] += H16<FMT_IN>::up((bf16_t)(lo.y & 0xffff)); x[i][3] += H16<FMT_IN>::up((bf16_t)(lo.y >> 16));
+            }
         } else {
             const float4 v = *(const float4*)((const float*)a.in + (size_t)m * a.ld_in + c);
             x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
@@ -253,6 +267,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
         if (a.out_bf16) {
             uint2 pk; pk.x = H16<FMT>::pack2(y0, y1); pk.y = H16<FMT>::pack2(y2, y3);
             *(uint2*)(a.out_bf16 + (size_t)m * a.ld_bf16 + c) = pk;
+            if constexpr (FMT == FMT_SPLIT) {
+                uint2 lo; lo.x = H16<FMT>::pack2_lo(y0, y1, pk.x); lo.y = H16<FMT>::pack2_lo(y2, y3, pk.y);
+                *(uint2*)(a.out_bf16 + a.out_lo + (size_t)m * a.ld_bf16 + c) = lo;
+            }
         }
         if (a.out_fp8) {
             // a 32-feature scale block = the 4 values of 8 consecutive lanes
@@ -288,6 +306,13 @@ int launch_layernorm(const LnArgs& a, hipStream_t s) {
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    if (a.fmt == FMT_SPLIT) {
+        if (a.D == 768 && !a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<768, false, FMT_SPLIT>), grid, dim3(256), 0, s, a);
+        else if (a.D == 512 && a.in_bf16) hipLaunchKernelGGL((layernorm_kernel<512, true, FMT_SPLIT>), grid, dim3(256), 0, s, a);
+        else { syl_set_error("launch_layernorm", "split16: only LN(768) of fp32 rows and LN(512) of split rows"); return 1; }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (a.fmt == FMT_F16 ? launch_ln_fmt<FMT_F16>(a, grid, s) : launch_ln_fmt<FMT_BF16>(a, grid, s)) {}
     else { syl_set_error("launch_layernorm", "D must be 512 or 768"); return 1; }
     HIP_TRY(hipGetLastError());
@@ -311,16 +336,36 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
     return 0;
 }
 
+// f32 -> split16 planes: hi = half(x) at out, lo = half(x - hi) at out + lo_off (element offset)
+__global__ __launch_bounds__(256) void f32_to_split16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long lo_off, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = *(const float4*)(in + i * 4);
+        uint2 hi; hi.x = H16<FMT_SPLIT>::pack2(v.x, v.y); hi.y = H16<FMT_SPLIT>::pack2(v.z, v.w);
+        uint2 lo; lo.x = H16<FMT_SPLIT>::pack2_lo(v.x, v.y, hi.x); lo.y = H16<FMT_SPLIT>::pack2_lo(v.z, v.w, hi.y);
+        *(uint2*)(out + i * 4) = hi;
+        *(uint2*)(out + lo_off + i * 4) = lo;
+    }
+}
+int launch_f32_to_split16(const float* in, bf16_t* out, long lo_off, size_t n, hipStream_t s) {
+    if (n % 4 || lo_off % 4) { syl_set_error("launch_f32_to_split16", "n and the plane offset must be multiples of 4"); return 1; }
+    const size_t n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(f32_to_split16_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, in, out, lo_off, n4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // compacting copy bf16 [B][Tp][D] (row stride ld_in) -> f32 [B][T][D]
 __global__ __launch_bounds__(256) void bf16_rows_to_f32_kernel(const bf16_t* __restrict__ in, long ld_in, float* __restrict__ out,
-                                                               int Tp, int T, int D, int fmt) {
+                                                               int Tp, int T, int D, int fmt, long in_lo) {
     const int b = blockIdx.y, t = blockIdx.x;
     const bf16_t* src = in + ((size_t)b * Tp + t) * ld_in;
     float* dst = out + ((size_t)b * T + t) * D;
-    for (int c = threadIdx.x; c < D; c += 256) dst[c] = fmt == FMT_F16 ? H16<FMT_F16>::up(src[c]) : bf2f(src[c]);
+    for (int c = threadIdx.x; c < D; c += 256)
+        dst[c] = fmt == FMT_SPLIT ? H16<FMT_F16>::up(src[c]) + H16<FMT_F16>::up(src[in_lo + c]) : (fmt == FMT_F16 ? H16<FMT_F16>::up(src[c]) : bf2f(src[c]));
 }
-int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s, int fmt) {
-    hipLaunchKernelGGL(bf16_rows_to_f32_kernel, dim3(T, B), dim3(256), 0, s, in, ld_in, out, Tp, T, D, fmt);
+int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s, int fmt, long in_lo) {
+    hipLaunchKernelGGL(bf16_rows_to_f32_kernel, dim3(T, B), dim3(256), 0, s, in, ld_in, out, Tp, T, D, fmt, in_lo);
     HIP_TRY(hipGetLastError());
     return 0;
 }

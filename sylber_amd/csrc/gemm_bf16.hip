@@ -33,6 +33,9 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// shader-clock timestamp (development, trace instantiation only): s_memtime shares lgkmcnt with the LDS reads, so a stamp
+// sits only where the kernel waits lgkmcnt(0) anyway or has no LDS read in flight
+#define TSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 
 template <int FM, int FN, int BK, int NSTAGE, bool PRIO, int EPI, int ACT, int FMT>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile_id, char* smem) {
@@ -273,6 +276,8 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     constexpr int NP = (BM + BN) / 16;               // 1-KiB pieces (16 rows x 64 B) per step
     constexpr int NPW_HI = (NP + 7) / 8, NPW_LO = NP / 8;
     static_assert(WM * WN == 8, "8 waves");
+    unsigned long long tk_start = 0;
+    if constexpr (VAR == 10) TSTAMP(tk_start);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int group = wave >> 2;                     // waves w and w+4 share a SIMD
@@ -347,9 +352,13 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     __builtin_amdgcn_s_barrier();
     if (group == 1) __builtin_amdgcn_s_barrier();    // stagger: group 1 runs one barrier behind
     int slot = 0;
+    constexpr bool TRACE = VAR == 10;
+    unsigned long long tk0 = tk_start, tl0 = 0, tl1 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, sA = 0, sW1 = 0, sB = 0, sW2 = 0, cal = 0;
+    if constexpr (TRACE) { TSTAMP(tl0); TSTAMP(ta); TSTAMP(tb); cal = tb - ta; }
     for (int s = 0; s < nt; ++s) {
         const char* sb = smem + slot * STAGE;
         bf16x8_t xf[2][FM], wf[2][FN];
+        if constexpr (TRACE) TSTAMP(ta);
         // ---- A: fragments of step s, DMA of step s+3, retire step s+1
         const bool dma = s + 3 < nt;
         char* dbase = smem + ((slot + 3) & 3) * STAGE;     // slot of step s-1: every wave left A(s-1) >= two program barriers ago
@@ -378,7 +387,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
             // as a whole step: NPW_HI / 2 pieces fewer outstanding than the bound allows -> conservative)
             const int after2 = (s + 2 < nt ? 1 : 0);
             const int after3 = (s + 3 < nt ? 1 : 0);
-            if constexpr (VAR == 0) wait_steps(after2);
+            if constexpr (VAR == 0 || VAR == 10) wait_steps(after2);
             else if constexpr (VAR == 3) {
                 if (after3) { if (hi) wait_vmcnt<NPW_HI + NPW_HI / 2>(); else wait_vmcnt<NPW_LO + NPW_HI / 2>(); }
                 else wait_steps(after2);
@@ -387,8 +396,10 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SCHED_FENCE();
+        if constexpr (TRACE) { TSTAMP(tb); SCHED_FENCE(); }
         __builtin_amdgcn_s_barrier();
         SCHED_FENCE();
+        if constexpr (TRACE) { TSTAMP(tc); SCHED_FENCE(); }
         // ---- B: MFMAs of step s
         // VAR 0: the LDS-DMA of step s+3 is spread between the MFMAs (one 1-KiB piece per quarter of the MFMAs): a DMA
         // instruction costs ~70-100 issue cycles because the CU's texture path moves 64 B/clk, and issued in a burst in
@@ -400,10 +411,10 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
             const int kk = i / (FM * FN), fm = (i / FN) % FM, fn = i % FN;
             acc[fm][fn] = H16<FMT>::mfma(wf[kk][fn], xf[kk][fm], acc[fm][fn]);
             // after MFMA number (q+1)*NMF/NPW_HI - 1 issue piece q
-            if constexpr (VAR == 0 || VAR == 3) {
+            if constexpr (VAR == 0 || VAR == 3 || VAR == 10) {
                 if ((i + 1) % (NMF / NPW_HI) == 0) {
                     const int q = (i + 1) / (NMF / NPW_HI) - 1;
-                    if (VAR == 0 || q >= NPW_HI / 2) {
+                    if (VAR != 3 || q >= NPW_HI / 2) {
                         SCHED_FENCE();
                         if (dma && q < NPW_HI && (q < NPW_LO || hi)) glds16(ksrc(s + 3, q), dbase + lds_off[q]);
                         SCHED_FENCE();
@@ -413,10 +424,20 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         }
         __builtin_amdgcn_s_setprio(0);
         SCHED_FENCE();
+        if constexpr (TRACE) { TSTAMP(td); SCHED_FENCE(); }
         __builtin_amdgcn_s_barrier();
+        if constexpr (TRACE) { SCHED_FENCE(); TSTAMP(te); sA += tb - ta; sW1 += tc - tb; sB += td - tc; sW2 += te - td; }
         slot = (slot + 1) & 3;
     }
+    if constexpr (TRACE) TSTAMP(tl1);
     if (group == 0) __builtin_amdgcn_s_barrier();    // pairs with group 1's extra barrier
+    auto trace_out = [&](unsigned long long t_end) {
+        if (a.trace && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0) {
+            unsigned long long* o = a.trace + group * 10;
+            o[0] = sA; o[1] = sW1; o[2] = sB; o[3] = sW2; o[4] = tl1 - tl0; o[5] = (unsigned long long)nt; o[6] = cal;
+            o[7] = t_end - tl1; o[8] = tl0 - tk0; o[9] = t_end - tk0;
+        }
+    };
 
     if constexpr (EPI == EPI_QK || EPI == EPI_PROJ || EPI == EPI_BF16) {
         // measured A/B (MI355X, instrumented): in this one-workgroup-per-CU kernel the LDS-staged, line-coalesced
@@ -427,6 +448,11 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         epilogue_staged<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
     } else {
         epilogue_direct<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
+    }
+    if constexpr (TRACE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the epilogue's stores have left
+        unsigned long long t_end; TSTAMP(t_end);
+        trace_out(t_end);
     }
 }
 
@@ -687,6 +713,7 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
         case 20: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 1>(a, s); break;   // K-loop schedule A/B
         case 21: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 2>(a, s); break;
         case 22: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 3>(a, s); break;
+        case 30: if constexpr (FMT == FMT_BF16 && (EPI == EPI_BF16 || EPI == EPI_F32_RESLN)) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 10>(a, s); break;   // trace
         default: break;
     }
     return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);              // 128x192, 2 WG/CU
@@ -698,13 +725,16 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
     if (a.fmt == FMT_SPLIT) {
         // what the split16 forward launches: erf-GELU 16-bit outputs (convs, FFN1), the projection, q/k/v, the residual
         // GEMMs, and the plain fp32 output of the op-level test entry point
-        if constexpr ((EPI == EPI_BF16 && ACT == ACT_GELU_ERF) || (EPI == EPI_F32 && ACT == ACT_NONE) || EPI == EPI_F32_RESLN ||
+        if constexpr ((EPI == EPI_BF16 && ACT == ACT_GELU_ERF7) || (EPI == EPI_F32 && ACT == ACT_NONE) || EPI == EPI_F32_RESLN ||
                       EPI == EPI_QK || EPI == EPI_PROJ)
             return launch_f<EPI, ACT, FMT_SPLIT>(a, s);
         else { syl_set_error("launch_gemm_bf16", "this epilogue has no split16 instantiation"); return 1; }
     }
-    if (a.fmt == FMT_F16) return launch_f<EPI, ACT, FMT_F16>(a, s);
-    return launch_f<EPI, ACT, FMT_BF16>(a, s);
+    if constexpr (ACT == ACT_GELU_ERF7) { syl_set_error("launch_gemm_bf16", "activation 3 exists for the split16 format only"); return 1; }
+    else {
+        if (a.fmt == FMT_F16) return launch_f<EPI, ACT, FMT_F16>(a, s);
+        return launch_f<EPI, ACT, FMT_BF16>(a, s);
+    }
 }
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s) {
@@ -714,6 +744,7 @@ int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s) {
         case EPI_BF16:
             if (a.act == 1) return launch_t<EPI_BF16, 1>(a, s);
             if (a.act == 2) return launch_t<EPI_BF16, 2>(a, s);
+            if (a.act == 3) return launch_t<EPI_BF16, 3>(a, s);
             return launch_t<EPI_BF16, 0>(a, s);
         case EPI_F32:
             if (a.act == 1) return launch_t<EPI_F32, 1>(a, s);

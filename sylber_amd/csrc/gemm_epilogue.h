@@ -13,6 +13,7 @@ template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {
     if constexpr (ACT == ACT_GELU_FAST) return gelu_fast(v);
     if constexpr (ACT == ACT_GELU_ERF) return gelu_erf(v);
+    if constexpr (ACT == ACT_GELU_ERF7) return gelu_erf7(v);
     return v;
 }
 // four values of one run: the fast GELU goes through the packed-fp32 pipe two at a time
@@ -173,7 +174,7 @@ __device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x
         const int n = ncol0 + f;
         if (n >= a.N) continue;
         const uint4 raw = *(const uint4*)(lds + f * 64 + c * 16);
-        bf16_t* dst = (bf16_t*)a.out2 + (PLANE == 1 ? a.out_lo : 0L) + ((size_t)b * SYL_HIDDEN + (n - 2 * SYL_HIDDEN)) * a.Tpv + t0 + 8 * c;
+        bf16_t* dst = (bf16_t*)a.out2 + (PLANE == 1 ? a.out2_lo : 0L) + ((size_t)b * SYL_HIDDEN + (n - 2 * SYL_HIDDEN)) * a.Tpv + t0 + 8 * c;
         *(uint4*)dst = raw;
         // the key tail [Tp, Tpv) (0 or 32 keys: Tp % 32 == 0, Tpv % 64 == 0) is read by the attention kernel's last
         // tile with P = 0; it must stay finite although the region is shared with the FFN intermediate

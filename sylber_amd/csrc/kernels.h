@@ -7,7 +7,7 @@
 // X rows may overlap (ldx < K): the strided 1-D convolutions are run as this GEMM on a channels-last
 // activation buffer with ldx = stride*512, K = taps*512 (implicit GEMM, no im2col).
 // ------------------------------------------------------------------------------------------------
-enum GemmAct { ACT_NONE = 0, ACT_GELU_FAST = 1, ACT_GELU_ERF = 2 };   // GemmArgs::act (bf16 / MXFP8 GEMMs)
+enum GemmAct { ACT_NONE = 0, ACT_GELU_FAST = 1, ACT_GELU_ERF = 2, ACT_GELU_ERF7 = 3 };   // GemmArgs::act (bf16 / MXFP8 GEMMs); 3 = erf form, 1.5e-7 (split16)
 enum GemmEpi {
     EPI_BF16 = 0,       // out0 bf16 [M][ld0] = act(acc + bias)
     EPI_F32 = 1,        // out0 f32  [M][ld0] = act(acc + bias)
@@ -37,7 +37,9 @@ struct GemmArgs {
     const float* ln_gamma; const float* ln_beta;
     int fmt;                      // FMT_BF16 (0), FMT_F16 or FMT_SPLIT: 16-bit format of X, W and of bf16-typed outputs
     long x_lo, w_lo;              // FMT_SPLIT: element offsets of the lo planes of X and W (hi plane at the pointer)
-    long out_lo;                  // FMT_SPLIT: element offset of the lo plane of every 16-bit output (out0 / out1 / out2)
+    long out_lo;                  // FMT_SPLIT: element offset of the lo plane of the 16-bit outputs out0 / out1
+    long out2_lo;                 //            ... of out2 (V^T)
+    unsigned long long* trace;    // development: per-phase cycle sums of two waves of workgroup 0 (trace instantiation only)
     int tune_cfg;                 // 0 = tile shape chosen by the cost model; k > 0 forces tile configuration k - 1
     int tune_persist;             // > 0: persistent launch (that many workgroups per CU walk the tile list)
 };
@@ -80,8 +82,9 @@ int launch_conv0_stats(const float* wav, int B, int Lmax, int L0, double* partia
 int launch_conv0_finalize(const double* partials, int nchunk, const float* w0, const float* gn_w, const float* gn_b,
                           int B, int L0, float* scale_shift, hipStream_t s);
 // out: [B][R0][512] (bf16 or f32); rows l >= L0 are written as zeros
+// fmt FMT_SPLIT: erf GELU, hi halves at out, lo halves at out + out_lo (element offset)
 int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, const float* w0,
-                         const float* scale_shift, void* out, int out_f32, hipStream_t s, int fmt = 0);
+                         const float* scale_shift, void* out, int out_f32, hipStream_t s, int fmt = 0, long out_lo = 0);
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (512 or 768), eps 1e-5, one wave per row
@@ -101,6 +104,7 @@ struct LnArgs {
     float* out_stats;             // optional [M][2] (mean, rstd): lets a later GEMM epilogue re-apply this LayerNorm
     int M, D;
     int Tp, T;        // compaction of the f32 output (final hidden states); 0 = none
+    long in_lo, out_lo;   // FMT_SPLIT: element offsets of the lo planes of a 16-bit input / of out_bf16
 };
 int launch_layernorm(const LnArgs& a, hipStream_t s);
 
@@ -109,8 +113,9 @@ int launch_layernorm(const LnArgs& a, hipStream_t s);
 //   q,k: [B,H,Tp,64] bf16; vt: [B,H,64,Tpv] bf16; ctx out: [B*Tp][768] bf16
 // ------------------------------------------------------------------------------------------------
 // qw: 0 = automatic, 1 / 2 = 32 / 64 queries per wave
+// fmt FMT_SPLIT: q / k / vt / ctx are hi planes, their lo planes lo_qk (q, k), lo_vt and lo_ctx elements further on
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T,
-                     int Tp, int Tpv, int qw, hipStream_t s, int fmt = 0);
+                     int Tp, int Tpv, int qw, hipStream_t s, int fmt = 0, long lo_qk = 0, long lo_vt = 0, long lo_ctx = 0);
 int launch_attention_f8out(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, uint8_t* ctx8, uint8_t* ctx_scale,
                            long scale_rows, int B, int T, int Tp, int Tpv, int qw, hipStream_t s);   // context as MXFP8 (SYLBER_FP8)
 int launch_attention_f32(const float* q, const float* k, const float* v, const int* valid, float* ctx, int B, int T,
@@ -122,8 +127,9 @@ int launch_attention_f32(const float* q, const float* k, const float* v, const i
 //   wpk : packed weights [16 groups][128 taps][64 n (48 used)][48 c] bf16
 //   out : f32 [B*Tp][768] = x_f32 + gelu(conv + bias)
 // ------------------------------------------------------------------------------------------------
+// fmt FMT_SPLIT: xpad / wpk are hi planes with lo planes x_lo / w_lo elements further on (three passes), erf GELU
 int launch_posconv(const bf16_t* xpad, const bf16_t* wpk, const float* bias, const float* x_f32, float* out, int B,
-                   int Tp, int act, hipStream_t s, int fmt = 0);
+                   int Tp, int act, hipStream_t s, int fmt = 0, long x_lo = 0, long w_lo = 0);
 int launch_posconv_f32(const float* xpad, const float* w, const float* bias, const float* x_f32, float* out, int B,
                        int Tp, hipStream_t s);
 
@@ -136,4 +142,5 @@ size_t segment_scratch_floats(int B, int T, int D);
 
 // misc elementwise
 int launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
-int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s, int fmt = 0);
+int launch_f32_to_split16(const float* in, bf16_t* out, long lo_off, size_t n, hipStream_t s);   // hi plane at out, lo plane at out + lo_off
+int launch_bf16_to_f32_rows(const bf16_t* in, long ld_in, float* out, int B, int Tp, int T, int D, hipStream_t s, int fmt = 0, long in_lo = 0);

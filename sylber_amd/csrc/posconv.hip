@@ -32,7 +32,7 @@ __device__ __forceinline__ void glds16p(const void* g, void* l) {
 template <int ACT, int FMT>
 __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __restrict__ xpad, const bf16_t* __restrict__ wpk,
                                                               const float* __restrict__ bias, const float* __restrict__ x_f32,
-                                                              float* __restrict__ out, int Tp) {
+                                                              float* __restrict__ out, int Tp, long x_lo, long w_lo) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     char* xwin = smem;
     char* wring = smem + PC_XWIN;
@@ -41,9 +41,19 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
     const int t0 = blockIdx.x * PC_BM, g = blockIdx.y, b = blockIdx.z;
     const int rows_per_b = Tp + 128;
 
+    f32x16_t acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // FMT_SPLIT: three passes into the same accumulators -- x.hi w.hi, x.lo w.hi, x.hi w.lo (hi / lo half planes)
+    constexpr int NPASS = FMT == FMT_SPLIT ? 3 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass) {
+    if (pass > 0) __syncthreads();                     // the previous pass's window and ring reads are done
     // ---- stage the x window: rows t0 .. t0+254 of xpad[b], channels g*48 .. +47
     {
-        const bf16_t* xb = xpad + (size_t)b * rows_per_b * SYL_HIDDEN + g * SYL_POSC;
+        const bf16_t* xb = xpad + (pass == 1 ? x_lo : 0L) + (size_t)b * rows_per_b * SYL_HIDDEN + g * SYL_POSC;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int idx = tid + 256 * i;         // 1536 16-B chunks
@@ -54,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
         }
     }
     // ---- weight ring: a step = 2 taps = 14 KiB = 14 wave-instructions; wave w issues pieces w, w+4, ...
-    const char* wg_base = (const char*)wpk + (size_t)g * SYL_POSK * PC_SLAB;
+    const char* wg_base = (const char*)(wpk + (pass == 2 ? w_lo : 0L)) + (size_t)g * SYL_POSK * PC_SLAB;
     auto stage = [&](int step, int buf) {
         const char* src = wg_base + (size_t)step * PC_STEP;
         char* dst = wring + buf * PC_STEP;
@@ -64,12 +74,6 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
             if (piece < 14) glds16p(src + piece * 1024 + lane * 16, dst + piece * 1024);
         }
     };
-
-    f32x16_t acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const int xfrag = (wave * 32 + ql) * PC_XROW + h * 16;
     const int wfrag = ql * 112 + h * 16;
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
             }
         }
     }
+    }   // pass
     // ---- epilogue: out = x + gelu(conv + bias); lane owns frame t, runs of 4 output channels
     const int t = t0 + wave * 32 + ql;
     if (t < Tp) {
@@ -110,7 +115,8 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
                 const float4 rr = *(const float4*)(x_f32 + m * SYL_HIDDEN + n);
                 float v0 = acc[nf][4 * gg + 0] + bb.x, v1 = acc[nf][4 * gg + 1] + bb.y;
                 float v2 = acc[nf][4 * gg + 2] + bb.z, v3 = acc[nf][4 * gg + 3] + bb.w;
-                if constexpr (ACT == 2) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                if constexpr (ACT == 2 && FMT == FMT_SPLIT) { v0 = gelu_erf7(v0); v1 = gelu_erf7(v1); v2 = gelu_erf7(v2); v3 = gelu_erf7(v3); }
+                else if constexpr (ACT == 2) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
                 else { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
                 *(float4*)(out + m * SYL_HIDDEN + n) = make_float4(rr.x + v0, rr.y + v1, rr.z + v2, rr.w + v3);
             }
@@ -118,18 +124,24 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
 }
 
 int launch_posconv(const bf16_t* xpad, const bf16_t* wpk, const float* bias, const float* x_f32, float* out, int B, int Tp,
-                   int act, hipStream_t s, int fmt) {
+                   int act, hipStream_t s, int fmt, long x_lo, long w_lo) {
     dim3 grid((Tp + PC_BM - 1) / PC_BM, SYL_POSG, B);
     static PerDeviceOnce attr_once;
     if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<1, FMT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<2, FMT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<1, FMT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<2, FMT_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
+    }
+    if (fmt == FMT_SPLIT) {
+        hipLaunchKernelGGL((posconv_bf16_kernel<2, FMT_SPLIT>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, x_lo, w_lo);
+        HIP_TRY(hipGetLastError());
+        return 0;
     }
     if (fmt == FMT_F16 && act == 2) { syl_set_error("launch_posconv", "the erf GELU (act 2) has no fp16 instantiation"); return 1; }
-    if (fmt == FMT_F16) hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_F16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
-    else if (act == 2) hipLaunchKernelGGL((posconv_bf16_kernel<2, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
-    else hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp);
+    if (fmt == FMT_F16) hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_F16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, 0L, 0L);
+    else if (act == 2) hipLaunchKernelGGL((posconv_bf16_kernel<2, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, 0L, 0L);
+    else hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, 0L, 0L);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -155,7 +155,7 @@ class HubertEncoderHIP:
             L.ff2_w, L.ff2_b = get(p + "feed_forward.output_dense.weight"), get(p + "feed_forward.output_dense.bias")
             L.ln2_w, L.ln2_b = get(p + "final_layer_norm.weight"), get(p + "final_layer_norm.bias")
         h = ctypes.c_void_p()
-        prec = {"bf16": 0, "fp32": 1, "fp8": 2, "fp16": 3, "mixed16": 4}[precision]
+        prec = {"bf16": 0, "fp32": 1, "fp8": 2, "fp16": 3, "mixed16": 4, "split16": 5}[precision]
         _lib.check(self.lib.sylber_create(ctypes.byref(w), self.device.index or 0, prec, ctypes.byref(h)),
                    "sylber_create")                 # (the library restores the caller's current device itself)
         self.handle = h

@@ -103,6 +103,27 @@ def test_linear_every_tile_config(lib, cfg):
         assert (c.cpu() - ref).abs().max().item() < 2e-3, (cfg, M, N, K)
 
 
+@pytest.mark.parametrize("cfg", [-1, 3, 4, 10])
+def test_linear_split16(lib, cfg):
+    """precision split16 (operands as hi / lo IEEE-half planes, three MFMA passes into one fp32 accumulator) is an
+    fp32-grade contraction: against float64 it is within fp32 accumulation noise, three orders below the bf16 / fp16
+    operand rounding, for every tile shape the mode instantiates (ragged tails, small and large K)"""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K) in [(700, 768, 768), (1000, 512, 1536), (333, 3072, 768), (257, 768, 3072), (16384, 768, 768)]:
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+        c = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 0, 5, cfg, None), "op_linear")
+        ref = a.double() @ w.double().T + b.double()
+        err = (c.cpu().double() - ref).abs().max().item()
+        assert err < 2e-5, (cfg, M, N, K, err)          # |ref| ~ 1; fp16 operands would give ~2e-3, bf16 ~2e-2
+        f32 = (a @ w.T + b).double()
+        assert err < 12 * (f32 - ref).abs().max().item() + 2e-6, (cfg, M, N, K)     # fp32 accumulation noise (a longer serial chain than the CPU's blocked sums)
+
+
 @pytest.mark.parametrize("cfg", [20, 21, 22])
 def test_gemm8_schedule_variants_bitwise(lib, cfg):
     """the K-loop schedule variants of the 8-wave kernel (where the LDS-DMA of step s+3 is issued) contract in the same
