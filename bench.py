@@ -459,6 +459,24 @@ def main():
     roofline = None
     kernels = {}
     frontend = None
+    if rank == 0 and args.precision == "fp32":
+        # the exact mode: every contraction on v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s dense, MI355X_MICROARCH.md)
+        enc.set_profiling(True)
+        nprof = 3
+        for _ in range(nprof):
+            h = enc.forward(my_batch, None)
+            enc.segment(h, 2.6, 0.8)
+        torch.cuda.synchronize(dev)
+        prof = enc.get_profile()
+        enc.set_profiling(False)
+        kernels = {k: round(v / nprof, 4) for k, v in prof.items()}
+        gemm_fl = sum(gemm_flops_per_forward(B, clip_samples).values())
+        if kernels.get("gemm_f32"):
+            tf = gemm_fl / (kernels["gemm_f32"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "gemm_f32_tiled_kernel (all 43 GEMM launches of the fp32 parity forward, v_mfma_f32_32x32x2_f32)",
+                        "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": None,
+                        "traffic_note": "no PMC pass for the parity mode", "flops_per_forward": gemm_fl,
+                        "ms_per_forward": kernels["gemm_f32"]}
     if rank == 0 and args.precision != "fp32":
         enc.set_profiling(True)
         nprof = max(3, min(args.steps, 10))

@@ -155,13 +155,13 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
                         tmp[(((size_t)g * 128 + t) * 64 + n) * 56 + cc] = w->pos_w[(((size_t)g * 48 + n) * 48 + cc) * 128 + t];
         if (!f32) o_posw = P.add_bf16(tmp.data(), tmp.size());
         else {
-            // fp32 parity kernel wants [g][tap][c][n] (n contiguous)
-            std::vector<float> t32((size_t)16 * 128 * 48 * 48);
+            // fp32 parity kernel: [g][tap][64 n][52 c] fp32, zero padded (208-byte rows, see fp32_path.hip)
+            std::vector<float> t32((size_t)16 * 128 * 64 * 52, 0.f);
             for (int g = 0; g < 16; ++g)
                 for (int n = 0; n < 48; ++n)
                     for (int cc = 0; cc < 48; ++cc)
                         for (int t = 0; t < 128; ++t)
-                            t32[(((size_t)g * 128 + t) * 48 + cc) * 48 + n] = w->pos_w[(((size_t)g * 48 + n) * 48 + cc) * 128 + t];
+                            t32[(((size_t)g * 128 + t) * 64 + n) * 52 + cc] = w->pos_w[(((size_t)g * 48 + n) * 48 + cc) * 128 + t];
             o_posw = P.add_f32(t32.data(), t32.size());
         }
     }
@@ -673,7 +673,7 @@ static int forward_f32(sylber_ctx* c, const float* wav_dev, const int32_t* lengt
     for (int i = 1; i < 7; ++i) {
         GemmArgsF32 a = {};
         a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w32[i]; a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.act = 1;
-        a.out0 = dst; a.ld0 = 512;
+        a.out0 = dst; a.ld0 = 512; a.tiled = 1;
         RUN("gemm_f32", launch_gemm_f32(a, s));
         float* t = src; src = dst; dst = t;
     }
@@ -691,7 +691,7 @@ static int forward_f32(sylber_ctx* c, const float* wav_dev, const int32_t* lengt
         RUN("ln512", launch_layernorm(a, s));
         GemmArgsF32 g = {};
         g.X = ln512; g.ldx = 512; g.W = c->fp_w32; g.M = (int)M; g.N = 768; g.K = 512; g.bias = c->fp_b; g.out0 = xf; g.ld0 = 768;
-        g.Tp = p.Tp; g.T = p.T; g.valid = valid; g.xpad = xpad; g.xpad_rows = p.Tp + 128;
+        g.Tp = p.Tp; g.T = p.T; g.valid = valid; g.xpad = xpad; g.xpad_rows = p.Tp + 128; g.tiled = 1;
         RUN("gemm_f32", launch_gemm_f32(g, s));
     }
     RUN("posconv_f32", launch_posconv_f32(xpad, c->pos_w32, c->pos_b, xf, pre, B, p.Tp, s));
@@ -708,21 +708,21 @@ static int forward_f32(sylber_ctx* c, const float* wav_dev, const int32_t* lengt
         const LayerDev& d = c->L[l];
         const bool last = (l == c->num_layers - 1) || (c->stop_stage == 3 + l);
         GemmArgsF32 g = {};
-        g.X = h; g.ldx = 768; g.W = c->L32[l].wqkv; g.M = (int)M; g.N = 2304; g.K = 768; g.bias = d.bqkv; g.out0 = qkv; g.ld0 = 2304;
+        g.X = h; g.ldx = 768; g.W = c->L32[l].wqkv; g.M = (int)M; g.N = 2304; g.K = 768; g.bias = d.bqkv; g.out0 = qkv; g.ld0 = 2304; g.tiled = 1;
         RUN("gemm_f32", launch_gemm_f32(g, s));
         RUN("attention_f32", launch_attention_f32(qkv, qkv + 768, qkv + 1536, valid, ctx, B, p.T, p.Tp, s));
         GemmArgsF32 o = {};
         o.X = ctx; o.ldx = 768; o.W = c->L32[l].wo; o.M = (int)M; o.N = 768; o.K = 768; o.bias = d.bo; o.out0 = pre; o.ld0 = 768;
-        o.res = h; o.ldres = 768;
+        o.res = h; o.ldres = 768; o.tiled = 1;
         RUN("gemm_f32", launch_gemm_f32(o, s));
         RUN("layernorm", run_ln(d.ln1w, d.ln1b, false));
         GemmArgsF32 f1 = {};
         f1.X = h; f1.ldx = 768; f1.W = c->L32[l].w1; f1.M = (int)M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = 1;
-        f1.out0 = ffn; f1.ld0 = 3072;
+        f1.out0 = ffn; f1.ld0 = 3072; f1.tiled = 1;
         RUN("gemm_f32", launch_gemm_f32(f1, s));
         GemmArgsF32 f2 = {};
         f2.X = ffn; f2.ldx = 3072; f2.W = c->L32[l].w2; f2.M = (int)M; f2.N = 768; f2.K = 3072; f2.bias = d.b2; f2.out0 = pre; f2.ld0 = 768;
-        f2.res = h; f2.ldres = 768;
+        f2.res = h; f2.ldres = 768; f2.tiled = 1;
         RUN("gemm_f32", launch_gemm_f32(f2, s));
         RUN("layernorm", run_ln(d.ln2w, d.ln2b, last));
         if (last) break;

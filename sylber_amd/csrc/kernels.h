@@ -72,6 +72,7 @@ struct GemmArgsF32 {
     const float* res; long ldres;
     int Tp, T; const int* valid;      // feature projection: zero frames t >= min(valid[b], T) (Tp > 0 enables row -> (b,t))
     float* xpad; int xpad_rows;       // optional second copy into the zero-padded pos-conv input
+    int tiled;                        // 1: the LDS-DMA 128x128 kernel (forward of the parity mode; K % 32 == 0); 0: the simple 64x64 one
 };
 int launch_gemm_f32(const GemmArgsF32& a, hipStream_t s);
 
