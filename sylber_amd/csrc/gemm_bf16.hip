@@ -29,6 +29,18 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((glb_vptr)g, (lds_vptr)l, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor: the per-lane part of the source address is a 32-bit byte offset that stays
+// CONSTANT over the K loop (and, in the persistent kernels, over the tiles), the K step / operand plane travel in the scalar
+// offset, the tile's first row in the descriptor base.  Against global_load_lds with a 64-bit per-lane address (two VALU
+// adds per piece and step, twice the address registers) tools/ubench/mfma_mix2.hip measures the DMA's cost beside the
+// MFMAs at +16 instead of +200 issue cycles per two pieces (profiles/r03_lds_dma_cost.md).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ void glds16b(__amdgpu_buffer_rsrc_t rs, int voff, int soff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)l, 16, voff, soff, 0, 0);
+}
+
 #include "gemm_epilogue.h"
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -60,35 +72,43 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
 
     // ---- staging: wave w owns pieces w, w+4, ...; piece p < BM/8 is X rows 8p.., else W rows
     const int srow = lane / CPR, spos = lane % CPR;
-    const bf16_t* gp[NPW];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + (size_t)m0 * a.ldx), rw = make_rsrc(a.W + (size_t)n0 * a.K);
+    int voff[NPW];                                           // byte offset of this lane's 16 bytes inside its operand's tile rows
     int lds_off[NPW];
-    long pl[NPW]; int sg[NPW];                               // FMT_SPLIT: lo-plane offset of piece i and the K segment that reads it
+    // pieces wave + 4 i with i < XPW are X rows for EVERY wave (the X pieces split evenly over the waves): which operand
+    // a piece belongs to is a compile-time property of i, so its descriptor is too
+    static_assert((BM / RPP) % 4 == 0, "X pieces must split evenly over the 4 waves");
+    constexpr int XPW = BM / RPP / 4;
+    const int pl_x = (int)(a.x_lo * 2), pl_w = (int)(a.w_lo * 2);   // FMT_SPLIT: lo-plane byte offsets
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         const int p = wave + 4 * i;
-        const bool isx = p < BM / RPP;
-        pl[i] = isx ? a.x_lo : a.w_lo; sg[i] = isx ? 1 : 2;
-        const int r = (isx ? p : p - BM / RPP) * RPP + srow;   // tile-local row
+        const bool isx_i = i < XPW;
+        const int r = (isx_i ? p : p - BM / RPP) * RPP + srow;   // tile-local row
         // source chunk landing at LDS position spos (bank swizzle through the source address)
         const int c = spos ^ (BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3));
-        if (isx) { int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1; gp[i] = a.X + (size_t)xm * a.ldx + c * 8; }
-        else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; gp[i] = a.W + (size_t)wr * a.K + c * 8; }
-        lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / RPP) * 1024;
+        if (isx_i) { int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1; voff[i] = (int)(((long)(xm - m0) * a.ldx + c * 8) * 2); }
+        else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; voff[i] = ((wr - n0) * a.K + c * 8) * 2; }
+        lds_off[i] = (isx_i ? 0 : XT) + (isx_i ? p : p - BM / RPP) * 1024;
     }
     // FMT_SPLIT: the K loop runs three segments over the same K range -- X.hi W.hi, X.lo W.hi, X.hi W.lo -- into one
-    // accumulator; a k-tile index beyond K / BK selects the plane through the source address only
+    // accumulator; a k-tile index beyond K / BK selects the plane through the scalar offset only
     const int ntk = a.K / BK;
-    auto ksrc = [&](int kt, int i) -> const bf16_t* {
-        if constexpr (FMT != FMT_SPLIT) return gp[i] + kt * BK;
+    auto ksoff = [&](int kt, bool isx_i) -> int {
+        if constexpr (FMT != FMT_SPLIT) return kt * (BK * 2);
         else {
             const int seg = (kt >= ntk ? 1 : 0) + (kt >= 2 * ntk ? 1 : 0);
-            return gp[i] + (kt - seg * ntk) * BK + (seg == sg[i] ? pl[i] : 0L);
+            return (kt - seg * ntk) * (BK * 2) + (seg == (isx_i ? 1 : 2) ? (isx_i ? pl_x : pl_w) : 0);
         }
+    };
+    auto dma = [&](int kt, int i, char* base) {
+        const bool isx_i = i < XPW;
+        glds16b(isx_i ? rx : rw, voff[i], ksoff(kt, isx_i), base + lds_off[i]);
     };
     auto stage = [&](int kt, int slot) {
         char* base = smem + slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) glds16(ksrc(kt, i), base + lds_off[i]);
+        for (int i = 0; i < NPW; ++i) dma(kt, i, base);
     };
 
     // ---- fragment read addresses (bytes within a stage)
@@ -143,7 +163,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
                 const int np = p1 - p0;
                 if (p >= p0 && p < p1 && ((p - p0 + 1) * NM + np - 1) / np - 1 == i) {
                     SCHED_FENCE();
-                    if (on) glds16(ksrc(kt, p), base + lds_off[p]);
+                    if (on) dma(kt, p, base);
                     SCHED_FENCE();
                 }
             }
@@ -291,34 +311,41 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     const int n0 = (wg % tiles_n) * BN;
 
     const int srow = lane >> 2, spos = lane & 3;
-    const bf16_t* gp[NPW_HI];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + (size_t)m0 * a.ldx), rw = make_rsrc(a.W + (size_t)n0 * a.K);
+    int voff[NPW_HI];
     int lds_off[NPW_HI];
-    long pl[NPW_HI]; int sg[NPW_HI];                 // FMT_SPLIT: lo-plane offset of piece i and the K segment that reads it
+    // pieces wave + 8 i with i < XPW are X rows for every wave: the operand (and its descriptor) of piece i is static
+    static_assert((BM / 16) % 8 == 0, "X pieces must split evenly over the 8 waves");
+    constexpr int XPW = BM / 16 / 8;
+    const int pl_x = (int)(a.x_lo * 2), pl_w = (int)(a.w_lo * 2);   // FMT_SPLIT: lo-plane byte offsets
 #pragma unroll
     for (int i = 0; i < NPW_HI; ++i) {
         int p = wave + 8 * i;
         p = p < NP ? p : NP - 1;                     // (unused slot of a "lo" wave; never issued)
-        const bool isx = p < BM / 16;
-        pl[i] = isx ? a.x_lo : a.w_lo; sg[i] = isx ? 1 : 2;
-        const int r = (isx ? p : p - BM / 16) * 16 + srow;
+        const bool isx_i = i < XPW;
+        const int r = (isx_i ? p : p - BM / 16) * 16 + srow;
         const int c = spos ^ ((r >> 2) & 3);
-        if (isx) { int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1; gp[i] = a.X + (size_t)xm * a.ldx + c * 8; }
-        else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; gp[i] = a.W + (size_t)wr * a.K + c * 8; }
-        lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / 16) * 1024;
+        if (isx_i) { int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1; voff[i] = (int)(((long)(xm - m0) * a.ldx + c * 8) * 2); }
+        else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; voff[i] = ((wr - n0) * a.K + c * 8) * 2; }
+        lds_off[i] = (isx_i ? 0 : XT) + (isx_i ? p : p - BM / 16) * 1024;
     }
     const int ntk = a.K / 32;                        // FMT_SPLIT: three K segments, see gemm_bf16_tile
-    auto ksrc = [&](int ks, int i) -> const bf16_t* {
-        if constexpr (FMT != FMT_SPLIT) return gp[i] + ks * 32;
+    auto ksoff = [&](int ks, bool isx_i) -> int {
+        if constexpr (FMT != FMT_SPLIT) return ks * 64;
         else {
             const int seg = (ks >= ntk ? 1 : 0) + (ks >= 2 * ntk ? 1 : 0);
-            return gp[i] + (ks - seg * ntk) * 32 + (seg == sg[i] ? pl[i] : 0L);
+            return (ks - seg * ntk) * 64 + (seg == (isx_i ? 1 : 2) ? (isx_i ? pl_x : pl_w) : 0);
         }
+    };
+    auto dma1 = [&](int ks, int i, char* base) {
+        const bool isx_i = i < XPW;
+        glds16b(isx_i ? rx : rw, voff[i], ksoff(ks, isx_i), base + lds_off[i]);
     };
     auto stage = [&](int ks, int slot) {
         char* base = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < NPW_HI; ++i)
-            if (i < NPW_LO || hi) glds16(ksrc(ks, i), base + lds_off[i]);
+            if (i < NPW_LO || hi) dma1(ks, i, base);
     };
     auto wait_steps = [&](int nsteps_in_flight) {    // leave that many of MY steps' pieces outstanding
         if (hi) {
@@ -365,7 +392,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         auto dma_pieces = [&](int q0, int q1) {
 #pragma unroll
             for (int q = q0; q < q1; ++q)
-                if (dma && q < NPW_HI && (q < NPW_LO || hi)) glds16(ksrc(s + 3, q), dbase + lds_off[q]);
+                if (dma && q < NPW_HI && (q < NPW_LO || hi)) dma1(s + 3, q, dbase);
         };
         SCHED_FENCE();
         if constexpr (VAR == 1) { dma_pieces(0, NPW_HI); SCHED_FENCE(); }
@@ -416,7 +443,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
                     const int q = (i + 1) / (NMF / NPW_HI) - 1;
                     if (VAR != 3 || q >= NPW_HI / 2) {
                         SCHED_FENCE();
-                        if (dma && q < NPW_HI && (q < NPW_LO || hi)) glds16(ksrc(s + 3, q), dbase + lds_off[q]);
+                        if (dma && q < NPW_HI && (q < NPW_LO || hi)) dma1(s + 3, q, dbase);
                         SCHED_FENCE();
                     }
                 }
@@ -456,6 +483,180 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// UNSTAGGERED 8-wave 256x256 tile (tile id 40).  The kernel above ping-pongs the two waves of a SIMD between an MFMA
+// phase and a load phase with TWO workgroup barriers per K step; its own stamps (profiles/r03_gemm_kloop_trace.md) put a
+// step at ~1420 cycles against the 1024 of the 2 x 16 MFMAs: the MFMA phase carries ~100 cycles of LDS-DMA issue, every
+// barrier hand-over costs 50-75, and the load phase waits ~250 idle.  Here all eight waves run the SAME stream, software-
+// pipelined inside the wave like the 4-wave kernel: fragments of the next k-substep are read while the MFMAs of the
+// current one issue (two register sets), the LDS-DMA of step s+3 sits between those MFMAs, and there is ONE barrier per
+// K step.  The two waves of a SIMD are not ordered against each other between barriers: whichever has an MFMA ready
+// issues it, and one wave's DMA / LDS issue time is covered by the other's MFMAs.
+//   step s (ring slot s & 3):   MFMA(s, kk0) x8  +  ds_read frags(s, kk1)      +  DMA(s+3) pieces 0,1  -> slot (s-1) & 3
+//                               lgkmcnt(0), vmcnt: my pieces of step s+1 landed;  s_barrier  [B(s)]
+//                               MFMA(s, kk1) x8  +  ds_read frags(s+1, kk0)    +  DMA(s+3) pieces 2,3
+// Hazards: slot (s-1) is free after B(s-1) (its last reads were waited for before that barrier); step s+1 is read only
+// after B(s), before which every wave retired its own pieces of it (younger: step s+2 and the first half of s+3 = 6).
+template <int EPI, int ACT, int FMT, bool TRACE = false>
+__device__ __forceinline__ void gemm8u_bf16_tile(const GemmArgs& a, const int tile_id, char* smem) {
+    constexpr int FM = 4, FN = 2, WM = 2, WN = 4;
+    unsigned long long tk0 = 0, tl0 = 0, tl1 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, sA = 0, sW1 = 0, sB = 0, sW2 = 0, cal = 0;
+    if constexpr (TRACE) TSTAMP(tk0);
+    constexpr int BM = 256, BN = 256, RB = 64;
+    constexpr int XT = BM * RB, STAGE = (BM + BN) * RB;
+    constexpr int NPW = 4;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+    const int wg = xcd_remap(tile_id, tiles_m * tiles_n);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const int srow = lane >> 2, spos = lane & 3;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + (size_t)m0 * a.ldx), rw = make_rsrc(a.W + (size_t)n0 * a.K);
+    int voff[NPW];
+    int lds_off[NPW];
+    constexpr int XPW = BM / 16 / 8;                 // pieces wave + 8 i with i < XPW are X rows for every wave
+    const int pl_x = (int)(a.x_lo * 2), pl_w = (int)(a.w_lo * 2);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int p = wave + 8 * i;
+        const bool isx_i = i < XPW;
+        const int r = (isx_i ? p : p - BM / 16) * 16 + srow;
+        const int c = spos ^ ((r >> 2) & 3);
+        if (isx_i) { int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1; voff[i] = (int)(((long)(xm - m0) * a.ldx + c * 8) * 2); }
+        else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; voff[i] = ((wr - n0) * a.K + c * 8) * 2; }
+        lds_off[i] = (isx_i ? 0 : XT) + (isx_i ? p : p - BM / 16) * 1024;
+    }
+    const int ntk = a.K / 32;
+    auto ksoff = [&](int ks, bool isx_i) -> int {
+        if constexpr (FMT != FMT_SPLIT) return ks * 64;
+        else {
+            const int seg = (ks >= ntk ? 1 : 0) + (ks >= 2 * ntk ? 1 : 0);
+            return (ks - seg * ntk) * 64 + (seg == (isx_i ? 1 : 2) ? (isx_i ? pl_x : pl_w) : 0);
+        }
+    };
+    auto dma1 = [&](int ks, int i, char* base) {
+        const bool isx_i = i < XPW;
+        glds16b(isx_i ? rx : rw, voff[i], ksoff(ks, isx_i), base + lds_off[i]);
+    };
+    auto stage = [&](int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) dma1(ks, i, smem + slot * STAGE);
+    };
+    const int frow = lane & 31, swz = (lane >> 2) & 3, fhalf = lane >> 5;
+    const int koff0 = (((0 + fhalf) ^ swz) << 4), koff1 = (((2 + fhalf) ^ swz) << 4);
+    const int xrow_off = (wm * 32 * FM + frow) * RB;
+    const int wrow_off = XT + (wn * 32 * FN + frow) * RB;
+    f32x16_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8_t xf[2][FM], wf[2][FN];
+    auto read_frags = [&](const char* sb, int koff, int buf) {
+#pragma unroll
+        for (int f = 0; f < FM; ++f) xf[buf][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff);
+#pragma unroll
+        for (int f = 0; f < FN; ++f) wf[buf][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff);
+    };
+    // 8 MFMAs of one k-substep with DMA pieces [p0, p0 + 2) of step `ks` between them
+    auto mfmas_dma = [&](int buf, int ks, char* dbase, int p0, bool on) {
+#pragma unroll
+        for (int i = 0; i < FM * FN; ++i) {
+            const int fm = i / FN, fn = i % FN;
+            acc[fm][fn] = H16<FMT>::mfma(wf[buf][fn], xf[buf][fm], acc[fm][fn]);
+            if (i == 1 || i == 5) {
+                const int q = p0 + (i == 5 ? 1 : 0);
+                SCHED_FENCE();
+                if (on) dma1(ks, q, dbase);
+                SCHED_FENCE();
+            }
+        }
+    };
+    const int nt = FMT == FMT_SPLIT ? 3 * ntk : ntk;
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    if (nt > 2) stage(2, 2);
+    if (nt > 2) wait_vmcnt<2 * NPW>(); else if (nt > 1) wait_vmcnt<NPW>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(smem, koff0, 0);
+    int slot = 0;
+    if constexpr (TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TSTAMP(tl0); TSTAMP(ta); TSTAMP(tb); cal = tb - ta; }
+    for (int s = 0; s < nt; ++s) {
+        const char* sb = smem + slot * STAGE;
+        const int nslot = (slot + 1) & 3;
+        char* dbase = smem + ((slot + 3) & 3) * STAGE;
+        const bool dma = s + 3 < nt;
+        if constexpr (TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TSTAMP(ta); }
+        SCHED_FENCE();
+        read_frags(sb, koff1, 1);
+        SCHED_FENCE();
+        mfmas_dma(0, s + 3, dbase, 0, dma);
+        SCHED_FENCE();
+        if (s + 1 < nt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (TRACE) { TSTAMP(tb); SCHED_FENCE(); }
+            // retire my pieces of step s+1; younger: step s+2 (4) and pieces 0,1 of step s+3
+            if (s + 3 < nt) wait_vmcnt<NPW + 2>(); else if (s + 2 < nt) wait_vmcnt<NPW>(); else wait_vmcnt<0>();
+            if constexpr (TRACE) { TSTAMP(tc); SCHED_FENCE(); }
+            __builtin_amdgcn_s_barrier();
+            SCHED_FENCE();
+            if constexpr (TRACE) { TSTAMP(td); SCHED_FENCE(); }
+            read_frags(smem + nslot * STAGE, koff0, 0);
+            SCHED_FENCE();
+        }
+        mfmas_dma(1, s + 3, dbase, 2, dma);
+        if constexpr (TRACE) { if (s + 1 < nt) { sA += tb - ta; sW1 += tc - tb; sB += td - tc; } }
+        slot = nslot;
+    }
+    if constexpr (TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TSTAMP(tl1); }
+    __builtin_amdgcn_s_barrier();                     // every wave is done reading operand tiles
+    if constexpr (TRACE) {
+        // [0] kk0 group (8 MFMA + 6 reads + 2 DMA) incl. the lgkmcnt wait, [1] vmcnt wait, [2] barrier, [3] unused
+        if (a.trace && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0) {
+            unsigned long long* o = a.trace + (wave >> 2) * 10;
+            o[0] = sA; o[1] = sW1; o[2] = sB; o[3] = sW2; o[4] = tl1 - tl0; o[5] = (unsigned long long)nt; o[6] = cal; o[7] = 0; o[8] = tl0 - tk0; o[9] = tl1 - tk0;
+        }
+    }
+    if constexpr (EPI == EPI_QK || EPI == EPI_PROJ || EPI == EPI_BF16) {
+        char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
+        epilogue_staged<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
+    } else {
+        epilogue_direct<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
+    }
+}
+
+template <int EPI, int ACT, int FMT, bool TRACE = false>
+__global__ __launch_bounds__(512, 2) void gemm8u_bf16_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gemm8u_bf16_tile<EPI, ACT, FMT, TRACE>(a, tile, smem);
+        if (tile + (int)gridDim.x < ntiles) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
+template <int EPI, int ACT, int FMT, bool TRACE = false>
+static int launch_cfg8u(const GemmArgs& a, hipStream_t s) {
+    constexpr int LDS = 4 * (256 + 256) * 64;
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    static PerDeviceOnce attr_once;
+    auto kern = gemm8u_bf16_kernel<EPI, ACT, FMT, TRACE>;
+    if (attr_once.need()) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    }
+    int grid = tiles;
+    if (a.tune_persist > 0 && tiles > 256) grid = 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 // One launch = min(#tiles, 256 x per_cu) workgroups walking the tile list with stride gridDim.x (256 % 8 == 0, so a
 // workgroup's tiles all map to its own XCD's chunk).  Measured with rocprofv3 PMC (profiles/r01_mfma_util.md): the
@@ -515,42 +716,45 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
     const int nt = FMT == FMT_SPLIT ? 3 * ntk : ntk;
 
     int lds_off[NPW];
-    bool isx[NPW];
-    int prow[NPW];                                   // tile-local row of this lane in piece i
+    int voff[NPW];                                   // this lane's byte offset inside its operand's tile rows: the SAME for every tile
+    constexpr int XPW = BM / 16 / 8;                 // pieces wave + 8 i with i < XPW (= 2) are X rows for every wave
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         const int p = wave + 8 * i;
-        isx[i] = p < BM / 16;
-        const int r = (isx[i] ? p : p - BM / 16) * 16 + srow;
-        prow[i] = r;
-        lds_off[i] = (isx[i] ? 0 : XT) + (isx[i] ? p : p - BM / 16) * 1024;
+        const bool isx_i = i < XPW;
+        const int r = (isx_i ? p : p - BM / 16) * 16 + srow;
+        const int c = spos ^ ((r >> 2) & 3);         // source chunk (bank swizzle through the source address)
+        voff[i] = isx_i ? (int)(((long)r * a.ldx + c * 8) * 2) : (r * a.K + c * 8) * 2;
+        lds_off[i] = (isx_i ? 0 : XT) + (isx_i ? p : p - BM / 16) * 1024;
     }
-    const int csw = spos;                            // source chunk = spos ^ ((r >> 2) & 3), r-dependent part below
-    auto setup = [&](int tile_id, const bf16_t* (&g)[NPW], int& m0, int& n0) {
+    const int pl_x = (int)(a.x_lo * 2), pl_w = (int)(a.w_lo * 2);
+    // a tile = two buffer descriptors (X rows from m0, W rows from n0): scalar registers only
+    struct TileSrc { __amdgpu_buffer_rsrc_t rx, rw; };
+    auto setup = [&](int tile_id, TileSrc& g, int& m0, int& n0) {
         const int wg = xcd_remap(tile_id, ntiles);
         m0 = (wg / tiles_n) * BM;
         n0 = (wg % tiles_n) * BN;
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            const int c = csw ^ ((prow[i] >> 2) & 3);
-            g[i] = isx[i] ? a.X + (size_t)(m0 + prow[i]) * a.ldx + c * 8 : a.W + (size_t)(n0 + prow[i]) * a.K + c * 8;
-        }
+        g.rx = make_rsrc(a.X + (size_t)m0 * a.ldx);
+        g.rw = make_rsrc(a.W + (size_t)n0 * a.K);
     };
-    auto ksrc = [&](const bf16_t* const (&g)[NPW], int ks, int i) -> const bf16_t* {
-        if constexpr (FMT != FMT_SPLIT) return g[i] + ks * 32;
+    auto ksoff = [&](int ks, bool isx_i) -> int {
+        if constexpr (FMT != FMT_SPLIT) return ks * 64;
         else {
             const int seg = (ks >= ntk ? 1 : 0) + (ks >= 2 * ntk ? 1 : 0);
-            return g[i] + (ks - seg * ntk) * 32 + (seg == (isx[i] ? 1 : 2) ? (isx[i] ? a.x_lo : a.w_lo) : 0L);
+            return (ks - seg * ntk) * 64 + (seg == (isx_i ? 1 : 2) ? (isx_i ? pl_x : pl_w) : 0);
         }
     };
-    auto stage = [&](const bf16_t* const (&g)[NPW], int ks, int slot) {
+    auto dma1 = [&](const TileSrc& g, int ks, int i, char* base) {
+        const bool isx_i = i < XPW;
+        glds16b(isx_i ? g.rx : g.rw, voff[i], ksoff(ks, isx_i), base + lds_off[i]);
+    };
+    auto stage = [&](const TileSrc& g, int ks, int slot) {
         char* base = smem + slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) glds16(ksrc(g, ks, i), base + lds_off[i]);
+        for (int i = 0; i < NPW; ++i) dma1(g, ks, i, base);
     };
 
-    const bf16_t* gp[NPW];
-    const bf16_t* gn[NPW];
+    TileSrc gp, gn;
     int m0, n0, m0n = 0, n0n = 0;
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
@@ -604,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
                 if ((i + 1) % (NMF / NPW) == 0) {
                     const int q = (i + 1) / (NMF / NPW) - 1;
                     SCHED_FENCE();
-                    if (dma) glds16(ksrc(gp, s + 3, q), dbase + lds_off[q]);
+                    if (dma) dma1(gp, s + 3, q, dbase);
                     SCHED_FENCE();
                 }
             }
@@ -630,8 +834,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
         if (nt > 2) stage(gn, 2, 0);
         // step 0 of the next tile has landed: younger than it are step 1, the NST stores and step 2
         if (nt > 2) wait_vmcnt<NPW + NST + NPW>(); else if (nt > 1) wait_vmcnt<NPW + NST>(); else wait_vmcnt<NST>();
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) gp[i] = gn[i];
+        gp = gn;
         m0 = m0n; n0 = n0n; tile = next; seam = true;
     }
 }
@@ -713,6 +916,8 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
         case 20: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 1>(a, s); break;   // K-loop schedule A/B
         case 21: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 2>(a, s); break;
         case 22: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 3>(a, s); break;
+        case 40: if constexpr (FMT == FMT_BF16) return launch_cfg8u<EPI, ACT, FMT>(a, s); break;                     // unstaggered 8-wave 256x256
+        case 41: if constexpr (FMT == FMT_BF16 && EPI == EPI_BF16 && ACT == 0) return launch_cfg8u<EPI, ACT, FMT, true>(a, s); break;   // its trace
         case 30: if constexpr (FMT == FMT_BF16 && (EPI == EPI_BF16 || EPI == EPI_F32_RESLN)) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 10>(a, s); break;   // trace
         default: break;
     }

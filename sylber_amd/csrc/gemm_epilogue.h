@@ -157,12 +157,15 @@ __device__ __forceinline__ void epilogue_vt_rows32(const GemmArgs& a, const f32x
         for (int g = 0; g < 4; ++g) {
             const int nl = 32 * fn + 8 * g + 4 * h;
             const float4 bb = bias[fn][g];
-            const float v[4] = {acc[fn][4 * g + 0] + bb.x, acc[fn][4 * g + 1] + bb.y, acc[fn][4 * g + 2] + bb.z, acc[fn][4 * g + 3] + bb.w};
+            if constexpr (PLANE != 1) {
+                *(bf16_t*)(lds + (nl + 0) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 0] + bb.x);
+                *(bf16_t*)(lds + (nl + 1) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 1] + bb.y);
+                *(bf16_t*)(lds + (nl + 2) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 2] + bb.z);
+                *(bf16_t*)(lds + (nl + 3) * 64 + pos * 2) = H16<FMT>::cvt(acc[fn][4 * g + 3] + bb.w);
+            } else {
+                const float v[4] = {acc[fn][4 * g + 0] + bb.x, acc[fn][4 * g + 1] + bb.y, acc[fn][4 * g + 2] + bb.z, acc[fn][4 * g + 3] + bb.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bf16_t w = H16<FMT>::cvt(v[e]);
-                if constexpr (PLANE == 1) w = H16<FMT_SPLIT>::cvt_lo(v[e], w);
-                *(bf16_t*)(lds + (nl + e) * 64 + pos * 2) = w;
+                for (int e = 0; e < 4; ++e) *(bf16_t*)(lds + (nl + e) * 64 + pos * 2) = H16<FMT_SPLIT>::cvt_lo(v[e], H16<FMT>::cvt(v[e]));
             }
         }
     if (mrow0 >= a.M) return;

@@ -25,3 +25,17 @@ for name, m, n, k, ldx, epi, act in SHAPES:
             name, g, st, o[0] / st, o[1] / st, o[2] / st, o[3] / st, o[4] / st, o[6], o[8], o[4], o[7], o[9]), flush=True)
 print("\ncycles per step and wave (shader clock, s_memtime); every segment contains one stamp (its cost in the 'stamp cost' column);")
 print("16 v_mfma_f32_32x32x16_bf16 occupy the SIMD's matrix pipe for 512 cycles, and two waves share a SIMD: 1024 per step is the floor.")
+
+print("\n### unstaggered 8-wave kernel (tile id 40), same stamps: [A] = kk0 group (8 MFMA + 6 reads + 2 DMA, until its fragments landed), "
+      "[barrier after A] = vmcnt wait, [B] = s_barrier\n")
+print("| shape | wave | steps | kk0 group | vmcnt wait | barrier | - | step total | stamp cost | prologue | K loop |")
+print("|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+for name, m, n, k, ldx, epi, act in SHAPES[:3]:
+    out = (ctypes.c_uint64 * 20)()
+    ms = ctypes.c_float()
+    _lib.check(lib.sylber_debug_gemm_trace(m, n, k, ldx, 0, 100, out, ctypes.byref(ms)), "gemm_trace")
+    for g in range(2):
+        o = out[g * 10:(g + 1) * 10]
+        st = max(int(o[5]), 1)
+        print("| %s | wave %d | %d | %.0f | %.0f | %.0f | %.0f | %.0f | %d | %d | %d |" % (
+            name, 4 * g, st, o[0] / st, o[1] / st, o[2] / st, o[3] / st, o[4] / st, o[6], o[8], o[4]), flush=True)
