@@ -68,6 +68,8 @@ def parse_args():
                     help="N>1 exchange step: 'scatter' = the job's clips live on rank 0 and are scattered over RCCL every step "
                          "(default, BASELINE configs[2]); 'per-rank' = every rank's shard lives in its own page-locked host memory "
                          "and crosses that GPU's own PCIe link every step (SURVEY.md §8(e)), gather unchanged")
+    ap.add_argument("--fuse-ln", choices=["auto", "on", "off"], default="auto",
+                    help="attention out-projection + LayerNorm as one launch (SYLBER_OPT_FUSE_OUTPROJ_LN); A/B switch")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
     ap.add_argument("--agreement-clips", type=int, default=0,
                     help="also report bf16-vs-fp32 segment agreement on this many synthetic clips (fp32 parity mode as truth)")
@@ -232,6 +234,9 @@ def main():
     if args.graph:
         for e_ in encs:
             e_.set_graph_mode(True)
+    if args.fuse_ln != "auto":
+        for e_ in encs:
+            e_.set_option(4, 1 if args.fuse_ln == "on" else -1)
     T_frames = enc.num_frames(clip_samples)
     on_cpu_group = world > 1 and dist.get_backend() != "nccl"
 

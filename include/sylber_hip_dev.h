@@ -11,7 +11,8 @@ extern "C" {
 #endif
 /* average ms of one launch of the bf16 GEMM kernel (M x N x K, activation row stride ldx) on pseudo-random
  * operands; epi / act as in csrc/kernels.h; cfg: -1 = automatic tile shape, else persist * 1000 + tile id;
- * cfg in [100, 200): the MXFP8 GEMM with tile configuration cfg - 100 */
+ * cfg in [100, 200): the MXFP8 GEMM with tile configuration cfg - 100; cfg + 200000: every timed launch finds its
+ * operands cold (1 GiB written between the launches, each launch timed by its own event pair) */
 int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
                             int32_t iters, float* ms_out);
 /* the same launch through the TRACE instantiation of the 8-wave 256x256 kernel (s_memtime stamps around the phases of its K

@@ -85,6 +85,7 @@ struct sylber_ctx {
     float* seg_scratch = nullptr; size_t seg_scratch_floats = 0;
     int stop_stage = 0;
     int opt_gemm_cfg = 0, opt_attn_qw = 0, opt_gemm_persist = 0;   // sylber_set_option (0 = automatic)
+    int opt_fuse_ln = 0;                                           // out-projection + LayerNorm in one launch: 0 auto, 1 always, -1 never
     bool graph_mode = false;
     std::vector<GraphEntry> graphs; unsigned long long graph_clock = 0;
     // profiling
@@ -269,6 +270,7 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
         case SYLBER_OPT_GEMM_TILE: c->opt_gemm_cfg = value < 0 ? 0 : value + 1; break;     // stored as id + 1, 0 = automatic
         case SYLBER_OPT_ATTN_QUERIES_PER_WAVE: c->opt_attn_qw = value == 32 ? 1 : (value == 64 ? 2 : 0); break;
         case SYLBER_OPT_GEMM_PERSISTENT: c->opt_gemm_persist = value; break;      // < 0: also keep the 256x256 kernel one tile per workgroup
+        case SYLBER_OPT_FUSE_OUTPROJ_LN: c->opt_fuse_ln = value > 0 ? 1 : (value < 0 ? -1 : 0); break;
         default: syl_set_error("sylber_set_option", "unknown option key"); return 1;
     }
     if (c->graph_mode) { for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec); c->graphs.clear(); }   // captured launches are stale
@@ -517,6 +519,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     for (int l = 0; l < c->num_layers; ++l) {
         const LayerDev& d = c->L[l];
         const bool last = (l == c->num_layers - 1) || (c->stop_stage == 3 + l);
+        bool fused_ln1 = false;
         // one launch for q, k and v (N = 2304): the q / k thirds leave head-major, the v third transposed (EPI_QK)
         if (f8) {
             GemmF8Args g = {};
@@ -546,9 +549,13 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
         o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist; o.fmt = c->fmt;
         o.x_lo = p.lo_ctx; o.w_lo = (long)768 * 768;
-        RUN("gemm_out", launch_gemm_bf16(EPI_F32_RESLN, o, s));
+        // out-projection + LayerNorm 1 as ONE launch on full-row tiles (gemm_rowln.hip) where the batch fills the chip
+        o.out1 = hbf; o.ln_stats_out = stats; o.ln_gamma_out = d.ln1w; o.ln_beta_out = d.ln1b;
+        fused_ln1 = !split && c->opt_fuse_ln > 0 && gemm_rowln_applicable(o);      // measured: faster as a pair, slower with two batches in flight
+        if (fused_ln1) RUN("gemm_out_ln", launch_gemm_rowln(o, s));
+        else RUN("gemm_out", launch_gemm_bf16(EPI_F32_RESLN, o, s));
         }
-        RUN("layernorm", run_ln(d.ln1w, d.ln1b, false, f8));
+        if (!fused_ln1) RUN("layernorm", run_ln(d.ln1w, d.ln1b, false, f8));
         if (f8) {
             GemmF8Args f1 = {};
             f1.g.M = M; f1.g.N = 3072; f1.g.K = 768; f1.g.bias = d.b1; f1.g.act = 1; f1.g.out0 = ffn8; f1.g.ld0 = 3072;
@@ -931,6 +938,8 @@ static int gemm_bench_f8(int M, int N, int K, int epi, int act, int cfg, int ite
 static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg, int32_t iters,
                            float* ms_out, unsigned long long* g_gemm_trace_out) {
     if (cfg >= 100 && cfg < 200) return gemm_bench_f8(M, N, K, epi, act, cfg - 100, iters, ms_out);
+    const bool cold = cfg >= 150000;                      // cfg + 200000: operands flushed out of the caches before every launch
+    if (cold) cfg -= 200000;
     TmpBuf xb, wb, ob, rb, bb;
     const size_t xn = (size_t)(M + 8) * ldx + K, wn = (size_t)N * K;
     if (xb.alloc(xn * 2) || wb.alloc(wn * 2) || ob.alloc((size_t)M * N * 4) || rb.alloc((size_t)M * N * 4) || bb.alloc((size_t)N * 4)) {
@@ -970,6 +979,26 @@ static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t
     hipEventCreate(&e0); hipEventCreate(&e1);
     int rc = 0;
     for (int i = 0; i < 3 && !rc; ++i) rc = launch_gemm_bf16(epi, g, 0);
+    if (cold) {
+        // every timed launch finds its operands COLD: 1 GiB is written between the launches (the 256 MB memory-side cache
+        // and the L2s hold none of X / W / res afterwards), each launch timed by its own event pair
+        TmpBuf flush;
+        if (flush.alloc((size_t)1 << 30)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }
+        float tot = 0.f;
+        for (int i = 0; i < iters && !rc; ++i) {
+            hipMemsetAsync(flush.p, i & 0xff, (size_t)1 << 30, 0);
+            hipEventRecord(e0, 0);
+            rc = launch_gemm_bf16(epi, g, 0);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms1 = 0.f;
+            hipEventElapsedTime(&ms1, e0, e1);
+            tot += ms1;
+        }
+        *ms_out = tot / iters;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        return rc;
+    }
     hipEventRecord(e0, 0);
     for (int i = 0; i < iters && !rc; ++i) rc = launch_gemm_bf16(epi, g, 0);
     hipEventRecord(e1, 0);

@@ -21,6 +21,7 @@
 // remapped so that each XCD owns a contiguous run of tiles (shared X panel in L2; same row ownership as the
 // LayerNorm / attention launches between the GEMMs).
 #include "kernels.h"
+#include <type_traits>
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* glb_vptr;
@@ -184,13 +185,19 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     __builtin_amdgcn_s_barrier();
     read_frags(smem, 0, 0);
     int slot = 0;
-    for (int t = 0; t < nt; ++t) {
+    // one K tile.  STEADY (2-slot ring, 1 <= t <= nt - 3): every "does tile t+1 / t+2 exist" test is true, so the loop
+    // that runs nearly all tiles carries no branch around its DMA instructions (same-box A/B of this peel on the 8-wave
+    // kernel: conv1-4, FFN1 +3 %); the first and the last two tiles take the general form
+    auto ktile = [&](auto steady, int t) {
+        constexpr bool STEADY = decltype(steady)::value;
         const char* sb = smem + slot * STAGE;
         const int nslot = slot == NSTAGE - 1 ? 0 : slot + 1;
         // 2-slot ring: the DMA of tile t+1 (into the slot tile t-1 left at the previous barrier) was started
         // under the last MFMA group of tile t-1 (pieces [0, D0)) and continues under groups 0 and 1 here
         constexpr int D0 = (NPW * 2 + 4) / 5, D1 = D0 + (NPW - D0 + 1) / 2;   // e.g. NPW = 10 -> 4 | 3 | 3
-        const bool cont = (NSTAGE == 2) && (t >= 1) && (t + 1 < nt);
+        const bool has_next = STEADY || (t + 1 < nt);
+        const bool cont = STEADY || ((NSTAGE == 2) && (t >= 1) && (t + 1 < nt));
+        const bool dma2 = STEADY || ((t + 1 < nt) && (t + 2 < nt));
 #pragma unroll
         for (int kk = 0; kk < KK - 1; ++kk) {
             SCHED_FENCE();
@@ -201,7 +208,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
             else mfmas(kk & 1);
         }
         SCHED_FENCE();
-        if (t + 1 < nt) {
+        if (has_next) {
             // every ds_read of tile t has been issued; once they have landed (lgkmcnt(0)) and my pieces of
             // tile t+1 have landed (counted vmcnt: tile t+2 stays in flight), meet the other waves.  After
             // the barrier tile t+1 is visible and slot(t) is dead -> refill it with tile t+3, and fetch the
@@ -217,9 +224,17 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
             if constexpr (NSTAGE != 2) { if (t + NSTAGE < nt) stage(t + NSTAGE, slot); }
             SCHED_FENCE();
         }
-        if constexpr (NSTAGE == 2) mfmas_dma((KK - 1) & 1, t + 2, slot, 0, D0, (t + 1 < nt) && (t + 2 < nt));
+        if constexpr (NSTAGE == 2) mfmas_dma((KK - 1) & 1, t + 2, slot, 0, D0, dma2);
         else mfmas((KK - 1) & 1);
         slot = nslot;
+    };
+    if constexpr (NSTAGE == 2) {
+        int t = 0;
+        if (nt > 0) ktile(std::false_type{}, t++);
+        for (; t < nt - 2; ++t) ktile(std::true_type{}, t);
+        for (; t < nt; ++t) ktile(std::false_type{}, t);
+    } else {
+        for (int t = 0; t < nt; ++t) ktile(std::false_type{}, t);
     }
 
     // ---- epilogue
@@ -776,7 +791,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         int slot = 2;
-        for (int s = 0; s < nt; ++s) {
+        // one K step; DMA_ON is a compile-time property of the loop it sits in (main loop: step s+3 exists, tail: it does
+        // not), so the steady-state loop carries no branch around its four DMA instructions
+        auto kstep = [&](auto dma_on, int s) {
+            constexpr bool DMA_ON = decltype(dma_on)::value;
             const char* sb = smem + slot * STAGE;
             bf16x8_t xf[2][FM], wf[2][FN];
             SCHED_FENCE();
@@ -791,13 +809,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
                 wf[1][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff1);
             }
             // retire step s+1 (step s+2 may stay in flight; at a seam the epilogue's stores sit between them)
-            if (nt - 2 - s >= 1) { if (seam && s == 0) wait_vmcnt<NST + NPW>(); else wait_vmcnt<NPW>(); }
+            if (DMA_ON || nt - 2 - s >= 1) { if (seam && s == 0) wait_vmcnt<NST + NPW>(); else wait_vmcnt<NPW>(); }
             else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             SCHED_FENCE();
             __builtin_amdgcn_s_barrier();
             SCHED_FENCE();
-            const bool dma = s + 3 < nt;
             char* dbase = smem + ((slot + 3) & 3) * STAGE;
             constexpr int NMF = 2 * FM * FN;
             __builtin_amdgcn_s_setprio(1);
@@ -805,18 +822,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
             for (int i = 0; i < NMF; ++i) {
                 const int kk = i / (FM * FN), fm = (i / FN) % FM, fn = i % FN;
                 acc[fm][fn] = H16<FMT>::mfma(wf[kk][fn], xf[kk][fm], acc[fm][fn]);
-                if ((i + 1) % (NMF / NPW) == 0) {
-                    const int q = (i + 1) / (NMF / NPW) - 1;
-                    SCHED_FENCE();
-                    if (dma) dma1(gp, s + 3, q, dbase);
-                    SCHED_FENCE();
+                if constexpr (DMA_ON) {
+                    if ((i + 1) % (NMF / NPW) == 0) {
+                        const int q = (i + 1) / (NMF / NPW) - 1;
+                        SCHED_FENCE();
+                        dma1(gp, s + 3, q, dbase);
+                        SCHED_FENCE();
+                    }
                 }
             }
             __builtin_amdgcn_s_setprio(0);
             SCHED_FENCE();
             __builtin_amdgcn_s_barrier();
             slot = (slot + 1) & 3;
-        }
+        };
+        for (int s = 0; s < nt - 3; ++s) kstep(std::true_type{}, s);
+        for (int s = nt - 3 > 0 ? nt - 3 : 0; s < nt; ++s) kstep(std::false_type{}, s);
         if (group == 0) __builtin_amdgcn_s_barrier();    // pairs with group 1's extra barrier
         __builtin_amdgcn_s_barrier();                    // every wave is done reading operand tiles
         const int next = tile + (int)gridDim.x;
@@ -916,6 +937,8 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
         case 20: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 1>(a, s); break;   // K-loop schedule A/B
         case 21: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 2>(a, s); break;
         case 22: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 3>(a, s); break;
+        case 50: if constexpr (FMT == FMT_BF16) return launch_cfg<4, 2, 32, 3, 2, false, EPI, ACT, FMT>(a, s); break;       // 256x128, K step 32, 3 slots, 2 WG/CU
+        case 51: if constexpr (FMT == FMT_BF16) return launch_cfg<2, 4, 32, 3, 2, false, EPI, ACT, FMT>(a, s); break;       // 128x256, same
         case 40: if constexpr (FMT == FMT_BF16) return launch_cfg8u<EPI, ACT, FMT>(a, s); break;                     // unstaggered 8-wave 256x256
         case 41: if constexpr (FMT == FMT_BF16 && EPI == EPI_BF16 && ACT == 0) return launch_cfg8u<EPI, ACT, FMT, true>(a, s); break;   // its trace
         case 30: if constexpr (FMT == FMT_BF16 && (EPI == EPI_BF16 || EPI == EPI_F32_RESLN)) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 10>(a, s); break;   // trace

@@ -35,6 +35,8 @@ struct GemmArgs {
     int xpad_rows;                // rows per utterance of the zero-padded pos-conv input (EPI_PROJ)
     const float* ln_stats;        // [M][2] (mean, rstd) of the rows of `res` (EPI_F32_RESLN)
     const float* ln_gamma; const float* ln_beta;
+    float* ln_stats_out;          // gemm_rowln: [M][2] (mean, rstd) of the rows this launch produces
+    const float* ln_gamma_out; const float* ln_beta_out;   // gemm_rowln: affine of the LayerNorm applied to them
     int fmt;                      // FMT_BF16 (0), FMT_F16 or FMT_SPLIT: 16-bit format of X, W and of bf16-typed outputs
     long x_lo, w_lo;              // FMT_SPLIT: element offsets of the lo planes of X and W (hi plane at the pointer)
     long out_lo;                  // FMT_SPLIT: element offset of the lo plane of the 16-bit outputs out0 / out1
@@ -45,6 +47,9 @@ struct GemmArgs {
 };
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
+// residual GEMM + the LayerNorm that follows it in one launch (gemm_rowln.hip): N = 768, full rows per workgroup
+bool gemm_rowln_applicable(const GemmArgs& a);
+int launch_gemm_rowln(const GemmArgs& a, hipStream_t s);
 
 // MXFP8 GEMM (gemm_mxfp8.hip): e4m3 operands [rows][K] with one E8M0 scale per 32 elements along K stored
 // K-pair-major [K/64][rows_pitch][2] (common.h mx_scale_index; pitches are multiples of 8, and the scale arrays of

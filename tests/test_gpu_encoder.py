@@ -104,6 +104,24 @@ def test_full_size_config_vs_oracle_sample(enc, sd):
     assert rel_rms(out[31], ref[1]) < STAGE_TOL["hidden"]
 
 
+def test_fused_outproj_layernorm_bitwise(sd):
+    """SYLBER_OPT_FUSE_OUTPROJ_LN: the attention out-projection + LayerNorm as ONE launch on full-row tiles
+    (csrc/gemm_rowln.hip) returns bit for bit what the GEMM launch + the LayerNorm launch return (same expressions, same
+    summation order), for a full batch, ragged lengths (tile tails) and a small batch (forced on)"""
+    from sylber_amd import HubertEncoderHIP
+    a, b = HubertEncoderHIP(sd), HubertEncoderHIP(sd)
+    a.set_option(4, 1); b.set_option(4, -1)
+    x = noise_batch(32, 160000, seed=21).cuda()
+    assert torch.equal(a.forward(x), b.forward(x))
+    assert torch.equal(a.forward(x), a.forward(x))                       # and reproducibly so
+    y = noise_batch(3, 52000, seed=22).cuda()
+    lens = [52000, 31000, 47011]
+    assert torch.equal(a.forward(y, lens), b.forward(y, lens))
+    h = HubertEncoderHIP(sd, precision="fp16"); g = HubertEncoderHIP(sd, precision="fp16")
+    h.set_option(4, 1); g.set_option(4, -1)
+    assert torch.equal(h.forward(y, lens), g.forward(y, lens))
+
+
 def test_long_form_config(enc, sd):
     """BASELINE configs[3] at its stated batch: 8 x 60 s clips (T = 2999: O(T^2) attention, 192k-step GroupNorm).
     At this size the CPU oracle would take minutes, so the full batch is checked through size-independent properties

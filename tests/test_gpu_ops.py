@@ -86,7 +86,7 @@ def test_attention(lib, B, T, valid, qw):
     assert (o.cpu() - ref).pow(2).mean().sqrt().item() < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11, 20, 21, 22, 40])
+@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11, 20, 21, 22, 40, 50, 51])
 def test_linear_every_tile_config(lib, cfg):
     """every GEMM tile configuration (4-wave 2/3-slot rings, 8-wave staggered big tiles) gives the same
     result, including ragged M / N tails and a strided (overlapping-row) activation operand"""
