@@ -868,8 +868,9 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
     const int qw = queries_per_wave == 32 ? 1 : (queries_per_wave == 64 ? 2 : 0);
     TmpBuf qb, kb, vb, cb;
     const size_t n = (size_t)B * Tp * 768;
-    if (qb.alloc(n * 2) || kb.alloc(n * 2) || vb.alloc((size_t)B * 768 * Tpv * 2) || cb.alloc(n * 2)) { syl_set_error("sylber_op_attention", "alloc"); return 1; }
-    HIP_TRY(hipMemsetAsync(qb.p, 0, n * 2, s)); HIP_TRY(hipMemsetAsync(kb.p, 0, n * 2, s));
+    // (k: one 64-key tile of slack -- the kernel's last K tile may start at Tp - 32 and reads 64 rows; the scores of rows >= Tp are masked)
+    if (qb.alloc(n * 2) || kb.alloc(n * 2 + 64 * 64 * 2) || vb.alloc((size_t)B * 768 * Tpv * 2) || cb.alloc(n * 2)) { syl_set_error("sylber_op_attention", "alloc"); return 1; }
+    HIP_TRY(hipMemsetAsync(qb.p, 0, n * 2, s)); HIP_TRY(hipMemsetAsync(kb.p, 0, n * 2 + 64 * 64 * 2, s));
     HIP_TRY(hipMemsetAsync(vb.p, 0, (size_t)B * 768 * Tpv * 2, s)); HIP_TRY(hipMemsetAsync(cb.p, 0, n * 2, s));
     hipLaunchKernelGGL(pack_qkv_kernel, dim3(T, B), dim3(256), 0, s, q_dev, k_dev, v_dev, (bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, T, Tp, Tpv);
     if (launch_attention((bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, valid_dev, (bf16_t*)cb.p, B, T, Tp, Tpv, qw, s)) return 1;

@@ -24,8 +24,13 @@
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* glb_vptr;
-__device__ __forceinline__ void glds16a(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((glb_vptr)g, (lds_vptr)l, 16, 0, 0);
+// LDS-DMA through a buffer descriptor (constant per-lane byte offset, the tile's first key in the scalar offset): no 64-bit
+// per-lane address arithmetic per tile (profiles/r03_lds_dma_cost.md)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_a(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ void glds16a(__amdgpu_buffer_rsrc_t rs, int voff, int soff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)l, 16, voff, soff, 0, 0);
 }
 
 // 1/l and the store of one 32-query sub-tile: ctx[b*Tp + q][head*64 + d] (or its MXFP8 form)
@@ -143,16 +148,18 @@ __global__ __launch_bounds__(256, FMT == FMT_SPLIT ? 2 : (QW == 2 ? 3 : 4)) void
     }
     // staging: wave w fills rows [16w, 16w+16) of the K tile and of the V^T tile, 8 rows per instruction
     const int srow = lane >> 3, spos = lane & 7;
-    const bf16_t* gk[2];
-    const bf16_t* gv[2];
-    int krow[2];
+    // K rows beyond Tp (a last tile of 64 keys when Tp % 64 == 32) are read from whatever follows -- the next head's rows or
+    // the next workspace buffer, finite or not: their scores are REPLACED by -inf through the key mask (a select, no
+    // arithmetic), and V^T's key tail is kept zero by its producer
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc_a(Kb), rv = make_rsrc_a(Vb);
+    const __amdgpu_buffer_rsrc_t rkl = make_rsrc_a(Kb + lo_qk), rvl = make_rsrc_a(Vb + lo_vt);
+    int kvoff[2], vvoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = wave * 16 + i * 8 + srow;
         const int c = spos ^ ((r >> 1) & 7);
-        krow[i] = r;
-        gk[i] = Kb + c * 8;                        // + key row * 64 added per tile (clamped)
-        gv[i] = Vb + (size_t)r * Tpv + c * 8;      // + kv0 per tile
+        kvoff[i] = (r * 64 + c * 8) * 2;           // + key tile * 64 rows in the scalar offset
+        vvoff[i] = (r * Tpv + c * 8) * 2;          // + first key of the tile
     }
     const int lds_piece = wave * 16 * 128;
 
@@ -175,12 +182,11 @@ __global__ __launch_bounds__(256, FMT == FMT_SPLIT ? 2 : (QW == 2 ? 3 : 4)) void
     {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int kr = krow[i]; kr = kr < Tp ? kr : Tp - 1;
-            glds16a(gk[i] + (size_t)kr * 64, smem + lds_piece + i * 1024);
-            glds16a(gv[i], smem + AT_TILE + lds_piece + i * 1024);
+            glds16a(rk, kvoff[i], 0, smem + lds_piece + i * 1024);
+            glds16a(rv, vvoff[i], 0, smem + AT_TILE + lds_piece + i * 1024);
             if constexpr (SP) {
-                glds16a(gk[i] + lo_qk + (size_t)kr * 64, smem + 2 * AT_TILE + lds_piece + i * 1024);
-                glds16a(gv[i] + lo_vt, smem + 3 * AT_TILE + lds_piece + i * 1024);
+                glds16a(rkl, kvoff[i], 0, smem + 2 * AT_TILE + lds_piece + i * 1024);
+                glds16a(rvl, vvoff[i], 0, smem + 3 * AT_TILE + lds_piece + i * 1024);
             }
         }
     }
@@ -302,12 +308,11 @@ __global__ __launch_bounds__(256, FMT == FMT_SPLIT ? 2 : (QW == 2 ? 3 : 4)) void
             const int kv1 = (t + 1) * AT_KV;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                int kr = kv1 + krow[i]; kr = kr < Tp ? kr : Tp - 1;
-                glds16a(gk[i] + (size_t)kr * 64, nb + lds_piece + i * 1024);
-                glds16a(gv[i] + kv1, nb + AT_TILE + lds_piece + i * 1024);
+                glds16a(rk, kvoff[i], kv1 * 128, nb + lds_piece + i * 1024);
+                glds16a(rv, vvoff[i], kv1 * 2, nb + AT_TILE + lds_piece + i * 1024);
                 if constexpr (SP) {
-                    glds16a(gk[i] + lo_qk + (size_t)kr * 64, nb + 2 * AT_TILE + lds_piece + i * 1024);
-                    glds16a(gv[i] + lo_vt + kv1, nb + 3 * AT_TILE + lds_piece + i * 1024);
+                    glds16a(rkl, kvoff[i], kv1 * 128, nb + 2 * AT_TILE + lds_piece + i * 1024);
+                    glds16a(rvl, vvoff[i], kv1 * 2, nb + 3 * AT_TILE + lds_piece + i * 1024);
                 }
             }
         }

@@ -298,9 +298,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
 // Hazards: a step's DMA is retired (vmcnt) two program barriers before its first ds_read (one more than
 // usual because the groups are staggered); fragment reads complete (lgkmcnt(0)) before the barrier that
 // lets the other group refill that slot.
-// VAR (K-loop schedule, A/B'd with tools/gemm_bench.py): 0 = the LDS-DMA of step s+3 interleaved with the MFMAs of phase B;
-// 1 = issued at the head of phase A (B is MFMAs only); 2 = at the tail of phase A, behind the fragment reads;
-// 3 = half at the tail of A, half inside B
+// VAR 0 = the shipping schedule (the LDS-DMA of step s+3 interleaved with the MFMAs of phase B: issuing it at the head or the tail
+// of phase A, or half / half, measured 4-10 % slower: profiles/r03_gemm_variants_ab.md); VAR 10 = the same with s_memtime stamps
 template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT, int VAR = 0>
 __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int tile_id, char* smem) {
     // K step 32 (64-byte LDS rows), 4-slot ring: the DMA of step s+3 is issued in step s and retired with
@@ -404,13 +403,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
         // ---- A: fragments of step s, DMA of step s+3, retire step s+1
         const bool dma = s + 3 < nt;
         char* dbase = smem + ((slot + 3) & 3) * STAGE;     // slot of step s-1: every wave left A(s-1) >= two program barriers ago
-        auto dma_pieces = [&](int q0, int q1) {
-#pragma unroll
-            for (int q = q0; q < q1; ++q)
-                if (dma && q < NPW_HI && (q < NPW_LO || hi)) dma1(s + 3, q, dbase);
-        };
         SCHED_FENCE();
-        if constexpr (VAR == 1) { dma_pieces(0, NPW_HI); SCHED_FENCE(); }
 #pragma unroll
         for (int f = 0; f < FM; ++f) {
             xf[0][f] = *(const bf16x8_t*)(sb + xrow_off + f * 32 * RB + koff0);
@@ -421,20 +414,9 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
             wf[0][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff0);
             wf[1][f] = *(const bf16x8_t*)(sb + wrow_off + f * 32 * RB + koff1);
         }
-        if constexpr (VAR == 2) { SCHED_FENCE(); dma_pieces(0, NPW_HI); SCHED_FENCE(); }
-        if constexpr (VAR == 3) { SCHED_FENCE(); dma_pieces(0, NPW_HI / 2); SCHED_FENCE(); }
         {
-            // retire step s+1.  VAR 0: step s+3's DMA is issued in phase B below, so the steps issued after s+1 are at
-            // most {s+2}; VAR 1 / 2: {s+2, s+3} are both in flight here; VAR 3: s+2 and the first half of s+3 (counted
-            // as a whole step: NPW_HI / 2 pieces fewer outstanding than the bound allows -> conservative)
-            const int after2 = (s + 2 < nt ? 1 : 0);
-            const int after3 = (s + 3 < nt ? 1 : 0);
-            if constexpr (VAR == 0 || VAR == 10) wait_steps(after2);
-            else if constexpr (VAR == 3) {
-                if (after3) { if (hi) wait_vmcnt<NPW_HI + NPW_HI / 2>(); else wait_vmcnt<NPW_LO + NPW_HI / 2>(); }
-                else wait_steps(after2);
-            }
-            else wait_steps(after2 + after3);
+            // retire step s+1: step s+3's DMA is issued in phase B below, so the steps issued after s+1 are at most {s+2}
+            wait_steps(s + 2 < nt ? 1 : 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SCHED_FENCE();
@@ -453,15 +435,11 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
             const int kk = i / (FM * FN), fm = (i / FN) % FM, fn = i % FN;
             acc[fm][fn] = H16<FMT>::mfma(wf[kk][fn], xf[kk][fm], acc[fm][fn]);
             // after MFMA number (q+1)*NMF/NPW_HI - 1 issue piece q
-            if constexpr (VAR == 0 || VAR == 3 || VAR == 10) {
-                if ((i + 1) % (NMF / NPW_HI) == 0) {
-                    const int q = (i + 1) / (NMF / NPW_HI) - 1;
-                    if (VAR != 3 || q >= NPW_HI / 2) {
-                        SCHED_FENCE();
-                        if (dma && q < NPW_HI && (q < NPW_LO || hi)) dma1(s + 3, q, dbase);
-                        SCHED_FENCE();
-                    }
-                }
+            if ((i + 1) % (NMF / NPW_HI) == 0) {
+                const int q = (i + 1) / (NMF / NPW_HI) - 1;
+                SCHED_FENCE();
+                if (dma && q < NPW_HI && (q < NPW_LO || hi)) dma1(s + 3, q, dbase);
+                SCHED_FENCE();
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -934,11 +912,6 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
             }
             return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
-        case 20: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 1>(a, s); break;   // K-loop schedule A/B
-        case 21: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 2>(a, s); break;
-        case 22: if constexpr (FMT == FMT_BF16) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 3>(a, s); break;
-        case 50: if constexpr (FMT == FMT_BF16) return launch_cfg<4, 2, 32, 3, 2, false, EPI, ACT, FMT>(a, s); break;       // 256x128, K step 32, 3 slots, 2 WG/CU
-        case 51: if constexpr (FMT == FMT_BF16) return launch_cfg<2, 4, 32, 3, 2, false, EPI, ACT, FMT>(a, s); break;       // 128x256, same
         case 40: if constexpr (FMT == FMT_BF16) return launch_cfg8u<EPI, ACT, FMT>(a, s); break;                     // unstaggered 8-wave 256x256
         case 41: if constexpr (FMT == FMT_BF16 && EPI == EPI_BF16 && ACT == 0) return launch_cfg8u<EPI, ACT, FMT, true>(a, s); break;   // its trace
         case 30: if constexpr (FMT == FMT_BF16 && (EPI == EPI_BF16 || EPI == EPI_F32_RESLN)) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 10>(a, s); break;   // trace

@@ -25,8 +25,9 @@
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* glb_vptr;
-__device__ __forceinline__ void glds16p(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((glb_vptr)g, (lds_vptr)l, 16, 0, 0);
+// LDS-DMA through a buffer descriptor: constant per-lane offset, the weight step in the scalar offset
+__device__ __forceinline__ void glds16p(__amdgpu_buffer_rsrc_t rs, int voff, int soff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)l, 16, voff, soff, 0, 0);
 }
 
 template <int ACT, int FMT>
@@ -65,13 +66,13 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
     }
     // ---- weight ring: a step = 2 taps = 14 KiB = 14 wave-instructions; wave w issues pieces w, w+4, ...
     const char* wg_base = (const char*)(wpk + (pass == 2 ? w_lo : 0L)) + (size_t)g * SYL_POSK * PC_SLAB;
+    const __amdgpu_buffer_rsrc_t rwg = __builtin_amdgcn_make_buffer_rsrc((void*)wg_base, 0, (int)0xffffffffu, 0x00020000);
     auto stage = [&](int step, int buf) {
-        const char* src = wg_base + (size_t)step * PC_STEP;
         char* dst = wring + buf * PC_STEP;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int piece = wave + 4 * i;
-            if (piece < 14) glds16p(src + piece * 1024 + lane * 16, dst + piece * 1024);
+            if (piece < 14) glds16p(rwg, piece * 1024 + lane * 16, step * PC_STEP, dst + piece * 1024);
         }
     };
 
