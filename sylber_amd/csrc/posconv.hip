@@ -7,7 +7,7 @@
 //
 // Per group this is a Toeplitz contraction: out[t][n] = sum_tap sum_c x[t + tap - 64][c] * w[n][c][tap]
 // with 48 channels in / out per group.  Rows t and t+1 share 127/128 of their input, so instead of an
-// im2col GEMM (K = 6144 per row) the workgroup stages ONE window of 255 frames x 48 channels in LDS and
+// im2col GEMM (K = 6144 per row) the workgroup stages ONE window of 383 frames (256 + 127) x 48 channels in LDS and
 // reads the B fragments of all 128 taps from it at shifted row offsets; the per-tap weight slabs
 // (64 n x 48 c, n padded 48->64, rows padded to 112 B so ds_read_b128 is conflict-free) stream through
 // a double-buffered LDS ring with global_load_lds_dwordx4, two taps per barrier.
@@ -15,13 +15,13 @@
 // and stores 16-byte runs.
 #include "kernels.h"
 
-#define PC_BM 128                 // frames per workgroup
+#define PC_BM 256                 // frames per workgroup (8 waves x 32): a weight slab read from L2 serves 256 frames
 #define PC_XROW 112               // bytes per staged x row (48 bf16 + 16 B pad)
-#define PC_XWIN (256 * PC_XROW)   // 28672
+#define PC_XWIN (384 * PC_XROW)   // 43008: the 383-frame window of 256 frames x 128 taps
 #define PC_SLAB (64 * 112)        // bytes of one (group, tap) weight slab: 7168
 #define PC_TAPS_PER_STEP 2
 #define PC_STEP (PC_TAPS_PER_STEP * PC_SLAB)   // 14336
-#define PC_LDS (PC_XWIN + 2 * PC_STEP)         // 57344
+#define PC_LDS (PC_XWIN + 2 * PC_STEP)         // 71680: two workgroups per CU
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* glb_vptr;
@@ -31,7 +31,7 @@ __device__ __forceinline__ void glds16p(__amdgpu_buffer_rsrc_t rs, int voff, int
 }
 
 template <int ACT, int FMT>
-__global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __restrict__ xpad, const bf16_t* __restrict__ wpk,
+__global__ __launch_bounds__(512, 4) void posconv_bf16_kernel(const bf16_t* __restrict__ xpad, const bf16_t* __restrict__ wpk,
                                                               const float* __restrict__ bias, const float* __restrict__ x_f32,
                                                               float* __restrict__ out, int Tp, long x_lo, long w_lo) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
@@ -52,26 +52,28 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16_t* __re
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
     if (pass > 0) __syncthreads();                     // the previous pass's window and ring reads are done
-    // ---- stage the x window: rows t0 .. t0+254 of xpad[b], channels g*48 .. +47
+    // ---- stage the x window: rows t0 .. t0+382 of xpad[b], channels g*48 .. +47
     {
         const bf16_t* xb = xpad + (pass == 1 ? x_lo : 0L) + (size_t)b * rows_per_b * SYL_HIDDEN + g * SYL_POSC;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int idx = tid + 256 * i;         // 1536 16-B chunks
-            const int r = idx / 6, ch = idx - r * 6;
-            int row = t0 + r; row = row < rows_per_b ? row : rows_per_b - 1;
-            const uint4 v = *(const uint4*)(xb + (size_t)row * SYL_HIDDEN + ch * 8);
-            *(uint4*)(xwin + r * PC_XROW + ch * 16) = v;
+        for (int i = 0; i < 5; ++i) {
+            const int idx = tid + 512 * i;         // 384 rows x 6 16-byte chunks = 2304 (4.5 per thread)
+            if (idx < 384 * 6) {
+                const int r = idx / 6, ch = idx - r * 6;
+                int row = t0 + r; row = row < rows_per_b ? row : rows_per_b - 1;
+                const uint4 v = *(const uint4*)(xb + (size_t)row * SYL_HIDDEN + ch * 8);
+                *(uint4*)(xwin + r * PC_XROW + ch * 16) = v;
+            }
         }
     }
-    // ---- weight ring: a step = 2 taps = 14 KiB = 14 wave-instructions; wave w issues pieces w, w+4, ...
+    // ---- weight ring: a step = 2 taps = 14 KiB = 14 wave-instructions; wave w issues pieces w and w + 8
     const char* wg_base = (const char*)(wpk + (pass == 2 ? w_lo : 0L)) + (size_t)g * SYL_POSK * PC_SLAB;
     const __amdgpu_buffer_rsrc_t rwg = __builtin_amdgcn_make_buffer_rsrc((void*)wg_base, 0, (int)0xffffffffu, 0x00020000);
     auto stage = [&](int step, int buf) {
         char* dst = wring + buf * PC_STEP;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave + 4 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave + 8 * i;
             if (piece < 14) glds16p(rwg, piece * 1024 + lane * 16, step * PC_STEP, dst + piece * 1024);
         }
     };
@@ -135,14 +137,14 @@ int launch_posconv(const bf16_t* xpad, const bf16_t* wpk, const float* bias, con
         HIP_TRY(hipFuncSetAttribute((const void*)posconv_bf16_kernel<2, FMT_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS));
     }
     if (fmt == FMT_SPLIT) {
-        hipLaunchKernelGGL((posconv_bf16_kernel<2, FMT_SPLIT>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, x_lo, w_lo);
+        hipLaunchKernelGGL((posconv_bf16_kernel<2, FMT_SPLIT>), grid, dim3(512), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, x_lo, w_lo);
         HIP_TRY(hipGetLastError());
         return 0;
     }
     if (fmt == FMT_F16 && act == 2) { syl_set_error("launch_posconv", "the erf GELU (act 2) has no fp16 instantiation"); return 1; }
-    if (fmt == FMT_F16) hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_F16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, 0L, 0L);
-    else if (act == 2) hipLaunchKernelGGL((posconv_bf16_kernel<2, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, 0L, 0L);
-    else hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_BF16>), grid, dim3(256), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, 0L, 0L);
+    if (fmt == FMT_F16) hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_F16>), grid, dim3(512), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, 0L, 0L);
+    else if (act == 2) hipLaunchKernelGGL((posconv_bf16_kernel<2, FMT_BF16>), grid, dim3(512), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, 0L, 0L);
+    else hipLaunchKernelGGL((posconv_bf16_kernel<1, FMT_BF16>), grid, dim3(512), PC_LDS, s, xpad, wpk, bias, x_f32, out, Tp, 0L, 0L);
     HIP_TRY(hipGetLastError());
     return 0;
 }
