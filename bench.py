@@ -543,7 +543,7 @@ def main():
             rows0 = enc.padded_frames(clip_samples) * 64       # R_0 = Tp * 2^6 rows per utterance
             fe_bytes = B * (rows0 * 512 * 2 + clip_samples * 4)
             fe_gbs = fe_bytes / (kernels["conv0_gn_gelu"] * 1e-3) / 1e9
-            frontend = {"bound": "hbm", "kernel": "conv0_gn_gelu_kernel (Conv1d(1->512,k10,s5) + GroupNorm + GELU, bf16 channels-last out)",
+            frontend = {"bound": "hbm", "kernel": "conv0_mfma_kernel (Conv1d(1->512,k10,s5) taps on the matrix pipe + GroupNorm + GELU, 16-bit channels-last out)",
                         "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fe_gbs / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": fe_bytes}
 

@@ -11,6 +11,8 @@
 //    channels-last bf16 rows of 1 KiB (one wave stores one row: fully coalesced).
 //  * LayerNorm(512/768) rows (TP:225-231, 441, 392-397): one wave per row, values held in registers,
 //    two-pass mean/variance, fp32 and/or bf16 outputs (the bf16 copy feeds the next MFMA GEMM).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 #define NSTAT 65  // 10 sums + 55 upper-triangular lag products
@@ -169,6 +171,119 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same layer with the ten taps on the MATRIX pipe (16-bit modes).  The VALU kernel above spends
+// 10 FMA + ~12 GELU instructions per value and is VALU-bound at half the store bandwidth; here the taps are one
+// [32 channels x 16] . [16 x 32 rows] MFMA block (K = 10 padded to 16, the pad rows of the weight operand are zero), so
+// only the GELU stays on the VALU.  Accuracy: the waveform window AND the (GroupNorm-scaled) tap weights enter as IEEE-half
+// hi / lo pairs, three v_mfma_f32_32x32x16_f16 per block (hi.hi + lo.hi + hi.lo, fp32 accumulate): 2^-22-grade products,
+// i.e. the fp32 FMA chain of the VALU kernel up to ~1e-6 relative -- far inside the 16-bit output rounding.  The
+// GroupNorm shift is the accumulator's initial value, the scale is folded into the weights once per (utterance, channel).
+// Orientation "lane = output row": A = weights (rows = channels), B = waveform windows (columns = rows l), so a lane's 16
+// results per block are runs of 4 consecutive channels of its row; four blocks (128 channels) are transposed through a
+// per-wave LDS region and leave as 16-byte chunks, consecutive lanes on consecutive chunks of a row (whole 128-byte lines).
+#define C0M_WFR (16 * 64 * 32)                    // weight fragments: [16 blocks][64 lanes][hi 16 B | lo 16 B] = 32 KiB
+#define C0M_STG (32 * (256 + 16))                 // per-wave staging: 32 rows x 128 channels (+ 16 B pad): 8704 B
+#define C0M_LDS (C0M_WFR + 512 * 4 + (C0_ROWS * 5 + 16) * 4 + 4 * C0M_STG)
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restrict__ wav, int Lmax, int L0, int R0,
+                                                            const float* __restrict__ w0, const float* __restrict__ scale_shift,
+                                                            bf16_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    char* wfr = smem;
+    float* shf = (float*)(smem + C0M_WFR);
+    float* xs = shf + 512;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    char* stg = smem + C0M_WFR + 512 * 4 + (C0_ROWS * 5 + 16) * 4 + wave * C0M_STG;
+    const float* x = wav + (size_t)b * Lmax;
+    // weight fragments of this utterance: entry (blk, ln): channel c = 32 blk + (ln & 31), taps k = 8 (ln >> 5) .. + 7
+    for (int e = tid; e < 16 * 64; e += 256) {
+        const int blk = e >> 6, ln = e & 63;
+        const int c = 32 * blk + (ln & 31), k0 = 8 * (ln >> 5);
+        const float sa = scale_shift[((size_t)b * SYL_CONV + c) * 2 + 0];
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ka = k0 + 2 * j, kb = ka + 1;
+            const float wa = ka < 10 ? w0[c * 10 + ka] * sa : 0.f, wb = kb < 10 ? w0[c * 10 + kb] * sa : 0.f;
+            hi[j] = H16<FMT_SPLIT>::pack2(wa, wb);
+            lo[j] = H16<FMT_SPLIT>::pack2_lo(wa, wb, hi[j]);
+        }
+        *(uint4*)(wfr + e * 32) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *(uint4*)(wfr + e * 32 + 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    for (int c = tid; c < 512; c += 256) shf[c] = scale_shift[((size_t)b * SYL_CONV + c) * 2 + 1];
+    const int ml = lane & 31, h = lane >> 5;
+    // a workgroup walks row blocks blockIdx.x, blockIdx.x + gridDim.x, ... of ITS utterance: the weight fragments are built
+    // once, and the launch holds ~2 workgroups per CU instead of 16 waves of short-lived ones (stores from few, long-lived
+    // workgroups reach a higher write bandwidth on this part: tools/ubench/hbm_bw.hip; measured in launch_conv0_gn_gelu)
+    const int nblk = (R0 + C0_ROWS - 1) / C0_ROWS;
+#pragma unroll 1
+    for (int bx = blockIdx.x; bx < nblk; bx += gridDim.x) {
+    const int l_blk = bx * C0_ROWS;
+    __syncthreads();                                   // the previous block's window has been consumed
+    for (int i = tid; i < C0_ROWS * 5 + 16; i += 256) {
+        const int idx = 5 * l_blk + i;
+        xs[i] = idx < Lmax ? x[idx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int rb = 0; rb < 2; ++rb) {
+        const int lrow0 = wave * 64 + rb * 32;           // first row of this 32-row block inside the workgroup's 256
+        const int l0 = l_blk + lrow0;
+        if (l0 >= R0) break;
+        // B operand: lane (row ml, half h) holds the window samples x[5 l + 8 h .. + 7] as half hi / lo pairs
+        f16x8_t xh, xl;
+        {
+            const float* xr = xs + 5 * (lrow0 + ml) + 8 * h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = xr[j];
+                const _Float16 vh = (_Float16)v;
+                xh[j] = vh; xl[j] = (_Float16)(v - (float)vh);
+            }
+        }
+        const bool live = l0 + ml < L0;                  // rows in [L0, R0) are written as zeros
+#pragma unroll 1
+        for (int q4 = 0; q4 < 4; ++q4) {                 // 128 channels = 4 blocks per staging round
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) {
+                const int blk = q4 * 4 + bi;
+                const f16x8_t whi = *(const f16x8_t*)(wfr + (blk * 64 + lane) * 32);
+                const f16x8_t wlo = *(const f16x8_t*)(wfr + (blk * 64 + lane) * 32 + 16);
+                f32x16_t acc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 sv = *(const float4*)(shf + 32 * blk + 8 * g + 4 * h);
+                    acc[4 * g + 0] = sv.x; acc[4 * g + 1] = sv.y; acc[4 * g + 2] = sv.z; acc[4 * g + 3] = sv.w;
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh, acc, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float y0 = gelu_fast(acc[4 * g + 0]), y1 = gelu_fast(acc[4 * g + 1]), y2 = gelu_fast(acc[4 * g + 2]), y3 = gelu_fast(acc[4 * g + 3]);
+                    if (!live) { y0 = y1 = y2 = y3 = 0.f; }
+                    uint2 pk; pk.x = H16<FMT>::pack2(y0, y1); pk.y = H16<FMT>::pack2(y2, y3);
+                    *(uint2*)(stg + ml * (256 + 16) + (32 * bi + 8 * g + 4 * h) * 2) = pk;
+                }
+            }
+            // out: 32 rows x 256 B; 16 chunks of 16 B per row, consecutive lanes on consecutive chunks
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * 64 + lane;
+                const int r = idx >> 4, ch = idx & 15;
+                typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t v = *(const u32x4_t*)(stg + r * (256 + 16) + ch * 16);
+                const int l = l0 + r;
+                if (l < R0) __builtin_nontemporal_store(v, (u32x4_t*)(out + ((size_t)b * R0 + l) * SYL_CONV + q4 * 128 + ch * 8));
+            }
+        }
+    }
+    }
+}
+
 int launch_conv0_stats(const float* wav, int B, int Lmax, int L0, double* partials, int nchunk, hipStream_t s) {
     const int chunk = (L0 + nchunk - 1) / nchunk;
     hipLaunchKernelGGL(conv0_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, wav, Lmax, L0, chunk, partials, nchunk);
@@ -188,10 +303,21 @@ int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, cons
         hipLaunchKernelGGL((conv0_gn_gelu_kernel<true, true, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
     else if (fmt == FMT_SPLIT)      // erf GELU in the reference's order (conv, then scale and shift), two half planes out
         hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, true, FMT_SPLIT>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, out_lo);
-    else if (fmt == FMT_F16)
-        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_F16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
-    else
-        hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
+    else if (fmt == FMT_F16 || fmt == FMT_BF16) {
+        // 16-bit modes: the taps on the matrix pipe (conv0_mfma_kernel).  Same-box A/B (32 x 10 s): VALU kernel 0.260 ms,
+        // this one 0.254 (4096 short-lived workgroups) / 0.244 (1024 row-block walkers) / 0.254 (512) / 0.395 (256): with the
+        // taps off the VALU the kernel sits at 4.4 TB/s of stores, the write ceiling of this part (tools/ubench/hbm_bw.hip)
+        static PerDeviceOnce once;
+        if (once.need()) {
+            HIP_TRY(hipFuncSetAttribute((const void*)conv0_mfma_kernel<FMT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, C0M_LDS));
+            HIP_TRY(hipFuncSetAttribute((const void*)conv0_mfma_kernel<FMT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, C0M_LDS));
+        }
+        int gx = (1024 + B - 1) / B;                  // ~1024 workgroups however long the batch: gx row-block walkers per utterance
+        gx = gx < 1 ? 1 : (gx > (int)grid.x ? (int)grid.x : gx);
+        const dim3 pgrid(gx, B);
+        if (fmt == FMT_F16) hipLaunchKernelGGL((conv0_mfma_kernel<FMT_F16>), pgrid, dim3(256), C0M_LDS, s, wav, Lmax, L0, R0, w0, scale_shift, (bf16_t*)out);
+        else hipLaunchKernelGGL((conv0_mfma_kernel<FMT_BF16>), pgrid, dim3(256), C0M_LDS, s, wav, Lmax, L0, R0, w0, scale_shift, (bf16_t*)out);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
