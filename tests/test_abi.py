@@ -83,5 +83,6 @@ def test_no_packed_fp32_valu_in_the_library(lib):
     import check_isa
     from sylber_amd import _lib
     text = check_isa.device_disassembly(_lib.LIB_PATH)                  # raises unless it really is the library's ISA
-    assert len(re.findall(r"\bv_mfma_", text)) > 1000 and len(re.findall(r"\bglobal_load_lds_dwordx4\b", text)) > 1000
+    n_dma = len(re.findall(r"\bbuffer_load_dwordx4\b[^\n]*\blds\b", text)) + len(re.findall(r"\bglobal_load_lds_dwordx4\b", text))
+    assert len(re.findall(r"\bv_mfma_", text)) > 1000 and n_dma > 1000          # LDS-DMA staging (buffer descriptors since round 3)
     assert check_isa.banned_instructions(_lib.LIB_PATH) == {}
