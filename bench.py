@@ -70,6 +70,7 @@ def parse_args():
                          "and crosses that GPU's own PCIe link every step (SURVEY.md §8(e)), gather unchanged")
     ap.add_argument("--fuse-ln", choices=["auto", "on", "off"], default="auto",
                     help="attention out-projection + LayerNorm as one launch (SYLBER_OPT_FUSE_OUTPROJ_LN); A/B switch")
+    ap.add_argument("--conv0-valu", action="store_true", help="conv layer 0 on the VALU kernel (SYLBER_OPT_CONV0_VALU); A/B switch")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
     ap.add_argument("--agreement-clips", type=int, default=0,
                     help="also report bf16-vs-fp32 segment agreement on this many synthetic clips (fp32 parity mode as truth)")
@@ -234,6 +235,9 @@ def main():
     if args.graph:
         for e_ in encs:
             e_.set_graph_mode(True)
+    if args.conv0_valu:
+        for e_ in encs:
+            e_.set_option(5, 1)
     if args.fuse_ln != "auto":
         for e_ in encs:
             e_.set_option(4, 1 if args.fuse_ln == "on" else -1)
@@ -500,7 +504,7 @@ def main():
             1 for k in ("gemm_qkv", "gemm_qk", "gemm_v", "gemm_out", "gemm_ffn1", "gemm_ffn2") if k in kernels)
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_note = None, "no PMC pass committed for these kernel sources"
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
         if os.path.exists(tpath) and B == BATCH_PER_GPU and clip_samples == CLIP_SAMPLES and args.precision == "bf16":
             # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 +
             # WRITE_SIZE, separate passes; tools/pmc_traffic.py).  PMC cannot be read live, so the figure is only
@@ -508,9 +512,9 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("csrc_sha16") == csrc_sha16():
                 traffic = round(tj["gemm_family_bytes_per_launch"])
-                traffic_note = "HBM bytes per launch, rocprofv3 PMC (profiles/r02_hbm_traffic.md), same kernel sources"
+                traffic_note = "HBM bytes per launch, rocprofv3 PMC (profiles/r03_hbm_traffic.md), same kernel sources"
             else:
-                traffic_note = "profiles/r02_hbm_traffic.json was collected with other kernel sources (csrc sha %s != %s)" % (
+                traffic_note = "profiles/r03_hbm_traffic.json was collected with other kernel sources (csrc sha %s != %s)" % (
                     tj.get("csrc_sha16"), csrc_sha16())
         roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (all %d launches per forward: 6 implicit-GEMM convs, "
                     "projection, 9 x {qkv, out, ffn1, ffn2})" % n_launch,

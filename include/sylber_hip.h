@@ -167,10 +167,12 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      walking the tile list (4-wave kernels: two per CU; the 256x256 kernel: one per CU
  *                                      with cross-tile operand prefetch); k > 0: k workgroups per CU for the 4-wave
  *                                      kernels; k < 0: one workgroup per tile everywhere (A/B switch)
- *   SYLBER_OPT_FUSE_OUTPROJ_LN         0 (automatic): the attention out-projection and the LayerNorm behind it run as ONE
- *                                      launch (full-row tiles, csrc/gemm_rowln.hip) when the batch fills the chip;
- *                                      1: always where the shape allows; -1: never (GEMM + LayerNorm launches, A/B switch) */
-enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3, SYLBER_OPT_FUSE_OUTPROJ_LN = 4 };
+ *   SYLBER_OPT_FUSE_OUTPROJ_LN         1: the attention out-projection and the LayerNorm behind it run as ONE launch on
+ *                                      full-row tiles (csrc/gemm_rowln.hip; bit-identical outputs) where the shape allows;
+ *                                      0 / -1 (default): GEMM launch + LayerNorm launch (faster with two batches in flight)
+ *   SYLBER_OPT_CONV0_VALU              1: conv layer 0 of the 16-bit modes on the VALU kernel instead of the matrix-pipe one (A/B switch) */
+enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3, SYLBER_OPT_FUSE_OUTPROJ_LN = 4,
+       SYLBER_OPT_CONV0_VALU = 5 };
 int sylber_set_option(sylber_t h, int32_t key, int32_t value);
 
 /* the `features is not None` branch of resynthesize (segment_synthesis.py:135-140): features_dev [rows, input_dim] frame

@@ -86,6 +86,7 @@ struct sylber_ctx {
     int stop_stage = 0;
     int opt_gemm_cfg = 0, opt_attn_qw = 0, opt_gemm_persist = 0;   // sylber_set_option (0 = automatic)
     int opt_fuse_ln = 0;                                           // out-projection + LayerNorm in one launch: 0 auto, 1 always, -1 never
+    int opt_conv0_valu = 0;                                        // 1: conv0 of the 16-bit modes on the VALU kernel (A/B switch)
     bool graph_mode = false;
     std::vector<GraphEntry> graphs; unsigned long long graph_clock = 0;
     // profiling
@@ -271,6 +272,7 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
         case SYLBER_OPT_ATTN_QUERIES_PER_WAVE: c->opt_attn_qw = value == 32 ? 1 : (value == 64 ? 2 : 0); break;
         case SYLBER_OPT_GEMM_PERSISTENT: c->opt_gemm_persist = value; break;      // < 0: also keep the 256x256 kernel one tile per workgroup
         case SYLBER_OPT_FUSE_OUTPROJ_LN: c->opt_fuse_ln = value > 0 ? 1 : (value < 0 ? -1 : 0); break;
+        case SYLBER_OPT_CONV0_VALU: c->opt_conv0_valu = value > 0 ? 1 : 0; break;
         default: syl_set_error("sylber_set_option", "unknown option key"); return 1;
     }
     if (c->graph_mode) { for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec); c->graphs.clear(); }   // captured launches are stale
@@ -459,7 +461,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     RUN("conv0_stats", launch_conv0_stats(wav_dev, B, Lmax, p.L[0], part, p.nchunk, s));
     RUN("conv0_finalize", launch_conv0_finalize(part, p.nchunk, c->conv0_w, c->gn_w, c->gn_b, B, p.L[0], ss, s));
     const bool split = c->precision == SYLBER_SPLIT16;      // hi / lo half planes, erf GELU (fp32-grade decisions)
-    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s, c->fmt_conv, p.lo_bufA));
+    RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s, c->fmt_conv, p.lo_bufA, c->opt_conv0_valu));
     // ---- conv layers 1..6 as implicit GEMM (ping-pong)
     bf16_t* src = bufA; bf16_t* dst = bufB;
     long src_lo = p.lo_bufA, dst_lo = p.lo_bufB;

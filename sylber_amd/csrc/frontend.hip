@@ -297,13 +297,16 @@ int launch_conv0_finalize(const double* partials, int nchunk, const float* w0, c
     return 0;
 }
 int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, const float* w0, const float* scale_shift,
-                         void* out, int out_f32, hipStream_t s, int fmt, long out_lo) {
+                         void* out, int out_f32, hipStream_t s, int fmt, long out_lo, int valu16) {
     dim3 grid((R0 + C0_ROWS - 1) / C0_ROWS, B);
     if (out_f32)
         hipLaunchKernelGGL((conv0_gn_gelu_kernel<true, true, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
     else if (fmt == FMT_SPLIT)      // erf GELU in the reference's order (conv, then scale and shift), two half planes out
         hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, true, FMT_SPLIT>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, out_lo);
-    else if (fmt == FMT_F16 || fmt == FMT_BF16) {
+    else if ((fmt == FMT_F16 || fmt == FMT_BF16) && valu16) {
+        if (fmt == FMT_F16) hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_F16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
+        else hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
+    } else if (fmt == FMT_F16 || fmt == FMT_BF16) {
         // 16-bit modes: the taps on the matrix pipe (conv0_mfma_kernel).  Same-box A/B (32 x 10 s): VALU kernel 0.260 ms,
         // this one 0.254 (4096 short-lived workgroups) / 0.244 (1024 row-block walkers) / 0.254 (512) / 0.395 (256): with the
         // taps off the VALU the kernel sits at 4.4 TB/s of stores, the write ceiling of this part (tools/ubench/hbm_bw.hip)

@@ -90,7 +90,7 @@ int launch_conv0_finalize(const double* partials, int nchunk, const float* w0, c
 // out: [B][R0][512] (bf16 or f32); rows l >= L0 are written as zeros
 // fmt FMT_SPLIT: erf GELU, hi halves at out, lo halves at out + out_lo (element offset)
 int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, const float* w0,
-                         const float* scale_shift, void* out, int out_f32, hipStream_t s, int fmt = 0, long out_lo = 0);
+                         const float* scale_shift, void* out, int out_f32, hipStream_t s, int fmt = 0, long out_lo = 0, int valu16 = 0);   // valu16: 16-bit modes on the VALU kernel (A/B)
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (512 or 768), eps 1e-5, one wave per row

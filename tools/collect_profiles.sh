@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): the bench lines, rocprofv3 kernel traces and PMC passes that profiles/ is built
 # from.  Everything lands in gpurun_out/; tools/rocprof_summary.py / tools/pmc_traffic.py turn it into profiles/.
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'      then, here:  bash tools/publish_profiles.sh r02
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'      then, here:  bash tools/publish_profiles.sh r03
 # The PMC passes run AFTER the bench lines, so the bench lines of this call cannot carry `roofline.traffic` yet: commit the
 # published profiles/rNN_hbm_traffic.json and run `python bench.py --agreement-clips 256` once more for the headline line.
 set -u
@@ -12,6 +12,7 @@ python bench.py --agreement-clips 256 > $OUT/bench_bf16.json 2> $OUT/bench_bf16.
 python bench.py --precision fp16 --no-cpu-baseline --agreement-clips 256 > $OUT/bench_fp16.json 2> $OUT/bench_fp16.err
 python bench.py --precision fp8 --no-cpu-baseline --no-api > $OUT/bench_fp8.json 2> $OUT/bench_fp8.err
 python bench.py --precision fp32 --no-cpu-baseline --no-api --steps 5 --warmup 1 --inflight 1 > $OUT/bench_fp32.json 2> $OUT/bench_fp32.err
+python bench.py --precision split16 --no-cpu-baseline --no-api --steps 10 --warmup 2 --agreement-clips 256 > $OUT/bench_split16.json 2> $OUT/bench_split16.err
 python bench.py --batch 8 --clip-seconds 60 --no-cpu-baseline --no-api > $OUT/bench_longform.json 2> $OUT/bench_longform.err
 python bench.py --no-overlap --no-cpu-baseline --no-api > $OUT/bench_sequential.json 2> $OUT/bench_sequential.err
 python bench.py --ragged --no-cpu-baseline --no-api > $OUT/bench_ragged.json 2> $OUT/bench_ragged.err
