@@ -24,8 +24,15 @@ typedef __attribute__((address_space(3))) void* lds_vptr8;
 typedef const __attribute__((address_space(1))) void* glb_vptr8;
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void glds16b(const void* g, void* l) {
+__device__ __forceinline__ void glds16g(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((glb_vptr8)g, (lds_vptr8)l, 16, 0, 0);
+}
+// the buffer-descriptor form (see gemm_bf16.hip): constant per-lane offset, the K step in the scalar offset
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t f8_make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ void f8_glds16b(__amdgpu_buffer_rsrc_t rs, int voff, int soff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr8)l, 16, voff, soff, 0, 0);
 }
 #define F8_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -128,22 +135,26 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const GemmF8Args a) 
 
     // ---- staging (identical byte geometry to the bf16 kernel's 128-byte rows)
     const int srow = lane >> 3, spos = lane & 7;
-    const uint8_t* gp[NPW];
+    static_assert((BM / 8) % 4 == 0, "X pieces must split evenly over the 4 waves");
+    constexpr int XPW = BM / 8 / 4;
+    const __amdgpu_buffer_rsrc_t rx = f8_make_rsrc(a.X8 + (size_t)m0 * a.ldx8), rw = f8_make_rsrc(a.W8 + (size_t)n0 * K);
+    int voff[NPW];
     int lds_off[NPW];
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         const int p = wave + 4 * i;
-        const bool isx = p < BM / 8;
+        const bool isx = i < XPW;
         const int r = (isx ? p : p - BM / 8) * 8 + srow;
         const int c = spos ^ ((r >> 1) & 7);
-        if (isx) { int xm = m0 + r; xm = xm < M ? xm : M - 1; gp[i] = a.X8 + (size_t)xm * a.ldx8 + c * 16; }
-        else { int wr = n0 + r; wr = wr < N ? wr : N - 1; gp[i] = a.W8 + (size_t)wr * K + c * 16; }
+        if (isx) { int xm = m0 + r; xm = xm < M ? xm : M - 1; voff[i] = (int)((long)(xm - m0) * a.ldx8 + c * 16); }
+        else { int wr = n0 + r; wr = wr < N ? wr : N - 1; voff[i] = (wr - n0) * K + c * 16; }
         lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / 8) * 1024;
     }
+    auto dma1 = [&](int kt, int i, char* base) { f8_glds16b(i < XPW ? rx : rw, voff[i], kt * RB, base + lds_off[i]); };
     auto stage = [&](int kt, int slot) {
         char* base = smem + slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) glds16b(gp[i] + (size_t)kt * RB, base + lds_off[i]);
+        for (int i = 0; i < NPW; ++i) dma1(kt, i, base);
     };
 
     // ---- fragment addresses: MFMA j of a stage reads 16-byte chunks 4j + h and 4j + 2 + h of its row
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_kernel(const GemmF8Args a) 
             for (int p = 0; p < NPW; ++p) {
                 if (((p + 1) * NMT + NPW - 1) / NPW - 1 == i) {
                     F8_FENCE();
-                    if (refill) glds16b(gp[p] + (size_t)(t + 2) * RB, dbase + lds_off[p]);
+                    if (refill) dma1(t + 2, p, dbase);
                     F8_FENCE();
                 }
             }
@@ -288,32 +299,44 @@ __global__ __launch_bounds__(512, 2) void gemm8_mxfp8_kernel(const GemmF8Args a)
     const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
 
     const int srow = lane >> 2, spos = lane & 3;
-    const uint8_t* gp[NPW_HI];
-    long gstep[NPW_HI];                              // bytes per K step of that piece's source
+    // operand pieces go through buffer descriptors (one per operand, based at the tile's first row): the per-lane
+    // offset is a constant 32-bit VGPR and the K step rides in the scalar offset, so a step costs no address VALU.
+    // The scale piece keeps the flat form: its two lane halves read two different arrays.
+    static_assert((BM / 16) % 8 == 0, "X pieces must split evenly over the 8 waves");
+    constexpr int XPW = BM / 16 / 8;                 // pieces wave + 8 i with i < XPW are X rows for every wave
+    const __amdgpu_buffer_rsrc_t rx = f8_make_rsrc(a.X8 + (size_t)m0 * a.ldx8), rw = f8_make_rsrc(a.W8 + (size_t)n0 * K);
+    int voff[NPW_HI];
     int lds_off[NPW_HI];
+    const uint8_t* gsc;                              // scale piece source of this lane and its bytes per K step
+    long gsc_step;
+    if (lane < 32) { long r = m0 + 8 * lane; r = r + 8 <= a.xs_rows ? r : a.xs_rows - 8; gsc = a.XS + r * 2; gsc_step = a.xs_rows * 2; }
+    else { long r = n0 + 8 * (lane - 32); r = r + 8 <= a.ws_rows ? r : a.ws_rows - 8; gsc = a.WS + r * 2; gsc_step = a.ws_rows * 2; }
+    bool is_sc[NPW_HI];
 #pragma unroll
     for (int i = 0; i < NPW_HI; ++i) {
         int p = wave + 8 * i;
         p = p < NP ? p : NP - 1;
-        if (p == NPT) {                              // the scale piece
-            if (lane < 32) { long r = m0 + 8 * lane; r = r + 8 <= a.xs_rows ? r : a.xs_rows - 8; gp[i] = a.XS + r * 2; gstep[i] = a.xs_rows * 2; }
-            else { long r = n0 + 8 * (lane - 32); r = r + 8 <= a.ws_rows ? r : a.ws_rows - 8; gp[i] = a.WS + r * 2; gstep[i] = a.ws_rows * 2; }
-            lds_off[i] = XT + WT;
-        } else {
-            const bool isx = p < BM / 16;
+        is_sc[i] = p == NPT;
+        if (p == NPT) { voff[i] = 0; lds_off[i] = XT + WT; }
+        else {
+            const bool isx = i < XPW;
             const int r = (isx ? p : p - BM / 16) * 16 + srow;
             const int c = spos ^ ((r >> 2) & 3);
-            if (isx) { int xm = m0 + r; xm = xm < M ? xm : M - 1; gp[i] = a.X8 + (size_t)xm * a.ldx8 + c * 16; }
-            else { int wr = n0 + r; wr = wr < N ? wr : N - 1; gp[i] = a.W8 + (size_t)wr * K + c * 16; }
-            gstep[i] = RB;
+            if (isx) { int xm = m0 + r; xm = xm < M ? xm : M - 1; voff[i] = (int)((long)(xm - m0) * a.ldx8 + c * 16); }
+            else { int wr = n0 + r; wr = wr < N ? wr : N - 1; voff[i] = (wr - n0) * K + c * 16; }
             lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / 16) * 1024;
         }
     }
+    auto dma1 = [&](int ks, int i, char* base) {
+        // only the last piece slot of a wave can be the scale piece (wave-uniform)
+        if (i == NPW_HI - 1 && is_sc[i]) glds16g(gsc + (size_t)ks * gsc_step, base + lds_off[i]);
+        else f8_glds16b(i < XPW ? rx : rw, voff[i], ks * RB, base + lds_off[i]);
+    };
     auto stage = [&](int ks, int slot) {
         char* base = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < NPW_HI; ++i)
-            if (i < NPW_LO || hi) glds16b(gp[i] + (size_t)ks * gstep[i], base + lds_off[i]);
+            if (i < NPW_LO || hi) dma1(ks, i, base);
     };
     auto wait_steps = [&](int nsteps_in_flight) {
         if (hi) {
@@ -389,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_mxfp8_kernel(const GemmF8Args a)
             for (int q = 0; q < NPW_HI; ++q) {
                 if (((q + 1) * NMF + NPW_HI - 1) / NPW_HI - 1 == i) {
                     F8_FENCE();
-                    if (dma && (q < NPW_LO || hi)) glds16b(gp[q] + (size_t)(s + 3) * gstep[q], dbase + lds_off[q]);
+                    if (dma && (q < NPW_LO || hi)) dma1(s + 3, q, dbase);
                     F8_FENCE();
                 }
             }
