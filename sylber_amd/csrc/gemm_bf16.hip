@@ -912,6 +912,7 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
             }
             return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
+        case 60: if (gemm_asm_applicable(EPI, a)) return launch_gemm_asm(EPI, a, s); break;                         // hand-scheduled K loop
         case 40: if constexpr (FMT == FMT_BF16) return launch_cfg8u<EPI, ACT, FMT>(a, s); break;                     // unstaggered 8-wave 256x256
         case 41: if constexpr (FMT == FMT_BF16 && EPI == EPI_BF16 && ACT == 0) return launch_cfg8u<EPI, ACT, FMT, true>(a, s); break;   // its trace
         case 30: if constexpr (FMT == FMT_BF16 && (EPI == EPI_BF16 || EPI == EPI_F32_RESLN)) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 10>(a, s); break;   // trace

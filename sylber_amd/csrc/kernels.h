@@ -50,6 +50,9 @@ int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
 // residual GEMM + the LayerNorm that follows it in one launch (gemm_rowln.hip): N = 768, full rows per workgroup
 bool gemm_rowln_applicable(const GemmArgs& a);
 int launch_gemm_rowln(const GemmArgs& a, hipStream_t s);
+// 256x256 tile, four waves x 128x128, K loop scheduled by hand (gemm_asm.hip, tile id 60)
+bool gemm_asm_applicable(int epi, const GemmArgs& a);
+int launch_gemm_asm(int epi, const GemmArgs& a, hipStream_t s);
 
 // MXFP8 GEMM (gemm_mxfp8.hip): e4m3 operands [rows][K] with one E8M0 scale per 32 elements along K stored
 // K-pair-major [K/64][rows_pitch][2] (common.h mx_scale_index; pitches are multiples of 8, and the scale arrays of
