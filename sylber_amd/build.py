@@ -47,7 +47,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + COMMON + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = EXTRA.get(src, []) + (["-DSYLBER_GEMM_ASM_EXPERIMENTS"] if os.environ.get("SYLBER_EXPERIMENTS") else [])   # timing-only kernels
+        cmd = [hipcc] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -45,41 +45,74 @@ def reads(Q, slot):
     return out
 
 
+# knock-out switches for timing experiments (results are wrong with any of them off): see VARIANTS
+OPT = {"dma": True, "barrier": True, "reads": True, "vmwait": True, "cpol": "", "spread": False, "freeze": False, "ndma": 8, "dmaop": "buffer_load_dwordx4"}
+
+
 def step(sm, dma, vmcnt, nxt):
     """K step with (s mod 4) = sm. dma: issue step s+3; vmcnt: None = no barrier; nxt: read step s+1's fragments"""
+    dma = dma and OPT["dma"]
+    nxt = nxt and OPT["reads"]
     P, Q = sm & 1, (sm & 1) ^ 1
     slot_r, slot_d = (sm + 1) & 3, (sm + 3) & 3
     L = [q(f"; ---- step {sm}: set {P}, dma {int(dma)}, vmcnt {vmcnt}"), q("s_waitcnt lgkmcnt(8)")]
     m = [mfma(P, kk, fm, fn) for kk in range(2) for fm in range(FM) for fn in range(FN)]
     rd = reads(Q, slot_r) if nxt else []
+    # after[i] = instructions that follow MFMA i
+    after = [[] for _ in range(32)]
+    if dma:
+        for piece in range(OPT["ndma"]):
+            rs = "rx" if piece < 4 else "rw"
+            i0 = 4 * piece if OPT["spread"] else 2 * piece          # spread: one piece per four MFMAs over the whole step
+            after[i0].append(q(f"s_add_u32 m0, %[lbase], {slot_d * SLOT + piece * 4096}"))
+            after[i0 + 1].append(q(f"{OPT['dmaop']} %[vo{piece}], %[{rs}], %[koff] offen{OPT['cpol']} lds"))
+        if not OPT["freeze"]:
+            after[31 if OPT["spread"] else 15].append(q("s_add_u32 %[koff], %[koff], 64"))
+    if vmcnt is not None:
+        if OPT["vmwait"]:
+            v = vmcnt - 4 if (OPT["spread"] and dma) else vmcnt     # spread: only 4 pieces of step s+3 precede the barrier
+            after[15].append(q(f"s_waitcnt vmcnt({v}) lgkmcnt(0)"))
+        if OPT["barrier"]:
+            after[15].append(q("s_barrier"))
+    # fragment reads of step s+1: kk0 two per MFMA (16..19), kk1 one per MFMA (20..27)
+    for i in range(16, 32):
+        n = 2 if i < 20 else 1
+        for _ in range(n):
+            if rd:
+                after[i].append(rd.pop(0))
     for i in range(32):
-        if i == 16:
-            L.append(q("s_waitcnt lgkmcnt(0)"))
         L.append(m[i])
-        if dma and i < 16:
-            piece = i // 2
-            if i % 2 == 0:
-                L.append(q(f"s_add_u32 m0, %[lbase], {slot_d * SLOT + piece * 4096}"))
-            else:
-                rs = "rx" if piece < 4 else "rw"
-                L.append(q(f"buffer_load_dwordx4 %[vo{piece}], %[{rs}], %[koff] offen lds"))
-        if i == 15:
-            if dma:
-                L.append(q("s_add_u32 %[koff], %[koff], 64"))
-            if vmcnt is not None:
-                L.append(q(f"s_waitcnt vmcnt({vmcnt})"))
-                L.append(q("s_barrier"))
-        if i >= 16 and rd:
-            # kk0 reads two per MFMA (16..19), kk1 reads one per MFMA (20..27)
-            n = 2 if i < 20 else 1
-            for _ in range(n):
-                if rd:
-                    L.append(rd.pop(0))
+        L += after[i]
     assert not rd
     return L
 
 
-def main():
+VARIANTS = {
+    0: {},                                                      # the shipping schedule
+    1: {"dma": False},
+    2: {"barrier": False},
+    3: {"reads": False},
+    4: {"dma": False, "barrier": False, "reads": False, "vmwait": False},
+    5: {"vmwait": False},
+    6: {"cpol": " sc1"},
+    7: {"cpol": " nt"},
+    8: {"cpol": " sc0 sc1"},
+    9: {"spread": True},
+    10: {"spread": True, "cpol": " sc1"},
+    11: {"freeze": True},                                       # every step re-requests the same K slice (cache-hot source)
+    12: {"reads": False, "barrier": False, "vmwait": False},    # MFMA + DMA only
+    13: {"dma": False, "barrier": False, "vmwait": False},      # MFMA + fragment reads only
+    14: {"reads": False, "barrier": False, "vmwait": False, "ndma": 4},                          # MFMA + half the DMA instructions
+    15: {"reads": False, "barrier": False, "vmwait": False, "dmaop": "buffer_load_dword"},     # MFMA + 8 DMA of 4 B per lane
+    16: {"reads": False, "barrier": False, "vmwait": False, "spread": True},                     # MFMA + DMA spread over the step
+    17: {"reads": False, "barrier": False, "vmwait": False},    # as 12; the kernel requests whole 128-byte lines (8 rows x 128 B per piece)
+    18: {},                                                     # as 0 with whole-line requests
+}
+
+
+def emit(var):
+    OPT.update({"dma": True, "barrier": True, "reads": True, "vmwait": True, "cpol": "", "spread": False, "freeze": False, "ndma": 8, "dmaop": "buffer_load_dwordx4"})
+    OPT.update(VARIANTS[var])
     L = []
     L.append(q("; ---- fragments of step 0 (ring slot 0)"))
     L += reads(0, 0)
@@ -122,7 +155,7 @@ def main():
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)']
 
     here = os.path.dirname(os.path.abspath(__file__))
-    dst = os.path.join(here, "..", "sylber_amd", "csrc", "gemm_asm_loop.inc")
+    dst = os.path.join(here, "..", "sylber_amd", "csrc", "gemm_asm_loop.inc" if var == 0 else f"gemm_asm_loop_v{var}.inc")
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit; the schedule is documented there.\n")
         f.write("// Expects: MF (mnemonic string literal), acc[4][4], fx[2][2][4], fw[2][2][4], ax/axh/aw/awh[2], voff[8], rx, rw,\n")
@@ -136,5 +169,143 @@ def main():
     print("wrote", os.path.normpath(dst), len(L), "lines")
 
 
+
+
+# ======================================================================================================================
+# K64 layout (tile id 80): 128-byte LDS rows (K step 64), TWO 64-KiB slots.  One LDS-DMA instruction then requests 8 whole
+# 128-byte lines instead of 16 half lines -- measured with the knock-out variants above, the L1 handles requests per line
+# and the half-line form made the DMA, not the MFMAs, the longest stream of the loop (profiles/r03_gemm_asm_loop.md).
+#
+# One K step j (slot j & 1) = four slices kk of 16 MFMAs; fragment set kk & 1 (8 fragments) holds slice kk:
+#   slice 0..2:  lgkmcnt(0) | 16 MFMA + 8 ds_read of slice kk+1 -> other set   (+ the tail pieces of DMA(j+1) -> other slot)
+#   slice 3:     lgkmcnt(0) | MFMA 0,1 | vmcnt(0) ; s_barrier | MFMA 2.. + 8 ds_read of (j+1, 0) from the other slot
+#                                                              + the head pieces of DMA(j+2) -> THIS slot
+# Behind the barrier of (j, 3) every wave has read its last fragments of slot j & 1 (waited at the head of the slice) and
+# every wave's pieces of step j+1 have landed.
+K64 = {"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": ""}
+
+
+def k64_reads(setq, slot, kk):
+    out = []
+    h = "h" if slot else ""
+    for f in range(4):
+        out.append(q(f"ds_read_b128 %[x{setq}{f}], %[ax{kk}{h}] offset:{f * 4096}"))
+    for f in range(4):
+        out.append(q(f"ds_read_b128 %[w{setq}{f}], %[aw{kk}{h}] offset:{f * 4096}"))
+    return out
+
+
+def k64_dma(piece, slot):
+    rs = "rx" if piece < 8 else "rw"
+    return (q(f"s_add_u32 m0, %[lbase], {slot * 65536 + piece * 4096}"),
+            q(f"buffer_load_dwordx4 %[vo{piece}], %[{rs}], %[koff] offen{K64['cpol']} lds"))
+
+
+def k64_step(par, tail, head, nxt=True):
+    L = [q(f"; ---- K64 step parity {par}: tail {int(tail)} head {int(head)} next {int(nxt)}")]
+    nh = K64["nhead"]
+    tail_pieces = list(range(nh, 16)) if tail else []
+    for kk in range(4):
+        S = kk & 1
+        after = [[] for _ in range(16)]
+        pre = [[] for _ in range(16)]
+        if kk < 3:
+            rd = k64_reads(S ^ 1, par, kk + 1)
+            for i in range(8):
+                after[i].append(rd[i])
+            # tail pieces of DMA(j+1) -> the other slot, from MFMA 1 of slice 0 on
+            i = 1 if kk == 0 else 0
+            while tail_pieces and i < 16 and kk < 2:
+                p = tail_pieces.pop(0)
+                a, b = k64_dma(p, par ^ 1)
+                pre[i].append(a)
+                after[i].append(b)
+                if not tail_pieces:
+                    after[i].append(q("s_add_u32 %[koff], %[koff], 128"))
+                i += K64["tail_stride"]
+        else:
+            after[1].append(q("s_waitcnt vmcnt(0)"))
+            after[1].append(q("s_barrier"))
+            if nxt:
+                rd = k64_reads(S ^ 1, par ^ 1, 0)
+                for i in range(8):
+                    after[2 + i].append(rd[i])
+            if head:
+                i = 3
+                for p in range(nh):
+                    assert i <= 15
+                    a, b = k64_dma(p, par)
+                    pre[i].append(a)
+                    after[i].append(b)
+                    i += K64["head_stride"]
+        L.append(q("s_waitcnt lgkmcnt(0)"))
+        n = 0
+        for fm in range(4):
+            for fn in range(4):
+                L += pre[n]
+                L.append(f'MF " %[c{fm}{fn}], %[w{S}{fn}], %[x{S}{fm}], %[c{fm}{fn}]\\n"')
+                L += after[n]
+                n += 1
+    assert not tail_pieces
+    return L
+
+
+def emit_k64(var, opts):
+    K64.update({"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": ""})
+    K64.update(opts)
+    L = [q("; ---- fragments of (step 0, slice 0)")]
+    L += k64_reads(0, 0, 0)
+    L += k64_step(0, False, True)                       # j = 0: DMA(1) came with the prologue
+    L.append(q("s_cmp_eq_u32 %[nloop], 0"))
+    L.append(q("s_cbranch_scc1 L_gemmb_tail_%="))
+    L.append(q("L_gemmb_loop_%=:"))
+    L += k64_step(1, True, True)
+    L += k64_step(0, True, True)
+    L.append(q("s_sub_u32 %[nloop], %[nloop], 1"))
+    L.append(q("s_cmp_lg_u32 %[nloop], 0"))
+    L.append(q("s_cbranch_scc1 L_gemmb_loop_%="))
+    L.append(q("L_gemmb_tail_%=:"))
+    L += k64_step(1, True, True)                        # j = nj - 3
+    L += k64_step(0, True, False)                       # j = nj - 2
+    L += k64_step(1, False, False, nxt=False)           # j = nj - 1
+    L.append(q("s_nop 15"))
+    L.append(q("s_nop 15"))
+    outs = [f'[c{fm}{fn}] "+a"(acc[{fm}][{fn}])' for fm in range(4) for fn in range(4)]
+    for S in range(2):
+        for f in range(4):
+            outs.append(f'[x{S}{f}] "=&v"(fx[{S}][{f}])')
+            outs.append(f'[w{S}{f}] "=&v"(fw[{S}][{f}])')
+    outs += ['[koff] "+s"(koff)', '[nloop] "+s"(nloop)']
+    ins = []
+    for kk in range(4):
+        ins += [f'[ax{kk}] "v"(ax[{kk}])', f'[ax{kk}h] "v"(axh[{kk}])', f'[aw{kk}] "v"(aw[{kk}])', f'[aw{kk}h] "v"(awh[{kk}])']
+    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range(16)]
+    ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)']
+    here = os.path.dirname(os.path.abspath(__file__))
+    dst = os.path.join(here, "..", "sylber_amd", "csrc", "gemm_asm_k64.inc" if var == 0 else f"gemm_asm_k64_v{var}.inc")
+    with open(dst, "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py (K64 layout) -- do not edit; the schedule is documented there.\n")
+        f.write("asm volatile(\n")
+        for l in L:
+            f.write("    " + l + "\n")
+        f.write("    : " + ",\n      ".join(outs) + "\n")
+        f.write("    : " + ",\n      ".join(ins) + "\n")
+        f.write('    : "scc", "memory");   // m0 is written too (reserved register, re-materialised by the compiler before its own uses)\n')
+    print("wrote", os.path.normpath(dst), len(L), "lines")
+
+
+K64_VARIANTS = {
+    0: {},
+    1: {"nhead": 7, "tail_stride": 1},
+    2: {"nhead": 5, "head_stride": 3, "tail_stride": 2},      # 11 tail pieces: 8 in slice 0, 3 in slice 1
+    3: {"cpol": " sc1"},
+}
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "k64":
+        for v in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]):
+            emit_k64(v, K64_VARIANTS[v])
+    else:
+        for v in ([int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]):
+            emit(v)
