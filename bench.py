@@ -70,6 +70,7 @@ def parse_args():
                          "and crosses that GPU's own PCIe link every step (SURVEY.md §8(e)), gather unchanged")
     ap.add_argument("--fuse-ln", choices=["auto", "on", "off"], default="auto",
                     help="attention out-projection + LayerNorm as one launch (SYLBER_OPT_FUSE_OUTPROJ_LN); A/B switch")
+    ap.add_argument("--gemm-tile", type=int, default=-1, help="force one GEMM tile id for every launch that has it (SYLBER_OPT_GEMM_TILE); A/B switch")
     ap.add_argument("--conv0-valu", action="store_true", help="conv layer 0 on the VALU kernel (SYLBER_OPT_CONV0_VALU); A/B switch")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
     ap.add_argument("--agreement-clips", type=int, default=0,
@@ -238,6 +239,9 @@ def main():
     if args.conv0_valu:
         for e_ in encs:
             e_.set_option(5, 1)
+    if args.gemm_tile >= 0:
+        for e_ in encs:
+            e_.set_option(1, args.gemm_tile)
     if args.fuse_ln != "auto":
         for e_ in encs:
             e_.set_option(4, 1 if args.fuse_ln == "on" else -1)

@@ -182,7 +182,7 @@ def emit(var):
 #                                                              + the head pieces of DMA(j+2) -> THIS slot
 # Behind the barrier of (j, 3) every wave has read its last fragments of slot j & 1 (waited at the head of the slice) and
 # every wave's pieces of step j+1 have landed.
-K64 = {"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": ""}
+K64 = {"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": "", "fn": 4}
 
 
 def k64_reads(setq, slot, kk):
@@ -190,32 +190,37 @@ def k64_reads(setq, slot, kk):
     h = "h" if slot else ""
     for f in range(4):
         out.append(q(f"ds_read_b128 %[x{setq}{f}], %[ax{kk}{h}] offset:{f * 4096}"))
-    for f in range(4):
+    for f in range(K64["fn"]):
         out.append(q(f"ds_read_b128 %[w{setq}{f}], %[aw{kk}{h}] offset:{f * 4096}"))
     return out
 
 
 def k64_dma(piece, slot):
     rs = "rx" if piece < 8 else "rw"
-    return (q(f"s_add_u32 m0, %[lbase], {slot * 65536 + piece * 4096}"),
+    stage = (256 + 64 * K64["fn"]) * 128
+    return (q(f"s_add_u32 m0, %[lbase], {slot * stage + piece * 4096}"),
             q(f"buffer_load_dwordx4 %[vo{piece}], %[{rs}], %[koff] offen{K64['cpol']} lds"))
 
 
-def k64_step(par, tail, head, nxt=True):
+def k64_step(par, tail, head, nxt=True, first=False):
+    FN_ = K64["fn"]
+    n_mf = 4 * FN_                       # MFMAs per slice
+    n_rd = 4 + FN_                       # fragment reads per slice
+    n_dma = 8 + 2 * FN_                  # pieces per wave and step
     L = [q(f"; ---- K64 step parity {par}: tail {int(tail)} head {int(head)} next {int(nxt)}")]
-    nh = K64["nhead"]
-    tail_pieces = list(range(nh, 16)) if tail else []
+    nh = min(K64["nhead"], (n_mf - 3 + K64["head_stride"] - 1) // K64["head_stride"])
+    tail_pieces = list(range(nh, n_dma)) if tail else []
     for kk in range(4):
         S = kk & 1
-        after = [[] for _ in range(16)]
-        pre = [[] for _ in range(16)]
+        after = [[] for _ in range(n_mf)]
+        pre = [[] for _ in range(n_mf)]
         if kk < 3:
             rd = k64_reads(S ^ 1, par, kk + 1)
-            for i in range(8):
+            for i in range(n_rd):
                 after[i].append(rd[i])
             # tail pieces of DMA(j+1) -> the other slot, from MFMA 1 of slice 0 on
             i = 1 if kk == 0 else 0
-            while tail_pieces and i < 16 and kk < 2:
+            while tail_pieces and i < n_mf and kk < 2:
                 p = tail_pieces.pop(0)
                 a, b = k64_dma(p, par ^ 1)
                 pre[i].append(a)
@@ -228,12 +233,12 @@ def k64_step(par, tail, head, nxt=True):
             after[1].append(q("s_barrier"))
             if nxt:
                 rd = k64_reads(S ^ 1, par ^ 1, 0)
-                for i in range(8):
+                for i in range(n_rd):
                     after[2 + i].append(rd[i])
             if head:
                 i = 3
                 for p in range(nh):
-                    assert i <= 15
+                    assert i <= n_mf - 1
                     a, b = k64_dma(p, par)
                     pre[i].append(a)
                     after[i].append(b)
@@ -241,21 +246,22 @@ def k64_step(par, tail, head, nxt=True):
         L.append(q("s_waitcnt lgkmcnt(0)"))
         n = 0
         for fm in range(4):
-            for fn in range(4):
+            for fn in range(FN_):
                 L += pre[n]
-                L.append(f'MF " %[c{fm}{fn}], %[w{S}{fn}], %[x{S}{fm}], %[c{fm}{fn}]\\n"')
+                srcc = "0" if (first and kk == 0) else f"%[c{fm}{fn}]"     # the tile's first slice starts the accumulators
+                L.append(f'MF " %[c{fm}{fn}], %[w{S}{fn}], %[x{S}{fm}], {srcc}\\n"')
                 L += after[n]
                 n += 1
     assert not tail_pieces
     return L
 
 
-def emit_k64(var, opts):
-    K64.update({"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": ""})
+def emit_k64(var, opts, fn=4):
+    K64.update({"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": "", "fn": fn})
     K64.update(opts)
     L = [q("; ---- fragments of (step 0, slice 0)")]
     L += k64_reads(0, 0, 0)
-    L += k64_step(0, False, True)                       # j = 0: DMA(1) came with the prologue
+    L += k64_step(0, False, True, first=True)           # j = 0: DMA(1) came with the prologue
     L.append(q("s_cmp_eq_u32 %[nloop], 0"))
     L.append(q("s_cbranch_scc1 L_gemmb_tail_%="))
     L.append(q("L_gemmb_loop_%=:"))
@@ -268,21 +274,23 @@ def emit_k64(var, opts):
     L += k64_step(1, True, True)                        # j = nj - 3
     L += k64_step(0, True, False)                       # j = nj - 2
     L += k64_step(1, False, False, nxt=False)           # j = nj - 1
+    L.append(q("s_barrier"))                             # every wave is done reading operand tiles (fragments waited above)
     L.append(q("s_nop 15"))
-    L.append(q("s_nop 15"))
-    outs = [f'[c{fm}{fn}] "+a"(acc[{fm}][{fn}])' for fm in range(4) for fn in range(4)]
+    outs = [f'[c{fm}{f}] "=a"(acc[{fm}][{f}])' for fm in range(4) for f in range(fn)]
     for S in range(2):
         for f in range(4):
             outs.append(f'[x{S}{f}] "=&v"(fx[{S}][{f}])')
+        for f in range(fn):
             outs.append(f'[w{S}{f}] "=&v"(fw[{S}][{f}])')
     outs += ['[koff] "+s"(koff)', '[nloop] "+s"(nloop)']
     ins = []
     for kk in range(4):
         ins += [f'[ax{kk}] "v"(ax[{kk}])', f'[ax{kk}h] "v"(axh[{kk}])', f'[aw{kk}] "v"(aw[{kk}])', f'[aw{kk}h] "v"(awh[{kk}])']
-    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range(16)]
+    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range(8 + 2 * fn)]
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)']
     here = os.path.dirname(os.path.abspath(__file__))
-    dst = os.path.join(here, "..", "sylber_amd", "csrc", "gemm_asm_k64.inc" if var == 0 else f"gemm_asm_k64_v{var}.inc")
+    name = "gemm_asm_k64" + ("" if fn == 4 else f"_n{fn}") + ("" if var == 0 else f"_v{var}") + ".inc"
+    dst = os.path.join(here, "..", "sylber_amd", "csrc", name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (K64 layout) -- do not edit; the schedule is documented there.\n")
         f.write("asm volatile(\n")
@@ -306,6 +314,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "k64":
         for v in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]):
             emit_k64(v, K64_VARIANTS[v])
+        emit_k64(0, {}, fn=3)
     else:
         for v in ([int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]):
             emit(v)
