@@ -182,7 +182,7 @@ def emit(var):
 #                                                              + the head pieces of DMA(j+2) -> THIS slot
 # Behind the barrier of (j, 3) every wave has read its last fragments of slot j & 1 (waited at the head of the slice) and
 # every wave's pieces of step j+1 have landed.
-K64 = {"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": "", "fn": 4}
+K64 = {"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": "", "fn": 4, "nw": 4, "bn": 256}
 
 
 def k64_reads(setq, slot, kk):
@@ -196,9 +196,10 @@ def k64_reads(setq, slot, kk):
 
 
 def k64_dma(piece, slot):
-    rs = "rx" if piece < 8 else "rw"
-    stage = (256 + 64 * K64["fn"]) * 128
-    return (q(f"s_add_u32 m0, %[lbase], {slot * stage + piece * 4096}"),
+    nw = K64["nw"]
+    rs = "rx" if piece < 32 // nw else "rw"              # wave w stages pieces w + nw i; the first 32 pieces are X rows
+    stage = (256 + K64["bn"]) * 128
+    return (q(f"s_add_u32 m0, %[lbase], {slot * stage + piece * nw * 1024}"),
             q(f"buffer_load_dwordx4 %[vo{piece}], %[{rs}], %[koff] offen{K64['cpol']} lds"))
 
 
@@ -206,7 +207,7 @@ def k64_step(par, tail, head, nxt=True, first=False):
     FN_ = K64["fn"]
     n_mf = 4 * FN_                       # MFMAs per slice
     n_rd = 4 + FN_                       # fragment reads per slice
-    n_dma = 8 + 2 * FN_                  # pieces per wave and step
+    n_dma = (256 + K64["bn"]) // 8 // K64["nw"]           # pieces per wave and step
     L = [q(f"; ---- K64 step parity {par}: tail {int(tail)} head {int(head)} next {int(nxt)}")]
     nh = min(K64["nhead"], (n_mf - 3 + K64["head_stride"] - 1) // K64["head_stride"])
     tail_pieces = list(range(nh, n_dma)) if tail else []
@@ -256,8 +257,9 @@ def k64_step(par, tail, head, nxt=True, first=False):
     return L
 
 
-def emit_k64(var, opts, fn=4):
-    K64.update({"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": "", "fn": fn})
+def emit_k64(var, opts, fn=4, nw=4):
+    bn = 64 * fn if nw == 4 else 128 * fn                # 4 waves: 2 x 2 grid; 8 waves: 2 x 4 grid
+    K64.update({"nhead": 7, "head_stride": 2, "tail_stride": 2, "cpol": "", "fn": fn, "nw": nw, "bn": bn})
     K64.update(opts)
     L = [q("; ---- fragments of (step 0, slice 0)")]
     L += k64_reads(0, 0, 0)
@@ -286,10 +288,10 @@ def emit_k64(var, opts, fn=4):
     ins = []
     for kk in range(4):
         ins += [f'[ax{kk}] "v"(ax[{kk}])', f'[ax{kk}h] "v"(axh[{kk}])', f'[aw{kk}] "v"(aw[{kk}])', f'[aw{kk}h] "v"(awh[{kk}])']
-    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range(8 + 2 * fn)]
+    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range((256 + bn) // 8 // nw)]
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)']
     here = os.path.dirname(os.path.abspath(__file__))
-    name = "gemm_asm_k64" + ("" if fn == 4 else f"_n{fn}") + ("" if var == 0 else f"_v{var}") + ".inc"
+    name = "gemm_asm_k64" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + ("" if var == 0 else f"_v{var}") + ".inc"
     dst = os.path.join(here, "..", "sylber_amd", "csrc", name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (K64 layout) -- do not edit; the schedule is documented there.\n")
@@ -315,6 +317,7 @@ if __name__ == "__main__":
         for v in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]):
             emit_k64(v, K64_VARIANTS[v])
         emit_k64(0, {}, fn=3)
+        emit_k64(0, {}, fn=2, nw=8)
     else:
         for v in ([int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]):
             emit(v)
