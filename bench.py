@@ -532,17 +532,18 @@ def main():
             enc_tf = sum(fl[k] for k in enc_keys) / (enc_ms * 1e-3) / 1e12
             roofline["encoder_gemms"] = {"achieved": round(enc_tf, 1), "frac": round(enc_tf / MFMA_BF16_PEAK_TFLOPS, 4),
                                          "ms_per_forward": round(enc_ms, 4)}
-        # the single dominant instantiation, exactly the row rocprofv3 prints as gemm8p_bf16_kernel<1, 0>: the persistent
-        # 8-wave 256x256 kernel with the GELU epilogue = conv1..conv4 + 9 x FFN1 (conv5's 256 tiles are one round and run
-        # the one-tile-per-workgroup form gemm8_bf16_kernel<4, 2, 2, 4, 0, 1, 0>)
-        if clip_samples == CLIP_SAMPLES and B == BATCH_PER_GPU and args.precision == "bf16":
-            big = ["gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_ffn1"]
-            n_big = 4 + 9
+        # the single dominant instantiation, exactly the row rocprofv3 prints as gemmb_bf16_kernel<0, 1, 0, 0, 2, 8>: the
+        # hand-scheduled 256x256 kernel on eight waves with the GELU epilogue (csrc/gemm_asm.hip, tile 95) = conv1..conv5 +
+        # 9 x FFN1, persistent with the next tile's first K step requested before the epilogue
+        if clip_samples == CLIP_SAMPLES and B == BATCH_PER_GPU and args.precision == "bf16" and args.gemm_tile < 0:
+            big = ["gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_ffn1"]
+            n_big = 5 + 9
             ms_big = sum(kernels.get(k, 0.0) for k in big)
             fl_big = sum(fl[k] for k in big)
             if ms_big > 0:
                 roofline["dominant_instantiation"] = {
-                    "kernel": "gemm8p_bf16_kernel<1, 0> (256x256 tile, 8 waves, GELU + bf16 epilogue, persistent with cross-tile operand prefetch)", "launches_per_forward": n_big,
+                    "kernel": "gemmb_bf16_kernel<0, 1, 0, 0, 2, 8> (256x256 tile, 8 waves x 128x64, inline-asm K loop over 128-byte LDS rows, "
+                              "GELU + bf16 epilogue, persistent)", "launches_per_forward": n_big,
                     "avg_launch_ms": round(ms_big / n_big, 4), "achieved": round(fl_big / (ms_big * 1e-3) / 1e12, 1),
                     "frac": round(fl_big / (ms_big * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
         # the HBM-bound end of the path (north_star: "achieved HBM GB/s on the conv frontend"): conv0 + GroupNorm + GELU
