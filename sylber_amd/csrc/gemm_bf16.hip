@@ -891,7 +891,7 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     for (int i = 0; i < 6; ++i) {
         if (i >= 3 && !asm_ok) continue;
         if (cfgs[i].id == 90 && FMT != FMT_BF16) continue;
-        if (cfgs[i].id == 95 && (FMT != FMT_BF16 || (EPI != EPI_BF16 && EPI != EPI_F32))) continue;
+        if (cfgs[i].id == 95 && EPI != EPI_BF16 && EPI != EPI_F32) continue;
         const long tm = (a.M + cfgs[i].bm - 1) / cfgs[i].bm, tn = (a.N + cfgs[i].bn - 1) / cfgs[i].bn;
         const long slots = 256L * cfgs[i].per_cu;
         const long rounds = (tm * tn + slots - 1) / slots;
