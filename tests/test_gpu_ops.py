@@ -86,7 +86,7 @@ def test_attention(lib, B, T, valid, qw):
     assert (o.cpu() - ref).pow(2).mean().sqrt().item() < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11, 40, 60, 80, 90, 95])
+@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11, 40, 60, 80, 85, 90, 91, 95, 97])
 def test_linear_every_tile_config(lib, cfg):
     """every GEMM tile configuration (4-wave 2/3-slot rings, 8-wave staggered big tiles) gives the same
     result, including ragged M / N tails and a strided (overlapping-row) activation operand"""
@@ -124,7 +124,7 @@ def test_linear_split16(lib, cfg):
         assert err < 12 * (f32 - ref).abs().max().item() + 2e-6, (cfg, M, N, K)     # fp32 accumulation noise (a longer serial chain than the CPU's blocked sums)
 
 
-@pytest.mark.parametrize("cfg", [40, 60, 80, 90, 95])
+@pytest.mark.parametrize("cfg", [40, 60, 80, 85, 90, 91, 95, 97])
 def test_gemm8_schedule_variants_bitwise(lib, cfg):
     """the K-loop schedule variants of the 8-wave kernel (where the LDS-DMA of step s+3 is issued) contract in the same
     order: bit-identical to the default schedule on a full-size launch, run to run (a hand-off race would show here)"""

@@ -304,6 +304,155 @@ def emit_k64(var, opts, fn=4, nw=4):
     print("wrote", os.path.normpath(dst), len(L), "lines")
 
 
+# ======================================================================================================================
+# X3 ring (tile ids 85 / 91 / 97): the K64 loop with THREE slots for the X operand (the activations, which the forward reads
+# cold: written by the previous kernel, at best in the MALL) and two for W (the weights, L2-resident).  X(j+2) is requested
+# during step j and has two K steps to land, W(j+2) one, as before.  LDS: X ring 3 x 32 KiB at 0, W ring 2 x BN x 128 B behind
+# it (256x256 tile: exactly the 160 KiB of a CU).  The X slot rotates through registers (xr: read-slot byte offset, the four X
+# fragment addresses advanced by VALU adds once per step); the W slot stays a compile-time parity of the 2x unrolled loop.
+#   step j, slices 0-1:  rest of W(j+1) -> W slot (j+1)&1, then X(j+2) -> X slot (j+2)%3 (= the slot step j-1 read), koff += 128
+#   step j, slice 3:     lgkmcnt(0) | MFMA 0,1 | vmcnt(#X pieces) ; s_barrier | rotate xr, advance X addresses |
+#                        ds_read (j+1, 0) | first pieces of W(j+2) -> W slot j&1
+# VMEM operations retire in order, so at the barrier "all but the youngest #X pieces" = every piece of step j+1.
+X3 = {}
+
+
+def x3_reads(setq, wslot, kk):
+    out = []
+    h = "h" if wslot else ""
+    for f in range(4):
+        out.append(q(f"ds_read_b128 %[x{setq}{f}], %[ax{kk}] offset:{f * 4096}"))
+    for f in range(X3["fn"]):
+        out.append(q(f"ds_read_b128 %[w{setq}{f}], %[aw{kk}{h}] offset:{f * 4096}"))
+    return out
+
+
+def x3_dma_w(i, wslot):
+    nw, nxp = X3["nw"], 32 // X3["nw"]
+    return (q(f"s_add_u32 m0, %[lbase], {98304 + wslot * X3['bn'] * 128 + (i - nxp) * nw * 1024}"),
+            q(f"buffer_load_dwordx4 %[vo{i}], %[rw], %[koff] offen lds"))
+
+
+def x3_dma_x(i):
+    # X runs one K step ahead of W: its byte offset is kofx = koff + 128 (an instruction offset would move the LDS address too)
+    return (q(f"s_add_u32 m0, %[xwl], {i * X3['nw'] * 1024}"),
+            q(f"buffer_load_dwordx4 %[vo{i}], %[rx], %[kofx] offen lds"))
+
+
+def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False):
+    FN_ = X3["fn"]
+    nw = X3["nw"]
+    nxp, nwp = 32 // nw, X3["bn"] // 8 // nw
+    n_mf, n_rd = 4 * FN_, 4 + FN_
+    L = [q(f"; ---- X3 step parity {par}: tail_w {int(tail_w)} x_next {int(x_next)} head {int(head)} vmcnt {vm}")]
+    nh = min(nwp - 1, (n_mf - 3 + 1) // 2)                   # W pieces issued in slice 3 (positions 3, 5, ...)
+    queue = []                                               # (m0 line, dma line) of slices 0-1, W first then X
+    if tail_w:
+        queue += [x3_dma_w(i, par ^ 1) for i in range(nxp + nh, nxp + nwp)]
+    if x_next:
+        xq = [x3_dma_x(i) for i in range(nxp)]
+        xq[0] = (q("s_add_u32 %[kofx], %[koff], 128") + "\n    " + xq[0][0], xq[0][1])
+        queue += xq
+    bump = tail_w or x_next
+    for kk in range(4):
+        S = kk & 1
+        after = [[] for _ in range(n_mf)]
+        pre = [[] for _ in range(n_mf)]
+        if kk < 3:
+            rd = x3_reads(S ^ 1, par, kk + 1)
+            for i in range(n_rd):
+                after[i].append(rd[i])
+            i = 1 if kk == 0 else 0
+            while queue and i < n_mf and kk < 2:
+                a, b = queue.pop(0)
+                pre[i].append(a)
+                after[i].append(b)
+                if not queue and bump:
+                    after[i].append(q("s_add_u32 %[koff], %[koff], 128"))
+                i += 2
+        else:
+            after[1].append(q(f"s_waitcnt vmcnt({vm})"))
+            after[1].append(q("s_barrier"))
+            if nxt:
+                # X(j+3) goes where step j was read; then rotate the read slot and advance the four X fragment addresses
+                after[1] += [q("s_add_u32 %[xwl], %[lbase], %[xr]"),
+                             q("s_add_u32 %[xr], %[xr], 0x8000"),
+                             q("s_cmp_eq_u32 %[xr], 0x18000"),
+                             q("s_cselect_b32 %[dlt], %[cneg], 0x8000"),
+                             q("s_cselect_b32 %[xr], 0, %[xr]")]
+                after[1] += [q(f"v_add_u32_e32 %[ax{k}], %[dlt], %[ax{k}]") for k in range(4)]
+                rd = x3_reads(S ^ 1, par ^ 1, 0)
+                for i in range(n_rd):
+                    after[min(2 + i, n_mf - 1)].append(rd[i])
+            if head:
+                i = 3
+                for p in range(nh):
+                    assert i <= n_mf - 1
+                    a, b = x3_dma_w(nxp + p, par)
+                    pre[i].append(a)
+                    after[i].append(b)
+                    i += 2
+        L.append(q("s_waitcnt lgkmcnt(0)"))
+        n = 0
+        for fm in range(4):
+            for fn in range(FN_):
+                L += pre[n]
+                srcc = "0" if (first and kk == 0) else f"%[c{fm}{fn}]"
+                L.append(f'MF " %[c{fm}{fn}], %[w{S}{fn}], %[x{S}{fm}], {srcc}\\n"')
+                L += after[n]
+                n += 1
+    assert not queue
+    return L
+
+
+def emit_x3(fn=4, nw=4):
+    bn = 64 * fn if nw == 4 else 128 * fn
+    X3.update({"fn": fn, "nw": nw, "bn": bn})
+    nxp = 32 // nw
+    L = [q("; ---- fragments of (step 0, slice 0)")]
+    L += x3_reads(0, 0, 0)
+    L += x3_step(0, False, False, True, nxp, first=True)     # j = 0: W(1), X(1), X(2) came with the prologue
+    L.append(q("s_cmp_eq_u32 %[nloop], 0"))
+    L.append(q("s_cbranch_scc1 L_gemmx_tail_%="))
+    L.append(q("L_gemmx_loop_%=:"))
+    L += x3_step(1, True, True, True, nxp)
+    L += x3_step(0, True, True, True, nxp)
+    L.append(q("s_sub_u32 %[nloop], %[nloop], 1"))
+    L.append(q("s_cmp_lg_u32 %[nloop], 0"))
+    L.append(q("s_cbranch_scc1 L_gemmx_loop_%="))
+    L.append(q("L_gemmx_tail_%=:"))
+    L += x3_step(1, True, True, True, nxp)                   # j = nj - 3: X(nj - 1), first pieces of W(nj - 1)
+    L += x3_step(0, True, False, False, 0)                   # j = nj - 2: rest of W(nj - 1)
+    L += x3_step(1, False, False, False, 0, nxt=False)       # j = nj - 1
+    L.append(q("s_barrier"))
+    L.append(q("s_nop 15"))
+    outs = [f'[c{m}{f}] "=a"(acc[{m}][{f}])' for m in range(4) for f in range(fn)]
+    for S in range(2):
+        for f in range(4):
+            outs.append(f'[x{S}{f}] "=&v"(fx[{S}][{f}])')
+        for f in range(fn):
+            outs.append(f'[w{S}{f}] "=&v"(fw[{S}][{f}])')
+    outs += [f'[ax{k}] "+v"(axc[{k}])' for k in range(4)]
+    outs += ['[koff] "+s"(koff)', '[nloop] "+s"(nloop)', '[xr] "+s"(xr)', '[xwl] "=&s"(xwl)', '[dlt] "=&s"(dlt)', '[kofx] "=&s"(kofx)']
+    ins = []
+    for kk in range(4):
+        ins += [f'[aw{kk}] "v"(aw[{kk}])', f'[aw{kk}h] "v"(awh[{kk}])']
+    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range((256 + bn) // 8 // nw)]
+    ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)', '[cneg] "s"(cneg)']
+    here = os.path.dirname(os.path.abspath(__file__))
+    name = "gemm_asm_x3" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + ".inc"
+    dst = os.path.join(here, "..", "sylber_amd", "csrc", name)
+    with open(dst, "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py (X3 ring) -- do not edit; the schedule is documented there.\n")
+        f.write("asm volatile(\n")
+        for l in L:
+            f.write("    " + l + "\n")
+        f.write("    : " + ",\n      ".join(outs) + "\n")
+        f.write("    : " + ",\n      ".join(ins) + "\n")
+        f.write('    : "scc", "memory");   // m0 is written too (reserved register, re-materialised by the compiler before its own uses)\n')
+    print("wrote", os.path.normpath(dst), len(L), "lines")
+
+
 K64_VARIANTS = {
     0: {},
     1: {"nhead": 7, "tail_stride": 1},
@@ -318,6 +467,9 @@ if __name__ == "__main__":
             emit_k64(v, K64_VARIANTS[v])
         emit_k64(0, {}, fn=3)
         emit_k64(0, {}, fn=2, nw=8)
+        emit_x3(4, 4)
+        emit_x3(3, 4)
+        emit_x3(2, 8)
     else:
         for v in ([int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]):
             emit(v)
