@@ -161,7 +161,10 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
 /* Tuning / test overrides, scoped to ONE handle (nothing process-global).  SYLBER_OPT_GEMM_TILE: value < 0 restores the
  * automatic choice (0 is a tile id); the other keys: 0 = automatic.
  *   SYLBER_OPT_GEMM_TILE               tile configuration id of the bf16 GEMM launches (csrc/gemm_bf16.hip launch_t:
- *                                      0 = 256x128, 3 = 128x128, 4 = 128x192, 10 = 256x256 8-wave, 11 = 256x192 8-wave)
+ *                                      0 = 256x128, 3 = 128x128, 4 = 128x192, 10 = 256x256 8-wave, 11 = 256x192 8-wave;
+ *                                      hand-scheduled K loops (csrc/gemm_asm.hip; a launch whose epilogue / K has no such
+ *                                      instantiation falls back to 128x192): 80 = 256x256 4-wave, 90 = 256x192, 95 = 256x256
+ *                                      8-wave, 85 / 91 / 97 = the same with a three-slot X ring, 60 = the 64-byte-row first cut)
  *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   32 (automatic choice) or 64
  *   SYLBER_OPT_GEMM_PERSISTENT         0 (automatic): GEMM launches of more than one round run as persistent workgroups
  *                                      walking the tile list (4-wave kernels: two per CU; the 256x256 kernel: one per CU

@@ -884,7 +884,7 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     const bool long_k = a.K >= 1024;
     // 95: the same loop on eight waves (two per SIMD share the epilogue's VALU work): the GELU GEMMs, K = 768 included.
     // 85 / 91 / 97 = 80 / 90 / 95 with three ring slots for X (bf16 only): never slower hot, 5-15 % faster on cold activations
-    const bool x3 = FMT == FMT_BF16;
+    const bool x3 = FMT != FMT_SPLIT;
     const Cfg cfgs[6] = {{3, 128, 128, 2, 0.93}, {4, 128, 192, 2, 1.00}, {10, 256, 256, 1, 1.20},
                          {x3 ? 85 : 80, 256, 256, 1, long_k ? 1.28 : 1.10}, {91, 256, 192, 1, long_k ? 1.10 : 1.04},
                          {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27}};
