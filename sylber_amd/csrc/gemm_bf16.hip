@@ -892,7 +892,7 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     double best_cost = 1e300;
     for (int i = 0; i < 6; ++i) {
         if (i >= 3 && !asm_ok) continue;
-        if (cfgs[i].id == 91 && FMT != FMT_BF16) continue;
+        if (cfgs[i].id == 91 && FMT == FMT_F16 && EPI != EPI_F32_RESLN && EPI != EPI_QK) continue;   // fp16: tile 91 exists for these two
         if (i == 5 && EPI != EPI_BF16 && EPI != EPI_F32) continue;
         const long tm = (a.M + cfgs[i].bm - 1) / cfgs[i].bm, tn = (a.N + cfgs[i].bn - 1) / cfgs[i].bn;
         const long slots = 256L * cfgs[i].per_cu;
