@@ -19,6 +19,8 @@ Slot (s+3)&3 = (s-1)&3 was last read during step s-2 and those reads were waited
 """
 import os
 
+OUTDIR = os.environ.get("GEN_GEMM_ASM_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sylber_amd", "csrc")
+
 FM = FN = 4
 SLOT = 32768
 XT = 256 * 64
@@ -155,7 +157,7 @@ def emit(var):
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)']
 
     here = os.path.dirname(os.path.abspath(__file__))
-    dst = os.path.join(here, "..", "sylber_amd", "csrc", "gemm_asm_loop.inc" if var == 0 else f"gemm_asm_loop_v{var}.inc")
+    dst = os.path.join(OUTDIR, "gemm_asm_loop.inc" if var == 0 else f"gemm_asm_loop_v{var}.inc")
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit; the schedule is documented there.\n")
         f.write("// Expects: MF (mnemonic string literal), acc[4][4], fx[2][2][4], fw[2][2][4], ax/axh/aw/awh[2], voff[8], rx, rw,\n")
@@ -292,7 +294,7 @@ def emit_k64(var, opts, fn=4, nw=4):
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)']
     here = os.path.dirname(os.path.abspath(__file__))
     name = "gemm_asm_k64" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + ("" if var == 0 else f"_v{var}") + ".inc"
-    dst = os.path.join(here, "..", "sylber_amd", "csrc", name)
+    dst = os.path.join(OUTDIR, name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (K64 layout) -- do not edit; the schedule is documented there.\n")
         f.write("asm volatile(\n")
@@ -441,7 +443,7 @@ def emit_x3(fn=4, nw=4):
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)', '[cneg] "s"(cneg)']
     here = os.path.dirname(os.path.abspath(__file__))
     name = "gemm_asm_x3" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + ".inc"
-    dst = os.path.join(here, "..", "sylber_amd", "csrc", name)
+    dst = os.path.join(OUTDIR, name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (X3 ring) -- do not edit; the schedule is documented there.\n")
         f.write("asm volatile(\n")
