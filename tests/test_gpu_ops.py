@@ -197,3 +197,21 @@ def test_linear_persistent_prefetch_kernel(lib, act):
         if act:
             ref = torch.nn.functional.gelu(ref)
         assert (got - ref).abs().max().item() < 2e-2 and (got - ref).pow(2).mean().sqrt().item() < 3e-3
+
+
+@pytest.mark.parametrize("tile", [80, 85, 90, 91, 95, 97])
+def test_asm_tiles_persistent_seams(lib, tile):
+    """the hand-scheduled kernels as persistent workgroups (more tiles than CUs: the next tile's operands requested before
+    the epilogue, counted waits across its stores) return bit for bit what the HIP 8-wave kernel returns, with whole tiles
+    and with a ragged last row tile (where the seam wait drains the stores instead of counting them), run to run"""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(33)
+    for (M, N, K, act) in [(256 * 90, 1024, 512, 1), (6437, 3072, 768, 1), (256 * 70, 1536, 256, 0)]:
+        a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+        ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+        ref = torch.full((M, N), -1, dtype=torch.int16, device="cuda")
+        _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(ref), M, N, K, act, 0, 9010, None), "op_linear16")
+        for _ in range(3):
+            c = torch.full((M, N), -1, dtype=torch.int16, device="cuda")
+            _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, act, 0, tile, None), "op_linear16")
+            assert torch.equal(c, ref), (tile, M, N, K)
