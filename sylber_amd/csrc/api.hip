@@ -1026,6 +1026,7 @@ extern "C" int sylber_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t 
                                        unsigned long long* out20, float* ms_out) {
     if (!out20 || !ms_out) { syl_set_error("sylber_debug_gemm_trace", "null argument"); return 1; }
     // act >= 100: the trace instantiation of the UNSTAGGERED kernel (tile id 41; plain bf16 epilogue only)
+    if (act >= 200) return gemm_bench_impl(M, N, K, ldx, 0, 1, 98, 3, ms_out, out20);   // asm tile 97 with phase stamps (SYLBER_EXPERIMENTS builds)
     if (act >= 100) return gemm_bench_impl(M, N, K, ldx, 0, 0, 9041, 3, ms_out, out20);
     return gemm_bench_impl(M, N, K, ldx, epi, act, 9030, 3, ms_out, out20);
 }
