@@ -8,7 +8,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SYLBER_HIP_LIB: development override (same-box A/B of two builds of the library, tools/ab_lib.sh); the product loads the in-tree build
-LIB_PATH = os.environ.get("SYLBER_HIP_LIB") or os.path.join(_HERE, "libsylber_hip.so")
+# SYLBER_EXPERIMENTS=1 (tools/ only): the timing-kernel build, which build.py writes to its own file
+LIB_PATH = os.environ.get("SYLBER_HIP_LIB") or os.path.join(_HERE, "libsylber_hip_exp.so" if os.environ.get("SYLBER_EXPERIMENTS") else "libsylber_hip.so")
 MAX_LAYERS = 12
 
 c_float_p = POINTER(c_float)

@@ -13,7 +13,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libsylber_hip.so")
+# SYLBER_EXPERIMENTS=1: the timing-only kernels (knock-out loops, phase stamps; some store nothing) are compiled in and the
+# result goes to ITS OWN file, so an experiments build can never be mistaken for / left behind as the product library.
+EXPERIMENTS = bool(os.environ.get("SYLBER_EXPERIMENTS"))
+LIB = os.path.join(HERE, "libsylber_hip_exp.so" if EXPERIMENTS else "libsylber_hip.so")
+GEN_DIR = os.path.join(HERE, "build", "gen")           # generated experiment loops (never committed)
 SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip", "gemm_rowln.hip", "gemm_asm.hip"]
 EXTRA = {"segment.hip": ["-ffp-contract=off"]}
 # -fno-slp-vectorize: NO packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the library.  Measured on
@@ -41,13 +45,26 @@ def _newest_source() -> float:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", "exp" if EXPERIMENTS else "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
+    exp_flags = []
+    if EXPERIMENTS:
+        gen = os.path.join(os.path.dirname(HERE), "tools", "gen_gemm_asm.py")
+        subprocess.run([sys.executable, gen, "experiments"], check=True, capture_output=True, env=dict(os.environ, GEN_GEMM_ASM_OUT=GEN_DIR))
+        exp_flags = ["-DSYLBER_GEMM_ASM_EXPERIMENTS", "-I", GEN_DIR]
+
+    # a source is recompiled when it, any header / generated loop beside it, the public headers or this file is newer
+    shared = [os.path.getmtime(os.path.abspath(__file__))]
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        shared += [os.path.getmtime(os.path.join(root, f)) for f in os.listdir(root) if not f.endswith(".hip")]
+    newest_shared = max(shared)
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        extra = EXTRA.get(src, []) + (["-DSYLBER_GEMM_ASM_EXPERIMENTS"] if os.environ.get("SYLBER_EXPERIMENTS") else [])   # timing-only kernels
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(newest_shared, os.path.getmtime(os.path.join(CSRC, src))):
+            return obj
+        extra = EXTRA.get(src, []) + exp_flags
         cmd = [hipcc] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

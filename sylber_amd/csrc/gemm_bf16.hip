@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     // a piece belongs to is a compile-time property of i, so its descriptor is too
     static_assert((BM / RPP) % 4 == 0, "X pieces must split evenly over the 4 waves");
     constexpr int XPW = BM / RPP / 4;
-    const int pl_x = (int)(a.x_lo * 2), pl_w = (int)(a.w_lo * 2);   // FMT_SPLIT: lo-plane byte offsets
+    const int pl_x = (int)(unsigned)(a.x_lo * 2), pl_w = (int)(unsigned)(a.w_lo * 2);   // FMT_SPLIT: lo-plane byte offsets
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         const int p = wave + 4 * i;
@@ -331,7 +331,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     // pieces wave + 8 i with i < XPW are X rows for every wave: the operand (and its descriptor) of piece i is static
     static_assert((BM / 16) % 8 == 0, "X pieces must split evenly over the 8 waves");
     constexpr int XPW = BM / 16 / 8;
-    const int pl_x = (int)(a.x_lo * 2), pl_w = (int)(a.w_lo * 2);   // FMT_SPLIT: lo-plane byte offsets
+    const int pl_x = (int)(unsigned)(a.x_lo * 2), pl_w = (int)(unsigned)(a.w_lo * 2);   // FMT_SPLIT: lo-plane byte offsets
 #pragma unroll
     for (int i = 0; i < NPW_HI; ++i) {
         int p = wave + 8 * i;
@@ -510,7 +510,7 @@ __device__ __forceinline__ void gemm8u_bf16_tile(const GemmArgs& a, const int ti
     int voff[NPW];
     int lds_off[NPW];
     constexpr int XPW = BM / 16 / 8;                 // pieces wave + 8 i with i < XPW are X rows for every wave
-    const int pl_x = (int)(a.x_lo * 2), pl_w = (int)(a.w_lo * 2);
+    const int pl_x = (int)(unsigned)(a.x_lo * 2), pl_w = (int)(unsigned)(a.w_lo * 2);
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         const int p = wave + 8 * i;
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
         voff[i] = isx_i ? (int)(((long)r * a.ldx + c * 8) * 2) : (r * a.K + c * 8) * 2;
         lds_off[i] = (isx_i ? 0 : XT) + (isx_i ? p : p - BM / 16) * 1024;
     }
-    const int pl_x = (int)(a.x_lo * 2), pl_w = (int)(a.w_lo * 2);
+    const int pl_x = (int)(unsigned)(a.x_lo * 2), pl_w = (int)(unsigned)(a.w_lo * 2);
     // a tile = two buffer descriptors (X rows from m0, W rows from n0): scalar registers only
     struct TileSrc { __amdgpu_buffer_rsrc_t rx, rw; };
     auto setup = [&](int tile_id, TileSrc& g, int& m0, int& n0) {
@@ -891,9 +891,7 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     int best = 0;
     double best_cost = 1e300;
     for (int i = 0; i < 6; ++i) {
-        if (i >= 3 && !asm_ok) continue;
-        if (cfgs[i].id == 91 && FMT == FMT_F16 && EPI != EPI_F32_RESLN && EPI != EPI_QK) continue;   // fp16: tile 91 exists for these two
-        if (i == 5 && EPI != EPI_BF16 && EPI != EPI_F32) continue;
+        if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, cfgs[i].id))) continue;   // only tiles that exist for this epilogue / format
         const long tm = (a.M + cfgs[i].bm - 1) / cfgs[i].bm, tn = (a.N + cfgs[i].bn - 1) / cfgs[i].bn;
         const long slots = 256L * cfgs[i].per_cu;
         const long rounds = (tm * tn + slots - 1) / slots;
@@ -925,7 +923,12 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
             }
             return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
-        case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 87: case 88: case 89: case 90: case 91: case 95: case 97: case 98: if (gemm_asm_applicable(EPI, a)) { GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm(EPI, b, s); } break;                         // hand-scheduled K loop
+        case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 87: case 88: case 89: case 90: case 91: case 95: case 97: case 98:
+            // hand-scheduled K loop; a forced tile without an instantiation for this epilogue falls back to 128x192 (sylber_hip.h)
+            if (gemm_asm_has_tile(EPI, a, cfg) || (cfg != 60 && cfg != 80 && cfg != 85 && cfg != 90 && cfg != 91 && cfg != 95 && cfg != 97 && gemm_asm_applicable(EPI, a))) {
+                GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm(EPI, b, s);
+            }
+            break;
         case 40: if constexpr (FMT == FMT_BF16) return launch_cfg8u<EPI, ACT, FMT>(a, s); break;                     // unstaggered 8-wave 256x256
         case 41: if constexpr (FMT == FMT_BF16 && EPI == EPI_BF16 && ACT == 0) return launch_cfg8u<EPI, ACT, FMT, true>(a, s); break;   // its trace
         case 30: if constexpr (FMT == FMT_BF16 && (EPI == EPI_BF16 || EPI == EPI_F32_RESLN)) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 10>(a, s); break;   // trace
@@ -955,6 +958,17 @@ static int launch_t(const GemmArgs& a, hipStream_t s) {
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s) {
     if (a.K % 64 != 0 || a.K <= 0 || a.M <= 0 || a.N <= 0) { syl_set_error("launch_gemm_bf16", "K must be a positive multiple of 64"); return 1; }
     if (a.N % 4 != 0) { syl_set_error("launch_gemm_bf16", "N must be a multiple of 4"); return 1; }
+    if (a.fmt == FMT_SPLIT) {
+        // the lo planes are reached through the 32-bit scalar offset of the tile's buffer descriptor (unsigned, range-checked
+        // against 2^32 - 1 records): plane offset + the largest in-tile offset must stay below 2^32 or the X.lo / W.lo passes
+        // would read wrapped addresses.  (~21 M samples per batch on the conv stack; beyond that: split the batch.)
+        const unsigned long long span_x = 256ull * (unsigned long long)a.ldx * 2 + (unsigned long long)a.K * 2;
+        const unsigned long long span_w = 256ull * (unsigned long long)a.K * 2 + (unsigned long long)a.K * 2;
+        if (a.x_lo < 0 || a.w_lo < 0 || (unsigned long long)a.x_lo * 2 + span_x >= (1ull << 32) || (unsigned long long)a.w_lo * 2 + span_w >= (1ull << 32)) {
+            syl_set_error("launch_gemm_bf16", "split16: the lo-plane offset of an operand does not fit the 32-bit buffer offset (batch too large for one launch; split the batch)");
+            return 1;
+        }
+    }
     switch (epi) {
         case EPI_BF16:
             if (a.act == 1) return launch_t<EPI_BF16, 1>(a, s);

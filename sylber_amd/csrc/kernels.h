@@ -52,6 +52,7 @@ bool gemm_rowln_applicable(const GemmArgs& a);
 int launch_gemm_rowln(const GemmArgs& a, hipStream_t s);
 // 256x256 tile, four waves x 128x128, K loop scheduled by hand (gemm_asm.hip, tile id 60)
 bool gemm_asm_applicable(int epi, const GemmArgs& a);
+bool gemm_asm_has_tile(int epi, const GemmArgs& a, int tile);
 int launch_gemm_asm(int epi, const GemmArgs& a, hipStream_t s);
 
 // MXFP8 GEMM (gemm_mxfp8.hip): e4m3 operands [rows][K] with one E8M0 scale per 32 elements along K stored

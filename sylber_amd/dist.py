@@ -136,6 +136,9 @@ class ShardedSegmenter:
         def too_many(n):
             return RuntimeError("an utterance has %d segments, more than max_segments=%d" % (n, k))
         if not self._coll:
+            # the reduction is enqueued on the producing (engine) stream BEFORE the event, so whoever waits for `done` also
+            # sees nmax written; it is handed over like the results (record_stream), or its block could be reused early
+            nmax = nseg[:btot].max()
             done = None
             if self._cuda:
                 done = torch.cuda.Event()
@@ -144,10 +147,11 @@ class ShardedSegmenter:
             def wait1():
                 if done is not None:
                     torch.cuda.current_stream(self.device).wait_event(done)
-                if check and int(nseg[:btot].max()) > k:
-                    raise too_many(int(nseg[:btot].max()))
+                self._hand_over((nmax,))
+                if check and int(nmax) > k:
+                    raise too_many(int(nmax))
                 return self._hand_over(tuple(t[:btot] for t in parts))
-            wait1.nmax = nseg[:btot].max()
+            wait1.nmax = nmax
             return wait1
         fulls, works = [], []
         for t in parts:
@@ -187,7 +191,10 @@ class ShardedSegmenter:
         ``ingest="per-rank"`` (inputs that originate on the host): no scatter; ``host_shards[i]`` is THIS
         rank's ``[Bper, Lmax]`` block of batch i in page-locked host memory and crosses this GPU's own PCIe link
         (asynchronous H2D on the consuming engine's stream); ``batches_root[i]`` then only supplies the shape on root.
-        The gather is unchanged.  The overflow test of ``max_segments`` runs once, after the last step."""
+        The gather is unchanged.  The overflow test of ``max_segments`` runs once, after the last step: a batch yielded
+        EARLIER may therefore carry a table truncated to ``max_segments`` rows (its ``nseg`` row still holds the true count,
+        so ``nseg[i] > max_segments`` identifies it); the error is raised when the generator is exhausted, or by
+        ``close()`` / garbage collection of a generator the consumer abandoned early (``GeneratorExit`` path below)."""
         if ingest not in ("scatter", "per-rank"):
             raise ValueError("ingest must be 'scatter' or 'per-rank'")
         batches = list(batches_root)
@@ -264,26 +271,33 @@ class ShardedSegmenter:
             if wait_fn.nmax is not None:
                 worst = wait_fn.nmax if worst is None else torch.maximum(worst, wait_fn.nmax)
             return out
-        for i in range(n):
-            k = i % E
-            my_wav, my_lens, btot = nxt
-            if i + 1 < n:
-                with on((i + 1) % E):
-                    nxt = scatter_known(i + 1)                           # prefetch the next input
-            with on(k):
-                hidden, seg, nseg, feats = self.compute(my_wav, my_lens, k)
-                wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False)
-            if pending is not None:
-                yield collect(pending)
-            pending = wait
-        last = collect(pending)
+        def overflow_check():
+            # the ONE host synchronisation of the stream of batches: did any utterance overflow the exchanged slots?
+            k = max(1, min(int(max_segments), 1 << 30))
+            if worst is not None and int(worst) > k:
+                raise RuntimeError("an utterance has %d segments, more than max_segments=%d" % (int(worst), k))
+        try:
+            for i in range(n):
+                k = i % E
+                my_wav, my_lens, btot = nxt
+                if i + 1 < n:
+                    with on((i + 1) % E):
+                        nxt = scatter_known(i + 1)                       # prefetch the next input
+                with on(k):
+                    hidden, seg, nseg, feats = self.compute(my_wav, my_lens, k)
+                    wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False)
+                if pending is not None:
+                    yield collect(pending)
+                pending = wait
+            last = collect(pending)
+        except GeneratorExit:
+            # the consumer stopped early: the batches it already holds are still checked (a truncated table must not go unnoticed)
+            overflow_check()
+            raise
         if self._cuda:
             for st in self._streams:
                 torch.cuda.current_stream(self.device).wait_stream(st)
-        # the ONE host synchronisation of the stream of batches: did any utterance overflow the exchanged slots?
-        k = max(1, min(int(max_segments), 1 << 30))
-        if worst is not None and int(worst) > k:
-            raise RuntimeError("an utterance has %d segments, more than max_segments=%d" % (int(worst), k))
+        overflow_check()
         yield last
 
     # ---- reference-shaped API on root ------------------------------------------------------------

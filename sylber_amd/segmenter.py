@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import collections
 import threading
 import weakref
 from pathlib import Path
@@ -64,21 +65,40 @@ class PinnedOutputPool:
 
     GRANULE = 1 << 20
 
-    def __init__(self, max_leased: int = 4):
+    def __init__(self, max_leased: int = 4, alloc=None):
         self.max_leased = int(max_leased)
         self._free: List[torch.Tensor] = []
         self._leased = 0
         self._lock = threading.Lock()
+        # blocks handed back by finalizers.  A finalizer can run at ANY allocation point -- including inside lease() on the
+        # same thread while it holds the (non-reentrant) lock, when a collection frees owner arrays caught in a reference
+        # cycle -- so the release path takes no lock: deque.append is atomic, and lease() drains the deque under the lock
+        self._returned = collections.deque()
+        self._alloc = alloc or (lambda cap: torch.empty(cap, dtype=torch.uint8, pin_memory=True))   # (tests inject pageable memory)
         self.allocations = 0                      # page-locking events so far (tests / bench: must stop growing)
 
     def _release(self, blk: torch.Tensor) -> None:
-        with self._lock:
+        self._returned.append(blk)
+
+    def _drain(self) -> None:                     # (lock held)
+        while True:
+            try:
+                blk = self._returned.popleft()
+            except IndexError:
+                return
             self._leased -= 1
             self._free.append(blk)
+
+    @property
+    def leased(self) -> int:
+        with self._lock:
+            self._drain()
+            return self._leased
 
     def lease(self, nbytes: int):
         """-> (owner ndarray uint8 [cap], block tensor) or None when ``max_leased`` blocks are already out"""
         with self._lock:
+            self._drain()
             if self._leased >= self.max_leased:
                 return None
             pick = None
@@ -92,7 +112,7 @@ class PinnedOutputPool:
         if blk is None:
             cap = (int(nbytes) + self.GRANULE - 1) // self.GRANULE * self.GRANULE
             try:
-                blk = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+                blk = self._alloc(cap)
             except BaseException:
                 with self._lock:
                     self._leased -= 1

@@ -100,6 +100,16 @@ def _worker(rank, world, port, q):
     except RuntimeError as e:
         raised = "max_segments=1" in str(e)
     ok &= raised if rank == 0 else True
+    # a consumer that stops early (every rank after the same step) still gets the overflow error, from close()
+    raised = False
+    g = S.run_stream(batches, lens, max_segments=1)
+    next(g)
+    try:
+        g.close()
+    except RuntimeError as e:
+        raised = "max_segments=1" in str(e)
+    ok &= raised if rank == 0 else True
+    dist.barrier()
     if rank == 0:
         for b, c in zip(streamed, streamed2):
             ok &= all(torch.equal(x, y) for x, y in zip(b, c))

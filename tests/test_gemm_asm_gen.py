@@ -11,15 +11,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_generated_loops_are_current(tmp_path):
     env = dict(os.environ, GEN_GEMM_ASM_OUT=str(tmp_path))
     gen = os.path.join(ROOT, "tools", "gen_gemm_asm.py")
-    subprocess.run([sys.executable, gen, "k64", "0,1,2,3"], check=True, env=env, capture_output=True)
-    subprocess.run([sys.executable, gen, ",".join(str(v) for v in range(19))], check=True, env=env, capture_output=True)
+    subprocess.run([sys.executable, gen, "product"], check=True, env=env, capture_output=True)
     made = sorted(os.listdir(tmp_path))
-    assert len(made) >= 25 and "gemm_asm_x3_w8.inc" in made and "gemm_asm_k64.inc" in made and "gemm_asm_loop.inc" in made
+    assert len(made) >= 7 and "gemm_asm_x3_w8.inc" in made and "gemm_asm_k64.inc" in made and "gemm_asm_loop.inc" in made
     csrc = os.path.join(ROOT, "sylber_amd", "csrc")
     shipped = sorted(f for f in os.listdir(csrc) if f.startswith("gemm_asm") and f.endswith(".inc"))
     assert shipped == made, (set(shipped) ^ set(made))
     for f in made:
         assert filecmp.cmp(os.path.join(tmp_path, f), os.path.join(csrc, f), shallow=False), f
+
+
+def test_experiment_loops_are_generated_not_committed(tmp_path):
+    """the knock-out / schedule variants (timing only, results wrong by construction) are generated into the build directory by a
+    SYLBER_EXPERIMENTS=1 build; none of them lives in csrc/"""
+    env = dict(os.environ, GEN_GEMM_ASM_OUT=str(tmp_path))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gemm_asm.py"), "experiments"], check=True, env=env, capture_output=True)
+    made = sorted(os.listdir(tmp_path))
+    assert len(made) >= 21 and all("_v" in f for f in made), made
+    csrc = os.path.join(ROOT, "sylber_amd", "csrc")
+    assert not [f for f in os.listdir(csrc) if f.startswith("gemm_asm") and "_v" in f]
 
 
 def test_every_loop_keeps_its_hazard_rules():

@@ -198,3 +198,48 @@ def test_two_and_a_half_minute_utterance(S):
     assert out["hidden_states"].shape == (7499, 768) and np.isfinite(out["hidden_states"]).all()
     assert len(out["segments"]) > 100
     _segments_consistent(out, S)
+
+
+def test_pinned_output_pool_behaviour(sd):
+    """the default hand-over of Segmenter.__call__ (leased page-locked blocks, sylber_amd/segmenter.py PinnedOutputPool):
+    page-locking stops after the first calls, results stay intact after later calls, retained results beyond
+    max_pinned_batches fall back to pageable copies, and output_memory="pageable" returns ordinary arrays"""
+    import gc
+    from sylber_amd import Segmenter
+    wavs = [syllable_wave(16000 + 800 * i, 40 + i) for i in range(3)]
+    S2 = Segmenter(model_ckpt=sd, max_pinned_batches=2)
+    first = S2(wav=wavs, in_second=False)
+    keep = [o["hidden_states"].copy() for o in first]
+    for _ in range(5):                                   # dropped results: their block goes back to the pool
+        S2(wav=wavs, in_second=False)
+        gc.collect()
+    assert S2.out_pool.allocations <= 2
+    held = [first, S2(wav=wavs, in_second=False)]        # two batches retained = max_pinned_batches
+    third = S2(wav=wavs, in_second=False)                # no block left: pageable per-utterance copies
+    assert S2.out_pool.leased == 2 and S2.out_pool.allocations <= 2
+    assert third[0]["hidden_states"].base is None or not _is_pool_view(third[0]["hidden_states"], S2)
+    for outs in held + [third]:
+        for o, k in zip(outs, keep):
+            assert np.array_equal(o["hidden_states"], k)  # nothing was overwritten by the later calls
+            _check_contract(o, False)
+            _segments_consistent(o, S2)
+    # one utterance's hidden_states keeps its whole batch block out (documented); dropping the rest does not free it
+    one = held[1][1]["hidden_states"]
+    del held, first, third
+    gc.collect()
+    assert S2.out_pool.leased == 1 and np.array_equal(one, keep[1])
+    del one
+    gc.collect()
+    assert S2.out_pool.leased == 0
+    S3 = Segmenter(model_ckpt=sd, output_memory="pageable")
+    outs = S3(wav=wavs, in_second=False)
+    assert S3.out_pool.allocations == 0
+    for o, k in zip(outs, keep):
+        assert np.array_equal(o["hidden_states"], k)
+
+
+def _is_pool_view(arr, S):
+    base = arr
+    while getattr(base, "base", None) is not None:
+        base = base.base
+    return isinstance(base, np.ndarray) and base.dtype == np.uint8 and base.nbytes % S.out_pool.GRANULE == 0 and base.nbytes >= arr.nbytes and base is not arr

@@ -462,16 +462,37 @@ K64_VARIANTS = {
     3: {"cpol": " sc1"},
 }
 
+def emit_product():
+    """the loops compiled into libsylber_hip.so (committed under sylber_amd/csrc/)"""
+    emit(0)
+    emit_k64(0, {})
+    emit_k64(0, {}, fn=3)
+    emit_k64(0, {}, fn=2, nw=8)
+    emit_x3(4, 4)
+    emit_x3(3, 4)
+    emit_x3(2, 8)
+
+
+def emit_experiments():
+    """knock-out / schedule variants, timing only (results wrong by construction).  Never committed: build.py generates
+    them into sylber_amd/build/gen/ for a SYLBER_EXPERIMENTS=1 build (library name libsylber_hip_exp.so)"""
+    for v in sorted(VARIANTS):
+        if v:
+            emit(v)
+    for v in sorted(K64_VARIANTS):
+        if v:
+            emit_k64(v, K64_VARIANTS[v])
+
+
 if __name__ == "__main__":
     import sys
-    if len(sys.argv) > 1 and sys.argv[1] == "k64":
-        for v in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]):
-            emit_k64(v, K64_VARIANTS[v])
-        emit_k64(0, {}, fn=3)
-        emit_k64(0, {}, fn=2, nw=8)
-        emit_x3(4, 4)
-        emit_x3(3, 4)
-        emit_x3(2, 8)
+    what = sys.argv[1] if len(sys.argv) > 1 else "product"
+    if what == "product":
+        emit_product()
+    elif what == "experiments":
+        if not os.environ.get("GEN_GEMM_ASM_OUT"):
+            OUTDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sylber_amd", "build", "gen")
+        os.makedirs(OUTDIR, exist_ok=True)
+        emit_experiments()
     else:
-        for v in ([int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]):
-            emit(v)
+        raise SystemExit("usage: gen_gemm_asm.py [product|experiments]   (GEN_GEMM_ASM_OUT overrides the directory)")
