@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--fuse-ln", choices=["auto", "on", "off"], default="auto",
                     help="attention out-projection + LayerNorm as one launch (SYLBER_OPT_FUSE_OUTPROJ_LN); A/B switch")
     ap.add_argument("--gemm-tile", type=int, default=-1, help="force one GEMM tile id for every launch that has it (SYLBER_OPT_GEMM_TILE); A/B switch")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="sylber_set_option(KEY, VALUE) on every handle (integers; A/B switches, include/sylber_hip.h)")
     ap.add_argument("--conv0-valu", action="store_true", help="conv layer 0 on the VALU kernel (SYLBER_OPT_CONV0_VALU); A/B switch")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
     ap.add_argument("--agreement-clips", type=int, default=0,
@@ -242,6 +243,10 @@ def main():
     if args.gemm_tile >= 0:
         for e_ in encs:
             e_.set_option(1, args.gemm_tile)
+    for kv in args.opt:
+        key, val = (int(x) for x in kv.split("="))
+        for e_ in encs:
+            e_.set_option(key, val)
     if args.fuse_ln != "auto":
         for e_ in encs:
             e_.set_option(4, 1 if args.fuse_ln == "on" else -1)
@@ -535,7 +540,7 @@ def main():
         # the single dominant instantiation, exactly the row rocprofv3 prints as gemmb_bf16_kernel<0, 1, 0, 0, 2, 8>: the
         # hand-scheduled 256x256 kernel on eight waves with the GELU epilogue (csrc/gemm_asm.hip, tile 95) = conv1..conv5 +
         # 9 x FFN1, persistent with the next tile's first K step requested before the epilogue
-        if clip_samples == CLIP_SAMPLES and B == BATCH_PER_GPU and args.precision == "bf16" and args.gemm_tile < 0:
+        if clip_samples == CLIP_SAMPLES and B == BATCH_PER_GPU and args.precision == "bf16" and args.gemm_tile < 0 and not args.opt:
             big = ["gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_ffn1"]
             n_big = 5 + 9
             ms_big = sum(kernels.get(k, 0.0) for k in big)
