@@ -164,7 +164,8 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      0 = 256x128, 3 = 128x128, 4 = 128x192, 10 = 256x256 8-wave, 11 = 256x192 8-wave;
  *                                      hand-scheduled K loops (csrc/gemm_asm.hip; a launch whose epilogue / K has no such
  *                                      instantiation falls back to 128x192): 80 = 256x256 4-wave, 90 = 256x192, 95 = 256x256
- *                                      8-wave, 85 / 91 / 97 = the same with a three-slot X ring, 60 = the 64-byte-row first cut)
+ *                                      8-wave, 85 / 91 / 97 = the same with a three-slot X ring (91 also requests the fp32 residual rows of out-proj / FFN2 from
+ *                                      inside its K loop when the launch has whole tiles; 96 = 91 without that), 60 = the 64-byte-row first cut)
  *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   32 (automatic choice) or 64
  *   SYLBER_OPT_GEMM_PERSISTENT         0 (automatic): GEMM launches of more than one round run as persistent workgroups
  *                                      walking the tile list (4-wave kernels: two per CU; the 256x256 kernel: one per CU
@@ -173,9 +174,13 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *   SYLBER_OPT_FUSE_OUTPROJ_LN         1: the attention out-projection and the LayerNorm behind it run as ONE launch on
  *                                      full-row tiles (csrc/gemm_rowln.hip; bit-identical outputs) where the shape allows;
  *                                      0 / -1 (default): GEMM launch + LayerNorm launch (faster with two batches in flight)
- *   SYLBER_OPT_CONV0_VALU              1: conv layer 0 of the 16-bit modes on the VALU kernel instead of the matrix-pipe one (A/B switch) */
+ *   SYLBER_OPT_CONV0_VALU              1: conv layer 0 of the 16-bit modes on the VALU kernel instead of the matrix-pipe one (A/B switch)
+ *   SYLBER_OPT_RESLN_PREFETCH          the K loops of the attention out-projection and FFN2 request the rows of the fp32 residual stream
+ *                                      they update while they run (csrc/gemm_asm.hip, bit-identical outputs): 1..3 = fragment columns
+ *                                      (of 3 per wave) prefetched, -1 = none (the epilogue loads them), 0 = the default (1: measured
+ *                                      best with two batches in flight; 3 is best with one, profiles/r04_resln_prefetch.md) */
 enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3, SYLBER_OPT_FUSE_OUTPROJ_LN = 4,
-       SYLBER_OPT_CONV0_VALU = 5 };
+       SYLBER_OPT_CONV0_VALU = 5, SYLBER_OPT_RESLN_PREFETCH = 6 };
 int sylber_set_option(sylber_t h, int32_t key, int32_t value);
 
 /* the `features is not None` branch of resynthesize (segment_synthesis.py:135-140): features_dev [rows, input_dim] frame
@@ -211,6 +216,12 @@ int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_d
 /* the same contraction through the 16-bit output epilogue the conv layers and FFN1 use: c16_dev [M,N] bf16 words */
 int sylber_op_linear16(const float* a_dev, const float* w_dev, const float* bias_dev, uint16_t* c16_dev, int32_t M,
                        int32_t N, int32_t K, int32_t act, int32_t precision, int32_t tile, void* stream);
+/* the residual GEMM of an encoder block (attention out-projection, FFN2; transformers modeling_hubert.py TP:361-397 reached from
+ * sylber/model/sylber.py:122), in place: pre[M,N] (fp32) <- A[M,K] W[N,K]^T + bias + LayerNorm(pre), the LayerNorm re-derived per
+ * element as ((pre - mean) * rstd) * gamma + beta from stats[M,2] = (mean, rstd) and gamma / beta [N] -- the form the forward
+ * uses, where the previous LayerNorm launch stores only its 16-bit output and the row statistics; bf16 operands, tile as above */
+int sylber_op_linear_resln(const float* a_dev, const float* w_dev, const float* bias_dev, float* pre_dev, const float* stats_dev,
+                           const float* gamma_dev, const float* beta_dev, int32_t M, int32_t N, int32_t K, int32_t tile, void* stream);
 /* MXFP8 quantiser used by SYLBER_FP8: x [R,K] fp32 -> data [R,K] e4m3 + E8M0 scales, one per 32 elements along K,
  * stored K-pair-major [K/64, R, 2] (K % 64 == 0; the layout the GEMM's scale fetch wants); the block scale is the
  * smallest power of two 2^e with amax <= 448 * 2^e, elements are x / 2^e rounded to nearest even */

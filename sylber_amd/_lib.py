@@ -57,6 +57,8 @@ EXPORTS = {
                                  c_int32, c_void_p]),
     "sylber_op_linear16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_void_p]),
+    "sylber_op_linear_resln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                       c_int32, c_void_p]),
     "sylber_op_mx_quantize": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "sylber_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "sylber_ingest_num_frames": (c_int64, [c_int64, c_int32]),
@@ -97,6 +99,8 @@ def load() -> ctypes.CDLL:
                 "or `python sylber_amd/build.py`; there is no CPU fallback on the product path." % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in list(EXPORTS.items()) + list(DEV_EXPORTS.items()):
+            if os.environ.get("SYLBER_HIP_LIB") and not hasattr(lib, name):
+                continue                 # an OLDER build loaded for a same-box A/B (tools/ab_*.sh) may lack the newest entry points
             fn = getattr(lib, name)      # AttributeError if the ABI drifted from include/sylber_hip.h
             fn.restype = res
             fn.argtypes = args

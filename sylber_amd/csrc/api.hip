@@ -87,6 +87,7 @@ struct sylber_ctx {
     int opt_gemm_cfg = 0, opt_attn_qw = 0, opt_gemm_persist = 0;   // sylber_set_option (0 = automatic)
     int opt_fuse_ln = 0;                                           // out-projection + LayerNorm in one launch: 0 auto, 1 always, -1 never
     int opt_conv0_valu = 0;                                        // 1: conv0 of the 16-bit modes on the VALU kernel (A/B switch)
+    int opt_resln_pre = 0;                                         // residual prefetch of the out-proj / FFN2 K loops: 0 default, -1 off, 1..3 columns
     bool graph_mode = false;
     std::vector<GraphEntry> graphs; unsigned long long graph_clock = 0;
     // profiling
@@ -273,6 +274,7 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
         case SYLBER_OPT_GEMM_PERSISTENT: c->opt_gemm_persist = value; break;      // < 0: also keep the 256x256 kernel one tile per workgroup
         case SYLBER_OPT_FUSE_OUTPROJ_LN: c->opt_fuse_ln = value > 0 ? 1 : (value < 0 ? -1 : 0); break;
         case SYLBER_OPT_CONV0_VALU: c->opt_conv0_valu = value > 0 ? 1 : 0; break;
+        case SYLBER_OPT_RESLN_PREFETCH: c->opt_resln_pre = value < 0 ? -1 : (value <= 3 ? value : 0); break;
         default: syl_set_error("sylber_set_option", "unknown option key"); return 1;
     }
     if (c->graph_mode) { for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec); c->graphs.clear(); }   // captured launches are stale
@@ -549,7 +551,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
         o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
-        o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist; o.fmt = c->fmt;
+        o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist; o.fmt = c->fmt; o.tune_pre = c->opt_resln_pre;
         o.x_lo = p.lo_ctx; o.w_lo = (long)768 * 768;
         // out-projection + LayerNorm 1 as ONE launch on full-row tiles (gemm_rowln.hip) where the batch fills the chip
         o.out1 = hbf; o.ln_stats_out = stats; o.ln_gamma_out = d.ln1w; o.ln_beta_out = d.ln1b;
@@ -577,7 +579,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         GemmArgs f2 = {};
         f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
         f2.out0 = pre; f2.ld0 = 768; f2.res = pre; f2.ldres = 768; f2.ln_stats = stats; f2.ln_gamma = d.ln1w; f2.ln_beta = d.ln1b;
-        f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist; f2.fmt = c->fmt;
+        f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist; f2.fmt = c->fmt; f2.tune_pre = c->opt_resln_pre;
         f2.x_lo = p.lo_ffn; f2.w_lo = (long)768 * 3072;
         RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RESLN, f2, s));
         }
@@ -812,6 +814,25 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
     g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev; g.act = act;
     g.out0 = c_dev; g.ld0 = N; g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
     if (launch_gemm_bf16(EPI_F32, g, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+// the residual GEMM of an encoder block (attention out-projection, FFN2): pre[M,N] <- A W^T + bias + LayerNorm(pre) in place,
+// the LayerNorm re-derived from the row statistics (mean, rstd) and affine the previous LayerNorm launch left (EPI_F32_RESLN)
+extern "C" int sylber_op_linear_resln(const float* a_dev, const float* w_dev, const float* bias_dev, float* pre_dev,
+                                      const float* stats_dev, const float* gamma_dev, const float* beta_dev, int32_t M, int32_t N,
+                                      int32_t K, int32_t tile, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TmpBuf ab, wb;
+    if (ab.alloc(((size_t)M + 128) * K * 2) || wb.alloc(((size_t)N + 128) * K * 2)) { syl_set_error("sylber_op_linear_resln", "alloc"); return 1; }
+    if (launch_f32_to_bf16(a_dev, (bf16_t*)ab.p, (size_t)M * K, s)) return 1;
+    if (launch_f32_to_bf16(w_dev, (bf16_t*)wb.p, (size_t)N * K, s)) return 1;
+    GemmArgs g = {};
+    g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev;
+    g.out0 = pre_dev; g.ld0 = N; g.res = pre_dev; g.ldres = N; g.ln_stats = stats_dev; g.ln_gamma = gamma_dev; g.ln_beta = beta_dev;
+    g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+    if (launch_gemm_bf16(EPI_F32_RESLN, g, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }

@@ -44,6 +44,7 @@ struct GemmArgs {
     unsigned long long* trace;    // development: per-phase cycle sums of two waves of workgroup 0 (trace instantiation only)
     int tune_cfg;                 // 0 = tile shape chosen by the cost model; k > 0 forces tile configuration k - 1
     int tune_persist;             // > 0: persistent launch (that many workgroups per CU walk the tile list)
+    int tune_pre;                 // residual GEMMs on tile 91: -1 no residual prefetch in the K loop, 1..3 fragment columns prefetched, 0 default
 };
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);

@@ -122,6 +122,22 @@ def test_fused_outproj_layernorm_bitwise(sd):
     assert torch.equal(h.forward(y, lens), g.forward(y, lens))
 
 
+def test_residual_prefetch_option_bitwise(sd):
+    """SYLBER_OPT_RESLN_PREFETCH: the K loops of out-proj / FFN2 requesting 1, 2 or all 3 fragment columns of the fp32 residual rows
+    themselves (csrc/gemm_asm.hip PRE / PC) return bit for bit what the epilogue-loaded form returns, for the full batch"""
+    from sylber_amd import HubertEncoderHIP
+    x = noise_batch(32, 160000, seed=23).cuda()
+    ref = None
+    for v in (-1, 1, 2, 3, 0):
+        e = HubertEncoderHIP(sd)
+        e.set_option(6, v)
+        out = e.forward(x)
+        if ref is None:
+            ref = out
+        assert torch.equal(out, ref), v
+        assert torch.equal(e.forward(x), ref), v
+
+
 def test_long_form_config(enc, sd):
     """BASELINE configs[3] at its stated batch: 8 x 60 s clips (T = 2999: O(T^2) attention, 192k-step GroupNorm).
     At this size the CPU oracle would take minutes, so the full batch is checked through size-independent properties

@@ -199,6 +199,30 @@ def test_linear_persistent_prefetch_kernel(lib, act):
         assert (got - ref).abs().max().item() < 2e-2 and (got - ref).pow(2).mean().sqrt().item() < 3e-3
 
 
+@pytest.mark.parametrize("tile", [4, 90, 91, 96])
+def test_residual_gemm_tiles(lib, tile):
+    """the residual GEMM of an encoder block (out-projection K = 768, FFN2 K = 3072: EPI_F32_RESLN, in place) against torch, and
+    bit for bit against the HIP-scheduled 128x192 kernel -- tile 91 with whole tiles runs the K loop that also prefetches the
+    residual rows into registers (gemm_asm_x3_n3_p4 / _p7), 96 the same tile without it; a ragged M falls back to the plain loop"""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(41)
+    for (M, N, K) in [(16384, 768, 768), (16384, 768, 3072), (4096, 768, 1536), (1000, 768, 768), (512, 384, 1152)]:
+        a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+        pre = torch.randn(M, N, generator=g) * 2.0 + 0.3
+        gamma = 1.0 + 0.2 * torch.randn(N, generator=g); beta = 0.1 * torch.randn(N, generator=g)
+        mean = pre.mean(-1); rstd = (pre.var(-1, unbiased=False) + 1e-5).rsqrt()
+        stats = torch.stack([mean, rstd], -1).contiguous()
+        ad, wd, bd, gd, bed, sd_ = a.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), stats.cuda()
+        outs = []
+        for t in (9004, tile, tile):
+            c = pre.clone().cuda()
+            _lib.check(lib.sylber_op_linear_resln(_p(ad), _p(wd), _p(bd), _p(c), _p(sd_), _p(gd), _p(bed), M, N, K, t, None), "op_linear_resln")
+            outs.append(c)
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), (tile, M, N, K)
+        ref = _bf(a) @ _bf(w).T + b + ((pre - mean[:, None]) * rstd[:, None] * gamma + beta)
+        assert (outs[1].cpu() - ref).abs().max().item() < 3e-3, (tile, M, N, K)
+
+
 @pytest.mark.parametrize("tile", [80, 85, 90, 91, 95, 97])
 def test_asm_tiles_persistent_seams(lib, tile):
     """the hand-scheduled kernels as persistent workgroups (more tiles than CUs: the next tile's operands requested before

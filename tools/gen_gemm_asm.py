@@ -341,8 +341,12 @@ def x3_dma_x(i):
             q(f"buffer_load_dwordx4 %[vo{i}], %[rx], %[kofx] offen lds"))
 
 
-def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False):
+def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
+    """ploads: residual-prefetch loads of this step (asm lines): issued behind the step's LDS-DMA pieces, in the free MFMA gaps of
+    slices 1 and 2, and left outstanding by the step's wait (vm is raised by their number: VMEM retires in order)"""
     FN_ = X3["fn"]
+    ploads = list(ploads)
+    vm = vm + len(ploads)
     nw = X3["nw"]
     nxp, nwp = 32 // nw, X3["bn"] // 8 // nw
     n_mf, n_rd = 4 * FN_, 4 + FN_
@@ -372,6 +376,13 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False):
                 if not queue and bump:
                     after[i].append(q("s_add_u32 %[koff], %[koff], 128"))
                 i += 2
+            if kk >= 1 and ploads:
+                # behind the last DMA piece (slice 1) / behind the fragment reads (slice 2), one load per two MFMAs
+                j = max(i, n_rd) if kk == 1 else n_rd
+                assert not queue
+                while ploads and j < n_mf:
+                    after[j].append(ploads.pop(0))
+                    j += 2
         else:
             after[1].append(q(f"s_waitcnt vmcnt({vm})"))
             after[1].append(q("s_barrier"))
@@ -403,11 +414,18 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False):
                 L.append(f'MF " %[c{fm}{fn}], %[w{S}{fn}], %[x{S}{fm}], {srcc}\\n"')
                 L += after[n]
                 n += 1
-    assert not queue
+    assert not queue and not ploads
     return L
 
 
-def emit_x3(fn=4, nw=4):
+def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0):
+    """pre_e = E > 0: the residual-prefetch form for the fp32-residual epilogue (EPI_F32_RESLN, tile 91): the loop's last 2 E
+    steps are peeled, and the peeled steps plus steps nj-3 and nj-2 carry the 16 FN loads of the wave's residual tile
+    (buffer_load_dwordx4, MFMA C layout: lane = row, 4 columns) into registers that stay live until the epilogue: the 50 MB
+    read of the residual stream rides under the K loop instead of standing, chip-wide, behind it (tools/resln_cost.py: that
+    read costs 9 us with hot and 22 us with cold operands, of a 36 / 58 us out-projection).  Loads retire in order, so each
+    step's wait leaves that step's loads outstanding and the next step's wait collects them: they have one K step to arrive,
+    like the X pieces.  The statement ends with vmcnt(0): the compiler does not know these registers are load results."""
     bn = 64 * fn if nw == 4 else 128 * fn
     X3.update({"fn": fn, "nw": nw, "bn": bn})
     nxp = 32 // nw
@@ -423,26 +441,61 @@ def emit_x3(fn=4, nw=4):
     L.append(q("s_cmp_lg_u32 %[nloop], 0"))
     L.append(q("s_cbranch_scc1 L_gemmx_loop_%="))
     L.append(q("L_gemmx_tail_%=:"))
-    L += x3_step(1, True, True, True, nxp)                   # j = nj - 3: X(nj - 1), first pieces of W(nj - 1)
-    L += x3_step(0, True, False, False, 0)                   # j = nj - 2: rest of W(nj - 1)
+    pre_names = []
+    if pre_e:
+        assert nw == 4
+        # consumption order of the epilogue: fragment column fn outermost, then row block fm, then 4-column run g
+        loads = []
+        pre_cols = pre_cols or fn                            # fragment columns prefetched (the epilogue loads the others itself)
+        for f in range(pre_cols):
+            for m in range(4):
+                for g in range(4):
+                    nm = f"rr{m}{f}{g}"
+                    pre_names.append(nm)
+                    loads.append(q(f"buffer_load_dwordx4 %[{nm}], %[vres], %[rres], %[sres{m}] offen offset:{f * 128 + g * 32}"))
+        nsteps = 2 * pre_e + 2
+        per = [len(loads) // nsteps + (1 if i < len(loads) % nsteps else 0) for i in range(nsteps)]
+        assert max(per) <= 6
+        chunks, k = [], 0
+        for n in per:
+            chunks.append(loads[k:k + n]); k += n
+        for e in range(pre_e):                               # peeled full steps (parities 1, 0, ...)
+            L += x3_step(1, True, True, True, nxp, ploads=chunks[2 * e])
+            L += x3_step(0, True, True, True, nxp, ploads=chunks[2 * e + 1])
+        L += x3_step(1, True, True, True, nxp, ploads=chunks[-2])
+        L += x3_step(0, True, False, False, 0, ploads=chunks[-1])
+    else:
+        L += x3_step(1, True, True, True, nxp)                   # j = nj - 3: X(nj - 1), first pieces of W(nj - 1)
+        L += x3_step(0, True, False, False, 0)                   # j = nj - 2: rest of W(nj - 1)
     L += x3_step(1, False, False, False, 0, nxt=False)       # j = nj - 1
+    if pre_e:
+        L.append(q("s_waitcnt vmcnt(0)"))
     L.append(q("s_barrier"))
     L.append(q("s_nop 15"))
     outs = [f'[c{m}{f}] "=a"(acc[{m}][{f}])' for m in range(4) for f in range(fn)]
+    # residual registers: the LAST 16 runs (consumed last) in the AGPRs the 128x96 wave tile leaves free, the rest in VGPRs (the fewer registers the
+    # kernel holds, the more of the OTHER stream's LayerNorm / conv0 waves fit beside it on the SIMD: bench.py runs two batches in flight)
+    for i, nm in enumerate(pre_names):
+        m, f, g = int(nm[2]), int(nm[3]), int(nm[4])
+        outs.append(f'[{nm}] "=&{"a" if i >= len(pre_names) - 16 else "v"}"(rr[{m}][{f}][{g}])')
     for S in range(2):
         for f in range(4):
             outs.append(f'[x{S}{f}] "=&v"(fx[{S}][{f}])')
         for f in range(fn):
             outs.append(f'[w{S}{f}] "=&v"(fw[{S}][{f}])')
-    outs += [f'[ax{k}] "+v"(axc[{k}])' for k in range(4)]
-    outs += ['[koff] "+s"(koff)', '[nloop] "+s"(nloop)', '[xr] "+s"(xr)', '[xwl] "=&s"(xwl)', '[dlt] "=&s"(dlt)', '[kofx] "=&s"(kofx)']
+    # in/out operands are early-clobber too: an input-only operand that happens to hold the same VALUE as one of them (the
+    # residual block offset 0 and the ring position xr = 0, found the hard way) would otherwise be given the same register
+    outs += [f'[ax{k}] "+&v"(axc[{k}])' for k in range(4)]
+    outs += ['[koff] "+&s"(koff)', '[nloop] "+&s"(nloop)', '[xr] "+&s"(xr)', '[xwl] "=&s"(xwl)', '[dlt] "=&s"(dlt)', '[kofx] "=&s"(kofx)']
     ins = []
     for kk in range(4):
         ins += [f'[aw{kk}] "v"(aw[{kk}])', f'[aw{kk}h] "v"(awh[{kk}])']
     ins += [f'[vo{i}] "v"(voff[{i}])' for i in range((256 + bn) // 8 // nw)]
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)', '[cneg] "s"(cneg)']
+    if pre_e:
+        ins += ['[vres] "v"(vres)', '[rres] "s"(rres)'] + [f'[sres{m}] "s"(sres[{m}])' for m in range(4)]
     here = os.path.dirname(os.path.abspath(__file__))
-    name = "gemm_asm_x3" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + ".inc"
+    name = "gemm_asm_x3" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + (f"_p{pre_e}" + (f"c{pre_cols}" if pre_cols and pre_cols != fn else "") if pre_e else "") + ".inc"
     dst = os.path.join(OUTDIR, name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (X3 ring) -- do not edit; the schedule is documented there.\n")
@@ -471,6 +524,9 @@ def emit_product():
     emit_x3(4, 4)
     emit_x3(3, 4)
     emit_x3(2, 8)
+    for cols in (1, 2, 3):
+        emit_x3(3, 4, pre_e=4, pre_cols=cols)          # K = 768 (12 steps): nothing left in the loop
+        emit_x3(3, 4, pre_e=7, pre_cols=cols)          # K >= 1152 (FFN2, K = 3072: 48 steps, the last 17 unrolled)
 
 
 def emit_experiments():
