@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--fuse-ln", choices=["auto", "on", "off"], default="auto",
                     help="attention out-projection + LayerNorm as one launch (SYLBER_OPT_FUSE_OUTPROJ_LN); A/B switch")
     ap.add_argument("--gemm-tile", type=int, default=-1, help="force one GEMM tile id for every launch that has it (SYLBER_OPT_GEMM_TILE); A/B switch")
+    ap.add_argument("--cu-split", choices=["none", "xcd", "half"], default="none",
+                    help="A/B: give each in-flight batch's main stream its own CUs (hipExtStreamCreateWithCUMask): 'xcd' = whole XCDs "
+                         "(mask bit i -> XCD i %% 8), 'half' = every other CU of every XCD; 2 batches in flight only")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="sylber_set_option(KEY, VALUE) on every handle (integers; A/B switches, include/sylber_hip.h)")
     ap.add_argument("--conv0-valu", action="store_true", help="conv layer 0 on the VALU kernel (SYLBER_OPT_CONV0_VALU); A/B switch")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
@@ -186,6 +189,27 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
     rccl_ranks = 1
     selftest = args.exchange_selftest and world == 1
+    # RCCL's own warnings go to a per-rank file (unless the caller configured NCCL_DEBUG already): a failed or hung exchange
+    # quotes its tail in `exchange_error`
+    nccl_log = None
+    if (selftest or world > 1) and "NCCL_DEBUG" not in os.environ:
+        import tempfile
+        nccl_log = os.path.join(tempfile.gettempdir(), "sylber_bench_rccl_%d_%%h_%%p.log" % os.getpid())
+        os.environ["NCCL_DEBUG"] = "WARN"
+        os.environ["NCCL_DEBUG_FILE"] = nccl_log
+
+    def rccl_warnings(limit=600):
+        if not nccl_log:
+            return ""
+        import glob
+        txt = ""
+        for f in sorted(glob.glob(nccl_log.replace("%h", "*").replace("%p", "*"))):
+            try:
+                txt += open(f, errors="replace").read()
+            except OSError:
+                pass
+        txt = " ".join(ln.strip() for ln in txt.splitlines() if "WARN" in ln or "error" in ln.lower())
+        return txt[-limit:]
     if selftest:
         import datetime
         import socket
@@ -314,6 +338,21 @@ def main():
     # side stream.  Every step is one full pass over one B-clip batch; all work is complete before the closing
     # device synchronize of the timed region.
     streams = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
+    if args.cu_split != "none" and NPIPE == 2:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        streams = []
+        for k in range(2):
+            bits = [(i % 8) // 4 == k if args.cu_split == "xcd" else (i // 8) % 2 == k for i in range(ncu)]
+            words = (ctypes.c_uint32 * ((ncu + 31) // 32))()
+            for i, b in enumerate(bits):
+                if b:
+                    words[i // 32] |= 1 << (i % 32)
+            sp = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(sp), len(words), words)
+            assert rc == 0, "hipExtStreamCreateWithCUMask: %d" % rc
+            streams.append(torch.cuda.ExternalStream(sp.value, device=dev))
     sides = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
     bufs = [(torch.empty(B, T_frames, 768, device=dev),
              (torch.empty(B, T_frames, 2, dtype=torch.int64, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
@@ -440,7 +479,11 @@ def main():
         def on_timeout():
             if rank == 0:
                 fb = build_line(total_audio / r_elapsed, r_elapsed, r_med, False)
-                fb["exchange_error"] = "exchange phase did not finish within %d s (watchdog); value = resident shards" % args.exchange_timeout
+                fb["exchange_error"] = ("exchange phase did not finish within %d s (watchdog); value = resident shards; rank 0 was in: %s"
+                                        % (args.exchange_timeout, sharded.phase))
+                w = rccl_warnings()
+                if w:
+                    fb["exchange_error"] += "; RCCL: " + w
                 sys.stdout.flush()
                 print(json.dumps(fb), flush=True)
             os._exit(0)
@@ -467,7 +510,10 @@ def main():
                 exchange_first = True
                 secondary = ("resident_shards", r_elapsed, r_med)
         except Exception as e:  # noqa: BLE001 - keep a measurable line; the failure is reported in the line itself
-            exchange_error = "%s: %s" % (type(e).__name__, e)
+            exchange_error = "%s: %s; rank %d was in: %s" % (type(e).__name__, e, rank, sharded.phase)
+            w = rccl_warnings()
+            if w:
+                exchange_error += "; RCCL: " + w
         finally:
             dog.cancel()
     value = total_audio / elapsed

@@ -49,6 +49,8 @@ class ShardedSegmenter:
         """counters of ``run_stream`` (what the N > 1 bench line reports): host seconds this rank spent blocked in the
         gather hand-over, bytes it sent / received through the communicator, H2D bytes of the per-rank ingest"""
         self.stats = {"steps": 0, "wait_s": 0.0, "scatter_bytes": 0, "gather_bytes": 0, "h2d_bytes": 0}
+        # what this rank was doing last (a watchdog-tripped bench line names it: "which collective hung")
+        self.phase = "idle"
 
     def _hand_over(self, tensors):
         """results were produced (and allocated) under an engine's side stream; the caller consumes them on ITS current
@@ -240,6 +242,7 @@ class ShardedSegmenter:
                 full = batches[i] if pad == 0 else torch.cat(
                     [batches[i], torch.zeros(pad, lmax, dtype=torch.float32, device=self.device)], 0)
                 chunks = list(full.contiguous().view(W, bper, lmax).unbind(0))
+            self.phase = "scatter of batch %d (root -> ranks, %d bytes per rank)" % (i, my_wav.numel() * 4)
             dist.scatter(my_wav, chunks, src=0, group=self.group)
             return my_wav, mine, btot
 
@@ -265,6 +268,7 @@ class ShardedSegmenter:
         def collect(wait_fn):
             nonlocal worst
             t0 = _time.perf_counter()
+            self.phase = "wait for the gather of batch %d (ranks -> root: hidden states, segment tables, counts, features)" % self.stats["steps"]
             out = wait_fn()
             self.stats["wait_s"] += _time.perf_counter() - t0
             self.stats["steps"] += 1
@@ -284,7 +288,9 @@ class ShardedSegmenter:
                     with on((i + 1) % E):
                         nxt = scatter_known(i + 1)                       # prefetch the next input
                 with on(k):
+                    self.phase = "compute of batch %d (forward + segmentation, engine %d)" % (i, k)
                     hidden, seg, nseg, feats = self.compute(my_wav, my_lens, k)
+                    self.phase = "issue of the asynchronous gather of batch %d" % i
                     wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False)
                 if pending is not None:
                     yield collect(pending)

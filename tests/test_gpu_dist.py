@@ -146,3 +146,22 @@ def test_bench_two_rank_per_rank_ingest():
     assert d["ingest"] == "per-rank" and d["scatter_bytes_per_step_root"] == 0
     assert d["h2d_bytes_per_step_rank0"] == 4 * 32000 * 4
     assert d["gather_bytes_per_step_root"] > 0 and line["value"] > 0
+
+
+def test_watchdog_line_is_complete_and_names_the_phase():
+    """a hung exchange must still yield ONE contract-complete JSON line whose `exchange_error` says which step of the exchange
+    rank 0 was in: the one-rank RCCL self-test with a zero-second watchdog trips it on purpose"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NCCL_DEBUG")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--exchange-selftest", "--exchange-timeout", "0", "--steps", "2",
+                        "--warmup", "1", "--batch", "4", "--clip-seconds", "2", "--no-cpu-baseline", "--no-api"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config"):
+        assert key in line, key
+    assert line["value"] > 0 and "workload" in line["config"]
+    err = line["exchange_error"]
+    assert "watchdog" in err and "rank 0 was in:" in err
+    assert any(w in err for w in ("scatter", "gather", "compute", "idle")), err
