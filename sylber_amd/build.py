@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 EXPERIMENTS = bool(os.environ.get("SYLBER_EXPERIMENTS"))
 LIB = os.path.join(HERE, "libsylber_hip_exp.so" if EXPERIMENTS else "libsylber_hip.so")
 GEN_DIR = os.path.join(HERE, "build", "gen")           # generated experiment loops (never committed)
-SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip", "gemm_rowln.hip", "gemm_asm.hip"]
+SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip", "gemm_rowln.hip", "gemm_asm.hip", "gemm_asm_f8.hip"]
 EXTRA = {"segment.hip": ["-ffp-contract=off"]}
 # -fno-slp-vectorize: NO packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the library.  Measured on
 # MI355X / ROCm 7.2 (profiles/r02_packed_f32_hazard.md): a wave running dependent packed-fp32 chains returns wrong values

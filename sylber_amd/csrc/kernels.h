@@ -69,6 +69,9 @@ struct GemmF8Args {
     uint8_t* out_scale; long os_rows;  // EPI_MXFP8: scales of the output, pitch os_rows
 };
 int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s);   // epi: EPI_MXFP8, EPI_F32, EPI_F32_RESLN, EPI_QK, EPI_V (g.tune_cfg as above)
+// the hand-scheduled X3 loop for MXFP8 operands (gemm_asm_f8.hip): which tile it has for this launch (0 = none), and the launch
+int gemm_asm_f8_tile(int epi, const GemmF8Args& a);
+int launch_gemm_asm_f8(int epi, const GemmF8Args& a, hipStream_t s, int tile);
 int launch_mx_quant_rows(const float* in, long ld_in, uint8_t* out, long ld_out, uint8_t* sc, long sc_rows, int R, int K, hipStream_t s);
 
 // fp32 parity-mode GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), same epilogues on fp32 tensors

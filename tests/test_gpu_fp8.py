@@ -89,6 +89,32 @@ def test_mxfp8_linear_exact_on_integer_data(cfg):
     assert np.array_equal(out.cpu().numpy().astype(np.float64), a.astype(np.float64) @ w.astype(np.float64).T)
 
 
+@pytest.mark.parametrize("cfg,M,N,K", [(85, 512, 768, 768), (91, 512, 768, 768), (85, 256, 256, 512), (91, 768, 384, 3072),
+                                        (85, 1024, 1024, 1024), (91, 16384, 768, 768), (-1, 16384, 3072, 768)])
+def test_mxfp8_asm_loop_tiles(cfg, M, N, K):
+    """the hand-scheduled X3 loop on MXFP8 operands (csrc/gemm_asm_f8.hip, tiles 85 = 256x256 / 91 = 256x192; -1 = the automatic
+    choice, which takes it wherever it applies): EXACT on integer data with power-of-two block scales (any fragment-half, OPSEL,
+    scale-routing or ring mistake is a wrong integer), and on Gaussian data bit for bit the 8-wave kernel of round 1 (same
+    contraction order over K), run to run"""
+    from sylber_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(K + N)
+    a = rng.integers(-3, 4, (M, K)).astype(np.float32) * (2.0 ** rng.integers(-3, 4, (M, K // 32))).repeat(32, 1).astype(np.float32)
+    w = rng.integers(-2, 3, (N, K)).astype(np.float32) * (2.0 ** rng.integers(-2, 3, (N, K // 32))).repeat(32, 1).astype(np.float32)
+    ad, wd = torch.from_numpy(a).cuda(), torch.from_numpy(w).cuda()
+    out = torch.empty(M, N, device="cuda")
+    _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), None, _p(out), M, N, K, 0, 2, cfg, None), "op_linear fp8")
+    assert torch.equal(out.cpu().double(), (ad.double() @ wd.double().T).cpu())
+    g = torch.Generator().manual_seed(M + K)
+    a2 = torch.randn(M, K, generator=g).cuda(); w2 = (torch.randn(N, K, generator=g) * 0.05).cuda(); b2 = torch.randn(N, generator=g).cuda()
+    ref = torch.empty(M, N, device="cuda")
+    _lib.check(lib.sylber_op_linear(_p(a2), _p(w2), _p(b2), _p(ref), M, N, K, 1, 2, 2, None), "op_linear fp8")
+    for _ in range(2):
+        got = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.sylber_op_linear(_p(a2), _p(w2), _p(b2), _p(got), M, N, K, 1, 2, cfg, None), "op_linear fp8")
+        assert torch.equal(got, ref), (cfg, M, N, K)
+
+
 def test_fp8_forward_close_to_bf16():
     from sylber_amd import HubertEncoderHIP
     from sylber_amd.synth import syllable_wave

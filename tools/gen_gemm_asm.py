@@ -508,6 +508,223 @@ def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0):
     print("wrote", os.path.normpath(dst), len(L), "lines")
 
 
+# ======================================================================================================================
+# MXFP8 form of the X3 loop (BASELINE configs[4], gemm_asm_f8.hip): the SAME byte geometry -- 256 rows x 128-byte LDS rows per
+# operand and K step, three X slots, two W slots, one barrier per step, the same LDS-DMA pieces and the same fragment addresses
+# (chunk (2 kk + h) ^ swizzle of a row) -- but a row is 128 e4m3 values, contracted by v_mfma_scale_f32_32x32x64_f8f6f4: a K step is
+# TWO slices of 4 x FN MFMAs of 64 cycles (the bf16 loop: four slices of 32-cycle MFMAs), and the operand of slice s of a fragment
+# is what the bf16 loop reads for kk = 2 s and kk = 2 s + 1: two ds_read_b128 into the halves of ONE 8-register tuple.  An asm
+# operand cannot be addressed by halves, so the fragment registers are literal (v128 .. v255, declared clobbered).
+# Block scales (E8M0, one byte per row and 32 k; memory layout [K / 64][rows][2]): lane (r, h) needs, per fragment and slice, the
+# byte of (its row, K block 2 s + h).  Per step and fragment two 16-bit loads (slice 2 j and 2 j + 1: buffer_load_ushort +
+# byte of (its row, K block 2 s + h).  Per step, fragment and slice ONE buffer_load_ubyte (lane offset = 2 row + h), requested one
+# step ahead at the HEAD of the step -- older than the step's X pieces, so the step's wait covers them (VMEM retires in order); the
+# MFMA selects byte 0.  Scale registers are double-buffered by step parity.
+F8 = {}
+
+
+def f8_xreg(S, fm):
+    b = 128 + S * 32 + fm * 8
+    return b
+
+
+def f8_wreg(S, fn):
+    b = 192 + S * 8 * F8["fn"] + fn * 8
+    return b
+
+
+def f8_reads(S, wslot, s):
+    """the fragment reads of slice s (of the step whose W slot is wslot) into set S: 8 registers per fragment"""
+    out = []
+    h = "h" if wslot else ""
+    for half, kk in enumerate((2 * s, 2 * s + 1)):
+        for f in range(4):
+            b = f8_xreg(S, f) + 4 * half
+            out.append(q(f"ds_read_b128 v[{b}:{b + 3}], %[ax{kk}] offset:{f * 4096}"))
+        for f in range(F8["fn"]):
+            b = f8_wreg(S, f) + 4 * half
+            out.append(q(f"ds_read_b128 v[{b}:{b + 3}], %[aw{kk}{h}] offset:{f * 4096}"))
+    return out
+
+
+def f8_scale_loads(Q):
+    """requests of the next step's scales into register set Q (plus the scalar offsets of its two slices): ONE BYTE per lane,
+    fragment and slice (the lane's own K block: its byte offset carries + h), zero-extended, so the MFMA selects byte 0.
+    (A 16-bit pair per slice merged with buffer_load_short_d16_hi does not work on this part: with SRAM ECC a D16 load
+    clears the other half of its destination.)"""
+    L = [q("s_add_u32 %[ksx1], %[ksx], %[xstep]"), q("s_add_u32 %[ksw1], %[ksw], %[wstep]")]
+    for f in range(4):
+        L.append(q(f"buffer_load_ubyte %[xs{Q}0{f}], %[vsx], %[rxs], %[ksx] offen offset:{f * 64}"))
+        L.append(q(f"buffer_load_ubyte %[xs{Q}1{f}], %[vsx], %[rxs], %[ksx1] offen offset:{f * 64}"))
+    for f in range(F8["fn"]):
+        L.append(q(f"buffer_load_ubyte %[ws{Q}0{f}], %[vsw], %[rws], %[ksw] offen offset:{f * 64}"))
+        L.append(q(f"buffer_load_ubyte %[ws{Q}1{f}], %[vsw], %[rws], %[ksw1] offen offset:{f * 64}"))
+    L += [q("s_add_u32 %[ksx], %[ksx1], %[xstep]"), q("s_add_u32 %[ksw], %[ksw1], %[wstep]")]
+    return L
+
+
+def f8_scale_piece(Q):
+    """LDS-staged scales (256x192 tile: 16 KiB of LDS are free): ONE LDS-DMA piece per wave and step -- wave 0 / 2 the X scales of
+    the next step (256 rows x 2 slices x 2 bytes = 1 KiB: lanes 0-31 slice a, lanes 32-63 slice b), wave 1 / 3 the W scales (same
+    image; the two waves of a pair write identical bytes) -- instead of 2 (4 + FN) byte loads per wave: the texture path works per
+    request, and 14 more requests per step beside 14 LDS-DMA pieces cost a third of the loop's rate."""
+    return [q(f"s_add_u32 m0, %[lsc], {Q * 2048}"),
+            q("s_nop 0"),
+            q("buffer_load_dwordx4 %[vsc], %[rsc], %[ksc] offen lds"),
+            q("s_add_u32 %[ksc], %[ksc], %[scstep]")]
+
+
+def f8_scale_reads(Q):
+    L = []
+    for s_ in range(2):
+        for f in range(4):
+            L.append(q(f"ds_read_u8 %[xs{Q}{s_}{f}], %[axs] offset:{Q * 2048 + s_ * 512 + f * 64}"))
+        for f in range(F8["fn"]):
+            L.append(q(f"ds_read_u8 %[ws{Q}{s_}{f}], %[aws] offset:{Q * 2048 + 1024 + s_ * 512 + f * 64}"))
+    return L
+
+
+def f8_dma_w(i, wslot):
+    nxp = 8
+    return (q(f"s_add_u32 m0, %[lbase], {98304 + wslot * F8['bn'] * 128 + (i - nxp) * 4096}"),
+            q(f"buffer_load_dwordx4 %[vo{i}], %[rw], %[koff] offen lds"))
+
+
+def f8_dma_x(i):
+    return (q(f"s_add_u32 m0, %[xwl], {i * 4096}"),
+            q(f"buffer_load_dwordx4 %[vo{i}], %[rx], %[kofx] offen lds"))
+
+
+def f8_step(par, tail_w, x_next, head, vm, s_next, nxt=True, first=False):
+    """one K step (128 e4m3 per row): parity par = W slot = scale set; s_next: request the scales of the next step"""
+    FN_ = F8["fn"]
+    nxp, nwp = 8, F8["bn"] // 32
+    n_mf, n_rd = 4 * FN_, 2 * (4 + FN_)
+    L = [q(f"; ---- F8 step parity {par}: tail_w {int(tail_w)} x_next {int(x_next)} head {int(head)} vmcnt {vm} scales_next {int(s_next)}")]
+    nh = min(nwp - 1, (n_mf - 3 + 1) // 2)
+    queue = []
+    if tail_w:
+        queue += [f8_dma_w(i, par ^ 1) for i in range(nxp + nh, nxp + nwp)]
+    if x_next:
+        xq = [f8_dma_x(i) for i in range(nxp)]
+        xq[0] = (q("s_add_u32 %[kofx], %[koff], 128") + "\n    " + xq[0][0], xq[0][1])
+        queue += xq
+    bump = tail_w or x_next
+    for s_ in range(2):
+        S = s_
+        after = [[] for _ in range(n_mf)]
+        pre = [[] for _ in range(n_mf)]
+        if s_ == 0:
+            rd = f8_reads(1, par, 1)                           # slice 1 of this step -> set 1
+            for i, r in enumerate(rd):
+                after[min(i, n_mf - 1) if FN_ == 4 else i * n_mf // len(rd)].append(r)
+            if s_next and F8["lds_scales"]:
+                after[0] += f8_scale_piece(par ^ 1)            # older than this step's operand pieces: the step's wait covers it
+            elif s_next:
+                sl = f8_scale_loads(par ^ 1)
+                # all of them behind MFMA 0 and 1: they must be OLDER than this step's LDS-DMA pieces
+                after[0] += sl[:len(sl) // 2]
+                after[1] += sl[len(sl) // 2:]
+            i = 2
+            while queue and i < n_mf:
+                a, b = queue.pop(0)
+                pre[i].append(a)
+                after[i].append(b)
+                if not queue and bump:
+                    after[i].append(q("s_add_u32 %[koff], %[koff], 128"))
+                i += 1 if len(queue) + 1 > (n_mf - i + 1) // 2 else 2
+        else:
+            after[1].append(q(f"s_waitcnt vmcnt({vm})"))
+            after[1].append(q("s_barrier"))
+            if nxt:
+                after[1] += [q("s_add_u32 %[xwl], %[lbase], %[xr]"),
+                             q("s_add_u32 %[xr], %[xr], 0x8000"),
+                             q("s_cmp_eq_u32 %[xr], 0x18000"),
+                             q("s_cselect_b32 %[dlt], %[cneg], 0x8000"),
+                             q("s_cselect_b32 %[xr], 0, %[xr]")]
+                after[1] += [q(f"v_add_u32_e32 %[ax{k}], %[dlt], %[ax{k}]") for k in range(4)]
+                rd = f8_reads(0, par ^ 1, 0)                   # slice 0 of the next step -> set 0
+                if s_next and F8["lds_scales"]:
+                    rd = rd + f8_scale_reads(par ^ 1)           # and its scales (landed: the wait + barrier above)
+                for i, r in enumerate(rd):
+                    after[min(2 + i * (n_mf - 2) // len(rd), n_mf - 1)].append(r)
+            if head:
+                i = 3
+                for p_ in range(nh):
+                    assert i <= n_mf - 1
+                    a, b = f8_dma_w(nxp + p_, par)
+                    pre[i].append(a)
+                    after[i].append(b)
+                    i += 2
+        assert not (s_ == 0 and queue), "slice 0 could not place every LDS-DMA piece"
+        L.append(q("s_waitcnt lgkmcnt(0)"))
+        n = 0
+        for fm in range(4):
+            for fn in range(FN_):
+                L += pre[n]
+                srcc = "0" if (first and s_ == 0) else f"%[c{fm}{fn}]"
+                wb, xb = f8_wreg(S, fn), f8_xreg(S, fm)
+                L.append(q(f"v_mfma_scale_f32_32x32x64_f8f6f4 %[c{fm}{fn}], v[{wb}:{wb + 7}], v[{xb}:{xb + 7}], {srcc}, %[ws{par}{s_}{fn}], %[xs{par}{s_}{fm}] op_sel_hi:[0,0,0]"))
+                L += after[n]
+                n += 1
+    return L
+
+
+def emit_f8(fn=4, lds_scales=False):
+    F8.update({"fn": fn, "bn": 64 * fn, "lds_scales": lds_scales})
+    nxp = 8
+    L = [q("; ---- fragments of (step 0, slice 0)")]
+    L += f8_reads(0, 0, 0)
+    # j = 0: W(1), X(1), X(2), scales(0) came with the prologue.  Its wait is vmcnt(0): the step issues no X pieces, so its
+    # youngest VMEM operations are the scale loads of step 1, which the shifts behind the barrier consume
+    L += f8_step(0, False, False, True, 0, True, first=True)
+    L.append(q("s_cmp_eq_u32 %[nloop], 0"))
+    L.append(q("s_cbranch_scc1 L_gemmf_tail_%="))
+    L.append(q("L_gemmf_loop_%=:"))
+    L += f8_step(1, True, True, True, nxp, True)
+    L += f8_step(0, True, True, True, nxp, True)
+    L.append(q("s_sub_u32 %[nloop], %[nloop], 1"))
+    L.append(q("s_cmp_lg_u32 %[nloop], 0"))
+    L.append(q("s_cbranch_scc1 L_gemmf_loop_%="))
+    L.append(q("L_gemmf_tail_%=:"))
+    L += f8_step(1, True, True, True, nxp, True)                     # j = nj - 3
+    L += f8_step(0, True, False, False, 0, True)                     # j = nj - 2 (scales of the last step)
+    L += f8_step(1, False, False, False, 0, False, nxt=False)        # j = nj - 1
+    L.append(q("s_barrier"))
+    L.append(q("s_nop 15"))
+    outs = [f'[c{m}{f}] "=a"(acc[{m}][{f}])' for m in range(4) for f in range(fn)]
+    for s_ in range(2):
+        outs += [f'[xs0{s_}{f}] "+&v"(xs0[{s_}][{f}])' for f in range(4)] + [f'[ws0{s_}{f}] "+&v"(ws0[{s_}][{f}])' for f in range(fn)]
+    for s_ in range(2):
+        outs += [f'[xs1{s_}{f}] "=&v"(xs1[{s_}][{f}])' for f in range(4)] + [f'[ws1{s_}{f}] "=&v"(ws1[{s_}][{f}])' for f in range(fn)]
+    outs += [f'[ax{k}] "+&v"(axc[{k}])' for k in range(4)]
+    outs += ['[koff] "+&s"(koff)', '[nloop] "+&s"(nloop)', '[xr] "+&s"(xr)', '[xwl] "=&s"(xwl)', '[dlt] "=&s"(dlt)', '[kofx] "=&s"(kofx)']
+    if not F8["lds_scales"]:
+        outs += ['[ksx] "+&s"(ksx)', '[ksw] "+&s"(ksw)', '[ksx1] "=&s"(ksx1)', '[ksw1] "=&s"(ksw1)']
+    ins = []
+    for kk in range(4):
+        ins += [f'[aw{kk}] "v"(aw[{kk}])', f'[aw{kk}h] "v"(awh[{kk}])']
+    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range(8 + 2 * fn)]
+    ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)', '[cneg] "s"(cneg)']
+    if F8["lds_scales"]:
+        outs += ['[ksc] "+&s"(ksc)']
+        ins += ['[vsc] "v"(vsc)', '[rsc] "s"(rsc)', '[scstep] "s"(scstep)', '[lsc] "s"(lsc)', '[axs] "v"(axs)', '[aws] "v"(aws)']
+    else:
+        ins += ['[vsx] "v"(vsx)', '[vsw] "v"(vsw)', '[rxs] "s"(rxs)', '[rws] "s"(rws)', '[xstep] "s"(xstep)', '[wstep] "s"(wstep)']
+    clob = ", ".join(f'"v{r}"' for r in range(128, 192 + 16 * fn))
+    name = "gemm_asm_f8" + ("" if fn == 4 else f"_n{fn}") + ("s" if lds_scales else "") + ".inc"
+    dst = os.path.join(OUTDIR, name)
+    with open(dst, "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py (MXFP8 X3 loop) -- do not edit; the schedule is documented there.\n")
+        f.write("asm volatile(\n")
+        for l in L:
+            f.write("    " + l + "\n")
+        f.write("    : " + ",\n      ".join(outs) + "\n")
+        f.write("    : " + ",\n      ".join(ins) + "\n")
+        f.write('    : "scc", "memory", ' + clob + ");   // m0 is written too (reserved register)\n")
+    print("wrote", os.path.normpath(dst), len(L), "lines")
+
+
 K64_VARIANTS = {
     0: {},
     1: {"nhead": 7, "tail_stride": 1},
@@ -527,6 +744,9 @@ def emit_product():
     for cols in (1, 2, 3):
         emit_x3(3, 4, pre_e=4, pre_cols=cols)          # K = 768 (12 steps): nothing left in the loop
         emit_x3(3, 4, pre_e=7, pre_cols=cols)          # K >= 1152 (FFN2, K = 3072: 48 steps, the last 17 unrolled)
+    emit_f8(4)
+    emit_f8(3)
+    emit_f8(3, lds_scales=True)     # scales through LDS (one DMA piece per wave and step): the long-K launches
 
 
 def emit_experiments():
