@@ -559,7 +559,10 @@ def main():
             1 for k in ("gemm_qkv", "gemm_qk", "gemm_v", "gemm_out", "gemm_ffn1", "gemm_ffn2") if k in kernels)
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_note = None, "no PMC pass committed for these kernel sources"
-        tpath = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))       # the newest round's PMC passes
+        tpath = cands[-1] if cands else os.path.join(ROOT, "profiles", "none.json")
+        tname = os.path.basename(tpath)
         if os.path.exists(tpath) and B == BATCH_PER_GPU and clip_samples == CLIP_SAMPLES and args.precision == "bf16":
             # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 +
             # WRITE_SIZE, separate passes; tools/pmc_traffic.py).  PMC cannot be read live, so the figure is only
@@ -567,10 +570,10 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("csrc_sha16") == csrc_sha16():
                 traffic = round(tj["gemm_family_bytes_per_launch"])
-                traffic_note = "HBM bytes per launch, rocprofv3 PMC (profiles/r03_hbm_traffic.md), same kernel sources"
+                traffic_note = "HBM bytes per launch, rocprofv3 PMC (profiles/%s), same kernel sources" % tname.replace(".json", ".md")
             else:
-                traffic_note = "profiles/r03_hbm_traffic.json was collected with other kernel sources (csrc sha %s != %s)" % (
-                    tj.get("csrc_sha16"), csrc_sha16())
+                traffic_note = "profiles/%s was collected with other kernel sources (csrc sha %s != %s)" % (
+                    tname, tj.get("csrc_sha16"), csrc_sha16())
         roofline = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (all %d launches per forward: 6 implicit-GEMM convs, "
                     "projection, 9 x {qkv, out, ffn1, ffn2})" % n_launch,
                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -583,7 +586,7 @@ def main():
             enc_tf = sum(fl[k] for k in enc_keys) / (enc_ms * 1e-3) / 1e12
             roofline["encoder_gemms"] = {"achieved": round(enc_tf, 1), "frac": round(enc_tf / MFMA_BF16_PEAK_TFLOPS, 4),
                                          "ms_per_forward": round(enc_ms, 4)}
-        # the single dominant instantiation, exactly the row rocprofv3 prints as gemmb_bf16_kernel<0, 1, 0, 0, 2, 8>: the
+        # the single dominant instantiation, exactly the row rocprofv3 prints as gemmb_bf16_kernel<0, 1, 0, 0, 2, 8, true, 0, 3>: the
         # hand-scheduled 256x256 kernel on eight waves with the GELU epilogue (csrc/gemm_asm.hip, tile 95) = conv1..conv5 +
         # 9 x FFN1, persistent with the next tile's first K step requested before the epilogue
         if clip_samples == CLIP_SAMPLES and B == BATCH_PER_GPU and args.precision == "bf16" and args.gemm_tile < 0 and not args.opt:
@@ -593,7 +596,7 @@ def main():
             fl_big = sum(fl[k] for k in big)
             if ms_big > 0:
                 roofline["dominant_instantiation"] = {
-                    "kernel": "gemmb_bf16_kernel<0, 1, 0, 0, 2, 8> (256x256 tile, 8 waves x 128x64, inline-asm K loop over 128-byte LDS rows, "
+                    "kernel": "gemmb_bf16_kernel<0, 1, 0, 0, 2, 8, true, 0, 3> (256x256 tile, 8 waves x 128x64, inline-asm K loop over 128-byte LDS rows, "
                               "GELU + bf16 epilogue, persistent)", "launches_per_forward": n_big,
                     "avg_launch_ms": round(ms_big / n_big, 4), "achieved": round(fl_big / (ms_big * 1e-3) / 1e12, 1),
                     "frac": round(fl_big / (ms_big * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
