@@ -292,6 +292,9 @@ class Segmenter:
         if self.output_memory not in ("pinned", "pageable"):
             raise ValueError("output_memory must be 'pinned' or 'pageable'")
         self.out_pool = PinnedOutputPool(max_leased=int(kwargs.get("max_pinned_batches", 4)))
+        self._fill_threads = max(1, int(kwargs.get("host_pad_threads", 2)))     # host padding of tensor inputs (encode_batch)
+        self._kcap_seen = 128                                                    # largest segment-slot count handed out so far
+        self._overlap_d2h = bool(kwargs.get("overlap_d2h", True))               # hidden-state D2H under the segmenter (A/B switch)
 
     @staticmethod
     def _load_state_dict(model_ckpt, encoding_layer):
@@ -345,12 +348,28 @@ class Segmenter:
             # the intra-op thread pool (128 threads on the MI355X boxes), which made one call cost anything from 10 ms
             # to 1.8 s (tools/api_profile.py: 9.4-9.9 ms with one thread, 9.8-188 ms with the default pool)
             stage_np = stage.numpy()
-            for i, r in enumerate(rows):
-                src = r.detach()
-                stage_np[i, : lengths[i]] = (src if src.dtype == torch.float32 else src.to(torch.float32)).numpy()
-                stage_np[i, lengths[i]:] = 0.0
             batch = torch.empty(len(rows), lmax, dtype=torch.float32, device=dev)
-            batch.copy_(stage, non_blocking=True)
+
+            def fill(lo, hi):
+                for i in range(lo, hi):
+                    src = rows[i].detach()
+                    stage_np[i, : lengths[i]] = (src if src.dtype == torch.float32 else src.to(torch.float32)).numpy()
+                    stage_np[i, lengths[i]:] = 0.0
+            # round 4: the 20 MB host copy of a 32 x 10 s batch is 0.47 ms on one thread, 0.26 ms on two, slower again on four or eight
+            # (probed on the 256-cpu boxes).  Row groups are padded by a small
+            # private thread pool (numpy's copy releases the GIL) and each group crosses PCIe as soon as it is padded, so the
+            # H2D of group g runs under the padding of group g + 1
+            nrow = len(rows)
+            ngrp = min(self._fill_threads, max(1, nrow // 8)) if nrow * lmax >= (1 << 20) else 1
+            if ngrp <= 1:
+                fill(0, nrow)
+                batch.copy_(stage, non_blocking=True)
+            else:
+                bounds = [(g * nrow // ngrp, (g + 1) * nrow // ngrp) for g in range(ngrp)]
+                futs = [self._fill_pool().submit(fill, lo, hi) for lo, hi in bounds]
+                for (lo, hi), f in zip(bounds, futs):
+                    f.result()
+                    batch[lo:hi].copy_(stage[lo:hi], non_blocking=True)
             slot["event"].record(torch.cuda.current_stream(dev))
         else:
             batch = torch.zeros(len(rows), lmax, dtype=torch.float32, device=dev)
@@ -358,6 +377,14 @@ class Segmenter:
                 batch[i, : lengths[i]] = r.to(dev, torch.float32, non_blocking=True)
         hidden = self.speech_model.forward(batch, lengths)
         return hidden, lengths
+
+    def _fill_pool(self):
+        pool = self.__dict__.get("_fill_executor")
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=self._fill_threads, thread_name_prefix="sylber-pad")
+            self._fill_executor = pool
+        return pool
 
     def _stage_buffer(self, shape):
         """next of two grow-only pinned H2D staging buffers; waits (host side) for the copy that last read it"""
@@ -404,15 +431,39 @@ class Segmenter:
     def __call__(self, wav_file=None, wav=None, in_second=True):
         batch_wavs, is_batch = self._collect(wav_file, wav)
         hidden, _ = self.encode_batch(batch_wavs)
-        seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold)
-        # D2H (sylber.py:122-138's .cpu().numpy()): the host waits for the segment counts only, trims segments /
-        # features to the batch's largest count and sends everything asynchronously into ONE leased page-locked block
-        # (PinnedOutputPool: persistent blocks, no page-locking per call).  The numpy results are views of that block --
-        # no second host copy of the 49 MB of hidden states per 32 x 10 s batch -- and the block goes back to the pool
-        # when the caller drops them.
+        # D2H (sylber.py:122-138's .cpu().numpy()) into ONE leased page-locked block (PinnedOutputPool: persistent blocks, no
+        # page-locking per call); the numpy results are views of that block -- no second host copy of the 49 MB of hidden
+        # states per 32 x 10 s batch -- and the block goes back to the pool when the caller drops them.
+        # Round 4: the block is leased BEFORE the segmenter runs, sized for the largest segment-slot count seen so far, so
+        # that the hidden states (the bulk: 0.87 ms over PCIe) leave on a copy stream WHILE boundary detection runs
+        # (0.24 ms + the host's wait for the counts); a batch with more segments than that gets a second block for its
+        # tables (rare, and the sizes repeat from then on).
         dev = hidden.device
         cur = torch.cuda.current_stream(dev)
         B, T, D = hidden.shape
+
+        def al(n):
+            return (n + 255) & ~255
+        hid_bytes = al(B * T * D * 4)
+
+        def sizes(kc):
+            return hid_bytes, hid_bytes + al(B * kc * 2 * 8), hid_bytes + al(B * kc * 2 * 8) + al(B * kc * D * 4)
+        kcap = min(T, self._kcap_seen)
+        o_seg, o_feat, need = sizes(kcap)
+        lease = self.out_pool.lease(need) if self.output_memory == "pinned" else None
+        handed = lease is not None
+        owner, blk = lease if handed else self._scratch_block(need)
+        copy_s = self.__dict__.get("_copy_stream")
+        if copy_s is None or copy_s.device != dev:
+            copy_s = self._copy_stream = torch.cuda.Stream(device=dev)
+        fwd_done = self.__dict__.setdefault("_ev_fwd", torch.cuda.Event())
+        fwd_done.record(cur)
+        if self._overlap_d2h:
+            with torch.cuda.stream(copy_s):
+                copy_s.wait_event(fwd_done)
+                blk[:B * T * D * 4].view(torch.float32).view(B, T, D).copy_(hidden, non_blocking=True)
+            hidden.record_stream(copy_s)
+        seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold)
         nseg_pin = self._nseg_pinned(B)
         nseg_pin.copy_(nseg, non_blocking=True)
         counted = self.__dict__.setdefault("_ev_counts", torch.cuda.Event())
@@ -421,23 +472,27 @@ class Segmenter:
         nseg_h = nseg_pin.numpy().copy()
         nmax = int(nseg_h.max()) if len(nseg_h) else 0
         k = max(nmax, 1)
-        kcap = min(T, (k + 63) & ~63)                        # block sizes repeat from call to call -> the pool reuses them
-
-        def al(n):
-            return (n + 255) & ~255
-        hid_bytes = al(B * T * D * 4)
-        o_seg, o_feat = hid_bytes, hid_bytes + al(B * kcap * 2 * 8)
-        need = o_feat + al(B * kcap * D * 4)
-        lease = self.out_pool.lease(need) if self.output_memory == "pinned" else None
-        handed = lease is not None
-        owner, blk = lease if handed else self._scratch_block(need)
-        blk[:B * T * D * 4].view(torch.float32).view(B, T, D).copy_(hidden, non_blocking=True)
-        blk[o_seg:o_seg + B * k * 2 * 8].view(torch.int64).view(B, k, 2).copy_(seg[:, :k], non_blocking=True)
-        blk[o_feat:o_feat + B * k * D * 4].view(torch.float32).view(B, k, D).copy_(feats[:, :k], non_blocking=True)
+        towner, tblk = owner, blk
+        if k > kcap:                                         # more segments than any batch before: the tables get their own block
+            self._kcap_seen = min(T, (k + 63) & ~63)
+            kcap = self._kcap_seen
+            t_seg, t_feat, t_need = al(0), al(B * kcap * 2 * 8), al(B * kcap * 2 * 8) + al(B * kcap * D * 4)
+            tl = self.out_pool.lease(t_need) if handed else None
+            if tl is not None:
+                towner, tblk = tl
+            else:                                            # pageable mode, or the pool is exhausted: a private pinned bounce block
+                pb = torch.empty(t_need, dtype=torch.uint8, pin_memory=True)
+                towner, tblk = pb.numpy(), pb
+            o_seg, o_feat = t_seg, t_feat
+        if not self._overlap_d2h:
+            blk[:B * T * D * 4].view(torch.float32).view(B, T, D).copy_(hidden, non_blocking=True)
+        tblk[o_seg:o_seg + B * k * 2 * 8].view(torch.int64).view(B, k, 2).copy_(seg[:, :k], non_blocking=True)
+        tblk[o_feat:o_feat + B * k * D * 4].view(torch.float32).view(B, k, D).copy_(feats[:, :k], non_blocking=True)
+        cur.wait_stream(copy_s)
         cur.synchronize()
         hidden_h = owner[:B * T * D * 4].view(np.float32).reshape(B, T, D)
-        seg_h = owner[o_seg:o_seg + B * k * 2 * 8].view(np.int64).reshape(B, k, 2)
-        feats_h = owner[o_feat:o_feat + B * k * D * 4].view(np.float32).reshape(B, k, D)
+        seg_h = towner[o_seg:o_seg + B * k * 2 * 8].view(np.int64).reshape(B, k, 2)
+        feats_h = towner[o_feat:o_feat + B * k * D * 4].view(np.float32).reshape(B, k, D)
         outputs = []
         for i in range(B):
             n = int(nseg_h[i])
