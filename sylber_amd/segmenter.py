@@ -283,6 +283,10 @@ class Segmenter:
         self.speech_model = HubertEncoderHIP(state_dict, num_layers=encoding_layer, device=device,
                                              precision=kwargs.get("precision", "bf16"))
         self.device = str(self.speech_model.device)
+        # __call__ is synchronous: ONE batch in flight on this handle, where the residual GEMMs' K loops prefetching all three
+        # fragment columns of the residual rows is the faster setting (-1.0 % of the forward; with two batches in flight on
+        # two handles, as bench.py's pipeline runs, one column is: profiles/r04_resln_prefetch.md).  Bit-identical either way.
+        self.speech_model.set_option(6, int(kwargs.get("resln_prefetch", 3)))
         self.norm_threshold = norm_threshold
         self.merge_threshold = merge_threshold
         # where __call__'s numpy results live: "pinned" (default) = views of leased page-locked blocks, at most
