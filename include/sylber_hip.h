@@ -216,6 +216,10 @@ int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_d
 /* the same contraction through the 16-bit output epilogue the conv layers and FFN1 use: c16_dev [M,N] bf16 words */
 int sylber_op_linear16(const float* a_dev, const float* w_dev, const float* bias_dev, uint16_t* c16_dev, int32_t M,
                        int32_t N, int32_t K, int32_t act, int32_t precision, int32_t tile, void* stream);
+/* one 3-tap stride-2 layer of the conv feature extractor (transformers modeling_hubert.py TP:160-175: Conv1d(512, 512, 3, stride 2,
+ * bias=False) + GELU) as the 16-bit forward runs it: implicit GEMM over channels-last rows, chunk-major K order, 16-bit out.
+ * x_dev [R, 512] fp32 rows (R >= 2 M + 1), w_host [512 out][512 in][3] fp32 in HOST memory (torch layout), y16_dev [M, 512] bf16 words */
+int sylber_op_conv3(const float* x_dev, const float* w_host, uint16_t* y16_dev, int32_t R, int32_t M, int32_t tile, void* stream);
 /* the residual GEMM of an encoder block (attention out-projection, FFN2; transformers modeling_hubert.py TP:361-397 reached from
  * sylber/model/sylber.py:122), in place: pre[M,N] (fp32) <- A[M,K] W[N,K]^T + bias + LayerNorm(pre), the LayerNorm re-derived per
  * element as ((pre - mean) * rstd) * gamma + beta from stats[M,2] = (mean, rstd) and gamma / beta [N] -- the form the forward

@@ -57,6 +57,7 @@ EXPORTS = {
                                  c_int32, c_void_p]),
     "sylber_op_linear16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_void_p]),
+    "sylber_op_conv3": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "sylber_op_linear_resln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                        c_int32, c_void_p]),
     "sylber_op_mx_quantize": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -137,11 +137,21 @@ extern "C" int sylber_create(const SylberWeights* w, int device, int precision, 
     for (int i = 1; i < 7; ++i) {
         // [o][c][j] -> [o][j*512 + c]: one output position's receptive field is then ONE contiguous
         // run of taps*512 channels-last activations (implicit GEMM with ldx = stride*512)
+        // The 3-tap layers of the 16-bit modes are packed in the chunk-major K order every kernel walks them in (GemmArgs::kpat,
+        // common.h tap3_offset): position o of a weight row holds the input element whose operand-row offset is tap3_offset(o)
         const int k = CK[i];
+        const bool chunk_major = k == 3 && !f32 && c->fmt_conv != FMT_SPLIT;
         std::vector<float> tmp((size_t)512 * k * 512);
         for (int o = 0; o < 512; ++o)
             for (int cc = 0; cc < 512; ++cc)
                 for (int j = 0; j < k; ++j) tmp[((size_t)o * k + j) * 512 + cc] = w->conv_w[i][((size_t)o * 512 + cc) * k + j];
+        if (chunk_major) {
+            std::vector<float> t2(tmp.size());
+            for (int o = 0; o < 512; ++o)
+                for (int pos = 0; pos < 1536; ++pos)
+                    t2[(size_t)o * 1536 + pos] = tmp[(size_t)o * 1536 + tap3_offset(pos * 2) / 2];
+            tmp.swap(t2);
+        }
         o_conv[i] = f32 ? P.add_f32(tmp.data(), tmp.size()) : P.add_bf16(tmp.data(), tmp.size());
     }
     P.fmt = c->fmt;                                      // everything after the conv stack
@@ -473,6 +483,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = split ? ACT_GELU_ERF7 : ACT_GELU_FAST;
         a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.fmt = c->fmt_conv;
         a.x_lo = src_lo; a.w_lo = (long)512 * CK[i] * 512; a.out_lo = dst_lo;
+        a.kpat = (CK[i] == 3 && c->fmt_conv != FMT_SPLIT) ? 1 : 0;      // chunk-major K order (weights packed to match at create)
         static const char* nm[7] = {"", "gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_conv6"};
         RUN(nm[i], launch_gemm_bf16(EPI_BF16, a, s));
         bf16_t* t = src; src = dst; dst = t;
@@ -837,6 +848,31 @@ extern "C" int sylber_op_linear_resln(const float* a_dev, const float* w_dev, co
     return 0;
 }
 
+// one 3-tap stride-2 conv layer of the feature extractor as the 16-bit forward runs it (implicit GEMM over channels-last rows in
+// the chunk-major K order, GELU, 16-bit out): x [R, 512] fp32 rows (R >= 2 M + 1), w [512 out][512 in][3] fp32 (torch Conv1d
+// layout), y16 [M, 512] bf16 words, y[m] = gelu(sum_{t, c} w[:, c, t] x[2 m + t, c])
+extern "C" int sylber_op_conv3(const float* x_dev, const float* w_host, uint16_t* y16_dev, int32_t R, int32_t M, int32_t tile, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (M < 1 || R < 2 * M + 1) { syl_set_error("sylber_op_conv3", "need R >= 2 M + 1 input rows"); return 1; }
+    TmpBuf xb, wb;
+    if (xb.alloc(((size_t)R + 130) * 512 * 2) || wb.alloc((size_t)512 * 1536 * 2)) { syl_set_error("sylber_op_conv3", "alloc"); return 1; }
+    HIP_TRY(hipMemsetAsync(xb.p, 0, ((size_t)R + 130) * 512 * 2, s));
+    if (launch_f32_to_bf16(x_dev, (bf16_t*)xb.p, (size_t)R * 512, s)) return 1;
+    std::vector<bf16_t> wp((size_t)512 * 1536);
+    for (int o = 0; o < 512; ++o)
+        for (int pos = 0; pos < 1536; ++pos) {
+            const int e = tap3_offset(pos * 2) / 2, t = e / 512, cc = e % 512;     // operand-row element = (tap t, channel cc)
+            wp[(size_t)o * 1536 + pos] = f2bf(w_host[((size_t)o * 512 + cc) * 3 + t]);
+        }
+    HIP_TRY(hipMemcpyAsync(wb.p, wp.data(), wp.size() * 2, hipMemcpyHostToDevice, s));
+    GemmArgs g = {};
+    g.X = (bf16_t*)xb.p; g.ldx = 1024; g.W = (bf16_t*)wb.p; g.M = M; g.N = 512; g.K = 1536; g.act = ACT_GELU_FAST; g.kpat = 1;
+    g.out0 = y16_dev; g.ld0 = 512; g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+    if (launch_gemm_bf16(EPI_BF16, g, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
 // the same GEMM with its 16-bit output epilogue (EPI_BF16: what the conv layers and FFN1 run): C16 = bf16 / fp16 words
 extern "C" int sylber_op_linear16(const float* a_dev, const float* w_dev, const float* bias_dev, uint16_t* c16_dev, int32_t M,
                                   int32_t N, int32_t K, int32_t act, int32_t precision, int32_t tile, void* stream) {
@@ -962,6 +998,8 @@ static int gemm_bench_f8(int M, int N, int K, int epi, int act, int cfg, int ite
 static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg, int32_t iters,
                            float* ms_out, unsigned long long* g_gemm_trace_out) {
     if (cfg >= 100 && cfg < 200) return gemm_bench_f8(M, N, K, epi, act, cfg - 100, iters, ms_out);
+    const bool kpat = cfg >= 350000;                      // cfg + 400000: the 3-tap conv layers' chunk-major K order (K = 1536, ldx = 1024)
+    if (kpat) cfg -= 400000;
     const bool cold = cfg >= 150000;                      // cfg + 200000: operands flushed out of the caches before every launch
     if (cold) cfg -= 200000;
     TmpBuf xb, wb, ob, rb, bb;
@@ -974,7 +1012,7 @@ static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t
     HIP_TRY(hipMemset(rb.p, 0, (size_t)M * N * 4)); HIP_TRY(hipMemset(bb.p, 0, (size_t)N * 4));
     GemmArgs g = {};
     g.X = (bf16_t*)xb.p; g.ldx = ldx; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = (float*)bb.p; g.act = act;
-    g.out0 = ob.p; g.ld0 = N; g.res = (float*)rb.p; g.ldres = N;
+    g.out0 = ob.p; g.ld0 = N; g.res = (float*)rb.p; g.ldres = N; g.kpat = kpat ? 1 : 0;
     TmpBuf lnb;
     if (epi == EPI_F32_RESLN) {
         if (lnb.alloc((size_t)M * 8 + (size_t)N * 8)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }

@@ -206,6 +206,17 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
     return (unsigned)w;
 }
 
+// ---- K order of the 3-tap stride-2 conv layers (GemmArgs::kpat) --------------------------------------------------------------
+// The operand row of output frame m is ONE run of 3 x 512 channels-last values starting at input frame 2 m; its third tap is the
+// first tap of frame m + 1.  Walked tap by tap, a tile re-reads those shared rows a 512-channel sweep later, when the XCD's L2 has
+// long dropped them (profiles/r04_conv_fetch_account.md: 1.5x over-fetch).  Walked chunk-major -- for each 64-channel chunk: tap 0,
+// tap 2, tap 1 -- the re-read follows one K step later.  Byte position o of that walk (128 bytes per chunk-tap) -> byte offset
+// inside the operand row.  Every kernel that runs these layers uses this one order (results must not depend on the tile shape).
+__host__ __device__ __forceinline__ int tap3_offset(int o) {
+    const int q = o >> 7, c = q / 3, i = q - 3 * c;
+    return (c << 7) + (i == 0 ? 0 : (i == 1 ? 2048 : 1024)) + (o & 127);
+}
+
 // ---- wave64 reductions ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

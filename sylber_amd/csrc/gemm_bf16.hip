@@ -96,7 +96,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     // accumulator; a k-tile index beyond K / BK selects the plane through the scalar offset only
     const int ntk = a.K / BK;
     auto ksoff = [&](int kt, bool isx_i) -> int {
-        if constexpr (FMT != FMT_SPLIT) return kt * (BK * 2);
+        if constexpr (FMT != FMT_SPLIT) return (a.kpat && isx_i) ? tap3_offset(kt * (BK * 2)) : kt * (BK * 2);
         else {
             const int seg = (kt >= ntk ? 1 : 0) + (kt >= 2 * ntk ? 1 : 0);
             return (kt - seg * ntk) * (BK * 2) + (seg == (isx_i ? 1 : 2) ? (isx_i ? pl_x : pl_w) : 0);
@@ -345,7 +345,7 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     }
     const int ntk = a.K / 32;                        // FMT_SPLIT: three K segments, see gemm_bf16_tile
     auto ksoff = [&](int ks, bool isx_i) -> int {
-        if constexpr (FMT != FMT_SPLIT) return ks * 64;
+        if constexpr (FMT != FMT_SPLIT) return (a.kpat && isx_i) ? tap3_offset(ks * 64) : ks * 64;
         else {
             const int seg = (ks >= ntk ? 1 : 0) + (ks >= 2 * ntk ? 1 : 0);
             return (ks - seg * ntk) * 64 + (seg == (isx_i ? 1 : 2) ? (isx_i ? pl_x : pl_w) : 0);
@@ -523,7 +523,7 @@ __device__ __forceinline__ void gemm8u_bf16_tile(const GemmArgs& a, const int ti
     }
     const int ntk = a.K / 32;
     auto ksoff = [&](int ks, bool isx_i) -> int {
-        if constexpr (FMT != FMT_SPLIT) return ks * 64;
+        if constexpr (FMT != FMT_SPLIT) return (a.kpat && isx_i) ? tap3_offset(ks * 64) : ks * 64;
         else {
             const int seg = (ks >= ntk ? 1 : 0) + (ks >= 2 * ntk ? 1 : 0);
             return (ks - seg * ntk) * 64 + (seg == (isx_i ? 1 : 2) ? (isx_i ? pl_x : pl_w) : 0);
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
         g.rw = make_rsrc(a.W + (size_t)n0 * a.K);
     };
     auto ksoff = [&](int ks, bool isx_i) -> int {
-        if constexpr (FMT != FMT_SPLIT) return ks * 64;
+        if constexpr (FMT != FMT_SPLIT) return (a.kpat && isx_i) ? tap3_offset(ks * 64) : ks * 64;
         else {
             const int seg = (ks >= ntk ? 1 : 0) + (ks >= 2 * ntk ? 1 : 0);
             return (ks - seg * ntk) * 64 + (seg == (isx_i ? 1 : 2) ? (isx_i ? pl_x : pl_w) : 0);

@@ -44,6 +44,8 @@ struct GemmArgs {
     unsigned long long* trace;    // development: per-phase cycle sums of two waves of workgroup 0 (trace instantiation only)
     int tune_cfg;                 // 0 = tile shape chosen by the cost model; k > 0 forces tile configuration k - 1
     int tune_persist;             // > 0: persistent launch (that many workgroups per CU walk the tile list)
+    int kpat;                     // 1: the 3-tap stride-2 conv layers' chunk-major K order (K = 1536, 512 channels): W is packed
+                                  // [out][64-channel chunk][tap 0, 2, 1][64] and the X byte offset of K position o follows tap3_offset(o)
     int tune_pre;                 // residual GEMMs on tile 91: -1 no residual prefetch in the K loop, 1..3 fragment columns prefetched, 0 default
 };
 

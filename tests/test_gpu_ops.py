@@ -199,6 +199,32 @@ def test_linear_persistent_prefetch_kernel(lib, act):
         assert (got - ref).abs().max().item() < 2e-2 and (got - ref).pow(2).mean().sqrt().item() < 3e-3
 
 
+def test_conv3_layer_every_tile(lib):
+    """a 3-tap stride-2 conv layer of the feature extractor (TP:160-175) as the forward runs it -- implicit GEMM in the chunk-major
+    K order (GemmArgs::kpat: tap 0, tap 2, tap 1 per 64-channel chunk) -- against torch's conv1d, and bit for bit the same on every
+    kernel that can run it: the 8-wave asm tile (97, the K order in generated asm), the hipcc-scheduled tiles (3, 4, 10, 11, 40) and
+    a forced asm tile without that order (85 -> documented fallback): results must not depend on the tile a batch size picks"""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    for M in (70000, 3000, 257):
+        R = 2 * M + 1
+        x = torch.randn(R, 512, generator=g)
+        w = torch.randn(512, 512, 3, generator=g) / (3 * 512) ** 0.5
+        xd = x.cuda()
+        wc = w.contiguous()
+        outs = {}
+        for tile in (9010, 97, 3, 4, 11, 40, 85, -1):
+            y = torch.full((M, 512), -1, dtype=torch.int16, device="cuda")
+            _lib.check(lib.sylber_op_conv3(_p(xd), ctypes.c_void_p(wc.data_ptr()), _p(y), R, M, tile, None), "op_conv3")
+            outs[tile] = y
+            assert torch.equal(y, outs[9010]), (M, tile)
+        rows = torch.randint(0, M, (256,))
+        got = outs[97][rows.cuda()].view(torch.bfloat16).float().cpu()
+        xr = torch.stack([_bf(x[2 * rows + t]) for t in range(3)], -1)            # [256, 512 in, 3]
+        ref = torch.nn.functional.gelu(torch.einsum("rct,oct->ro", xr, _bf(w)))
+        assert (got - ref).abs().max().item() < 2e-2 and (got - ref).pow(2).mean().sqrt().item() < 3e-3, M
+
+
 @pytest.mark.parametrize("tile", [4, 90, 91, 96])
 def test_residual_gemm_tiles(lib, tile):
     """the residual GEMM of an encoder block (out-projection K = 768, FFN2 K = 3072: EPI_F32_RESLN, in place) against torch, and

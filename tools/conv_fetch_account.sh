@@ -13,7 +13,9 @@ SH[conv1_n512_overlap]="524288 512 1536 1024 0 1 200097"
 SH[conv1_n256_overlap]="524288 256 1536 1024 0 1 200097"
 SH[conv1_n512_norows]="524288 512 1536 1536 0 1 200097"
 SH[conv1_n256_norows]="524288 256 1536 1536 0 1 200097"
-for name in conv1_n512_overlap conv1_n256_overlap conv1_n512_norows conv1_n256_norows; do
+SH[conv1_n512_chunkmajor]="524288 512 1536 1024 0 1 600097"
+SH[conv1_n256_chunkmajor]="524288 256 1536 1024 0 1 600097"
+for name in conv1_n512_overlap conv1_n256_overlap conv1_n512_norows conv1_n256_norows conv1_n512_chunkmajor conv1_n256_chunkmajor; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$name -- python $ROOT/tools/gemm_bench_one.py ${SH[$name]} > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name '*counter_collection.csv' | head -1)
   python - "$name" "$f" "${SH[$name]}" <<'PY'

@@ -341,6 +341,21 @@ def x3_dma_x(i):
             q(f"buffer_load_dwordx4 %[vo{i}], %[rx], %[kofx] offen lds"))
 
 
+def x3_tap_update():
+    """conv 3-tap chunk-major K order (X3["tap"]): the X byte offset of K step s is 128 (s / 3) + (0, 2048, 1024)[s % 3] -- for each
+    64-channel chunk: tap 0, tap 2, tap 1 -- so that the rows tap 2 of output row m shares with tap 0 of row m + 1 are re-read ONE
+    step later (L2-hot) instead of 8-16 steps later (profiles/r04_conv_fetch_account.md: the 1.5x over-fetch of the conv GEMMs).
+    kofx is carried (not derived from koff), ph = step mod 3 of the step kofx points at."""
+    return [q("s_cmp_eq_u32 %[ph], 0"),
+            q("s_cselect_b32 %[dk], %[c2048], %[cm1024]"),
+            q("s_cmp_eq_u32 %[ph], 2"),
+            q("s_cselect_b32 %[dk], %[cm896], %[dk]"),
+            q("s_add_u32 %[kofx], %[kofx], %[dk]"),
+            q("s_add_u32 %[ph], %[ph], 1"),
+            q("s_cmp_eq_u32 %[ph], 3"),
+            q("s_cselect_b32 %[ph], 0, %[ph]")]
+
+
 def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
     """ploads: residual-prefetch loads of this step (asm lines): issued behind the step's LDS-DMA pieces, in the free MFMA gaps of
     slices 1 and 2, and left outstanding by the step's wait (vm is raised by their number: VMEM retires in order)"""
@@ -357,7 +372,8 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
         queue += [x3_dma_w(i, par ^ 1) for i in range(nxp + nh, nxp + nwp)]
     if x_next:
         xq = [x3_dma_x(i) for i in range(nxp)]
-        xq[0] = (q("s_add_u32 %[kofx], %[koff], 128") + "\n    " + xq[0][0], xq[0][1])
+        if not X3.get("tap"):
+            xq[0] = (q("s_add_u32 %[kofx], %[koff], 128") + "\n    " + xq[0][0], xq[0][1])
         queue += xq
     bump = tail_w or x_next
     for kk in range(4):
@@ -375,6 +391,8 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
                 after[i].append(b)
                 if not queue and bump:
                     after[i].append(q("s_add_u32 %[koff], %[koff], 128"))
+                    if x_next and X3.get("tap"):
+                        after[i] += x3_tap_update()
                 i += 2
             if kk >= 1 and ploads:
                 # behind the last DMA piece (slice 1) / behind the fragment reads (slice 2), one load per two MFMAs
@@ -418,7 +436,7 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
     return L
 
 
-def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0):
+def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0, tap=False):
     """pre_e = E > 0: the residual-prefetch form for the fp32-residual epilogue (EPI_F32_RESLN, tile 91): the loop's last 2 E
     steps are peeled, and the peeled steps plus steps nj-3 and nj-2 carry the 16 FN loads of the wave's residual tile
     (buffer_load_dwordx4, MFMA C layout: lane = row, 4 columns) into registers that stay live until the epilogue: the 50 MB
@@ -427,7 +445,7 @@ def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0):
     step's wait leaves that step's loads outstanding and the next step's wait collects them: they have one K step to arrive,
     like the X pieces.  The statement ends with vmcnt(0): the compiler does not know these registers are load results."""
     bn = 64 * fn if nw == 4 else 128 * fn
-    X3.update({"fn": fn, "nw": nw, "bn": bn})
+    X3.update({"fn": fn, "nw": nw, "bn": bn, "tap": tap})
     nxp = 32 // nw
     L = [q("; ---- fragments of (step 0, slice 0)")]
     L += x3_reads(0, 0, 0)
@@ -486,16 +504,19 @@ def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0):
     # in/out operands are early-clobber too: an input-only operand that happens to hold the same VALUE as one of them (the
     # residual block offset 0 and the ring position xr = 0, found the hard way) would otherwise be given the same register
     outs += [f'[ax{k}] "+&v"(axc[{k}])' for k in range(4)]
-    outs += ['[koff] "+&s"(koff)', '[nloop] "+&s"(nloop)', '[xr] "+&s"(xr)', '[xwl] "=&s"(xwl)', '[dlt] "=&s"(dlt)', '[kofx] "=&s"(kofx)']
+    outs += ['[koff] "+&s"(koff)', '[nloop] "+&s"(nloop)', '[xr] "+&s"(xr)', '[xwl] "=&s"(xwl)', '[dlt] "=&s"(dlt)']
+    outs += ['[kofx] "+&s"(kofx)', '[ph] "+&s"(ph)', '[dk] "=&s"(dk)'] if tap else ['[kofx] "=&s"(kofx)']
     ins = []
     for kk in range(4):
         ins += [f'[aw{kk}] "v"(aw[{kk}])', f'[aw{kk}h] "v"(awh[{kk}])']
     ins += [f'[vo{i}] "v"(voff[{i}])' for i in range((256 + bn) // 8 // nw)]
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)', '[cneg] "s"(cneg)']
+    if tap:
+        ins += ['[c2048] "s"(c2048)', '[cm1024] "s"(cm1024)', '[cm896] "s"(cm896)']
     if pre_e:
         ins += ['[vres] "v"(vres)', '[rres] "s"(rres)'] + [f'[sres{m}] "s"(sres[{m}])' for m in range(4)]
     here = os.path.dirname(os.path.abspath(__file__))
-    name = "gemm_asm_x3" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + (f"_p{pre_e}" + (f"c{pre_cols}" if pre_cols and pre_cols != fn else "") if pre_e else "") + ".inc"
+    name = "gemm_asm_x3" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + (f"_p{pre_e}" + (f"c{pre_cols}" if pre_cols and pre_cols != fn else "") if pre_e else "") + ("_t" if tap else "") + ".inc"
     dst = os.path.join(OUTDIR, name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (X3 ring) -- do not edit; the schedule is documented there.\n")
@@ -741,6 +762,7 @@ def emit_product():
     emit_x3(4, 4)
     emit_x3(3, 4)
     emit_x3(2, 8)
+    emit_x3(2, 8, tap=True)          # the 3-tap conv layers: chunk-major K order (tap 0, tap 2, tap 1 per 64-channel chunk)
     for cols in (1, 2, 3):
         emit_x3(3, 4, pre_e=4, pre_cols=cols)          # K = 768 (12 steps): nothing left in the loop
         emit_x3(3, 4, pre_e=7, pre_cols=cols)          # K >= 1152 (FFN2, K = 3072: 48 steps, the last 17 unrolled)
