@@ -164,7 +164,7 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      0 = 256x128, 3 = 128x128, 4 = 128x192, 10 = 256x256 8-wave, 11 = 256x192 8-wave;
  *                                      hand-scheduled K loops (csrc/gemm_asm.hip; a launch whose epilogue / K has no such
  *                                      instantiation falls back to 128x192): 80 = 256x256 4-wave, 90 = 256x192, 95 = 256x256
- *                                      8-wave, 85 / 91 / 97 = the same with a three-slot X ring (91 also requests the fp32 residual rows of out-proj / FFN2 from
+ *                                      8-wave, 85 / 91 / 97 = the same with a three-slot X ring, 86 = that ring on a 256x128 tile / four waves (91 also requests the fp32 residual rows of out-proj / FFN2 from
  *                                      inside its K loop when the launch has whole tiles; 96 = 91 without that), 60 = the 64-byte-row first cut)
  *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   32 (automatic choice) or 64
  *   SYLBER_OPT_GEMM_PERSISTENT         0 (automatic): GEMM launches of more than one round run as persistent workgroups

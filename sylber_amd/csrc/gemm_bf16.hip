@@ -885,14 +885,17 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     // 95: the same loop on eight waves (two per SIMD share the epilogue's VALU work): the GELU GEMMs, K = 768 included.
     // 85 / 91 / 97 = 80 / 90 / 95 with three ring slots for X (bf16 only): never slower hot, 5-15 % faster on cold activations
     const bool x3 = FMT != FMT_SPLIT;
-    const Cfg cfgs[6] = {{3, 128, 128, 2, 0.93}, {4, 128, 192, 2, 1.00}, {10, 256, 256, 1, 1.20},
+    // 86 = the X3 loop on a 256x128 tile / four waves: slower per FLOP than 97 (923 vs 974 TF on conv1), but a launch of 64 row tiles
+    // x 512 columns (conv6) fills 256 CUs with it and half of them with 256x256 tiles: 22.0 vs 29.7 us
+    const Cfg cfgs[7] = {{3, 128, 128, 2, 0.93}, {4, 128, 192, 2, 1.00}, {10, 256, 256, 1, 1.20},
                          {x3 ? 85 : 80, 256, 256, 1, long_k ? 1.28 : 1.10}, {91, 256, 192, 1, long_k ? 1.10 : 1.04},
-                         {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27}};
+                         {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27}, {86, 256, 128, 1, 1.10}};
     int best = 0;
     double best_cost = 1e300;
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 7; ++i) {
         if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, cfgs[i].id))) continue;   // only tiles that exist for this epilogue / format
         const long tm = (a.M + cfgs[i].bm - 1) / cfgs[i].bm, tn = (a.N + cfgs[i].bn - 1) / cfgs[i].bn;
+        if (cfgs[i].id == 86 && tm * tn < 192) continue;    // (measured for launches that fill the chip; small batches keep their tiles)
         const long slots = 256L * cfgs[i].per_cu;
         const long rounds = (tm * tn + slots - 1) / slots;
         const double cost = (double)rounds * cfgs[i].per_cu * cfgs[i].bm * cfgs[i].bn / cfgs[i].eff;
@@ -923,9 +926,9 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
             }
             return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
-        case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 87: case 88: case 89: case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 98:
+        case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 86: case 87: case 88: case 89: case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 98:
             // hand-scheduled K loop; a forced tile without an instantiation for this epilogue falls back to 128x192 (sylber_hip.h)
-            if (gemm_asm_has_tile(EPI, a, cfg) || (cfg != 60 && cfg != 80 && cfg != 85 && cfg != 90 && cfg != 91 && cfg != 95 && cfg != 96 && cfg != 97 && gemm_asm_applicable(EPI, a))) {
+            if (gemm_asm_has_tile(EPI, a, cfg) || (cfg != 60 && cfg != 80 && cfg != 85 && cfg != 86 && cfg != 90 && cfg != 91 && cfg != 95 && cfg != 96 && cfg != 97 && gemm_asm_applicable(EPI, a))) {
                 GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm(EPI, b, s);
             }
             break;

@@ -249,7 +249,7 @@ def test_residual_gemm_tiles(lib, tile):
         assert (outs[1].cpu() - ref).abs().max().item() < 3e-3, (tile, M, N, K)
 
 
-@pytest.mark.parametrize("tile", [80, 85, 90, 91, 95, 97])
+@pytest.mark.parametrize("tile", [80, 85, 86, 90, 91, 95, 97])
 def test_asm_tiles_persistent_seams(lib, tile):
     """the hand-scheduled kernels as persistent workgroups (more tiles than CUs: the next tile's operands requested before
     the epilogue, counted waits across its stores) return bit for bit what the HIP 8-wave kernel returns, with whole tiles

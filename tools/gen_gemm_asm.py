@@ -376,6 +376,7 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
             xq[0] = (q("s_add_u32 %[kofx], %[koff], 128") + "\n    " + xq[0][0], xq[0][1])
         queue += xq
     bump = tail_w or x_next
+    npieces_01 = len(queue)
     for kk in range(4):
         S = kk & 1
         after = [[] for _ in range(n_mf)]
@@ -385,6 +386,8 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
             for i in range(n_rd):
                 after[i].append(rd[i])
             i = 1 if kk == 0 else 0
+            # one piece per two MFMAs where the two slices have room for that, else one per MFMA (wave tile 128x64 on four waves)
+            stride = 2 if (n_mf - 1 + 1) // 2 + (n_mf + 1) // 2 >= npieces_01 else 1
             while queue and i < n_mf and kk < 2:
                 a, b = queue.pop(0)
                 pre[i].append(a)
@@ -393,7 +396,7 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
                     after[i].append(q("s_add_u32 %[koff], %[koff], 128"))
                     if x_next and X3.get("tap"):
                         after[i] += x3_tap_update()
-                i += 2
+                i += stride
             if kk >= 1 and ploads:
                 # behind the last DMA piece (slice 1) / behind the fragment reads (slice 2), one load per two MFMAs
                 j = max(i, n_rd) if kk == 1 else n_rd
@@ -763,6 +766,8 @@ def emit_product():
     emit_x3(3, 4)
     emit_x3(2, 8)
     emit_x3(2, 8, tap=True)          # the 3-tap conv layers: chunk-major K order (tap 0, tap 2, tap 1 per 64-channel chunk)
+    emit_x3(2, 4)                    # 256x128 tile on four waves (wave tile 128x64): the loop of the ping-pong kernel's groups
+    emit_x3(2, 4, tap=True)
     for cols in (1, 2, 3):
         emit_x3(3, 4, pre_e=4, pre_cols=cols)          # K = 768 (12 steps): nothing left in the loop
         emit_x3(3, 4, pre_e=7, pre_cols=cols)          # K >= 1152 (FFN2, K = 3072: 48 steps, the last 17 unrolled)
