@@ -76,6 +76,8 @@ def parse_args():
                          "(mask bit i -> XCD i %% 8), 'half' = every other CU of every XCD; 2 batches in flight only")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="sylber_set_option(KEY, VALUE) on every handle (integers; A/B switches, include/sylber_hip.h)")
     ap.add_argument("--conv0-valu", action="store_true", help="conv layer 0 on the VALU kernel (SYLBER_OPT_CONV0_VALU); A/B switch")
+    ap.add_argument("--skip-segment", action="store_true",
+                    help="A/B switch: leave boundary detection out of the timed steps (the line is marked `invalid`)")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
     ap.add_argument("--agreement-clips", type=int, default=0,
                     help="also report bf16-vs-fp32 segment agreement on this many synthetic clips (fp32 parity mode as truth)")
@@ -372,7 +374,8 @@ def main():
                     main_s.wait_event(seg_done[k])      # the segmenter that last read this buffer set has finished
                 encs[k].forward(my_batch, lengths, out=hidden)
                 if args.no_overlap:
-                    encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
+                    if not args.skip_segment:
+                        encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record(main_s)
                     evs.append(ev)
@@ -381,7 +384,8 @@ def main():
                 ready.record(main_s)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
+                if not args.skip_segment:
+                    encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(side)
             seg_done[k] = ev
@@ -668,6 +672,8 @@ def main():
             line["exchange_error"] = exchange_error
         if agreement is not None:
             line["segment_agreement"] = agreement
+        if args.skip_segment:
+            line["invalid"] = "--skip-segment: boundary detection left out of the timed steps (A/B measurement only)"
     if world > 1 or selftest:
         dist.barrier()
         dist.destroy_process_group()
