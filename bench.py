@@ -76,6 +76,9 @@ def parse_args():
                          "(mask bit i -> XCD i %% 8), 'half' = every other CU of every XCD; 2 batches in flight only")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="sylber_set_option(KEY, VALUE) on every handle (integers; A/B switches, include/sylber_hip.h)")
     ap.add_argument("--conv0-valu", action="store_true", help="conv layer 0 on the VALU kernel (SYLBER_OPT_CONV0_VALU); A/B switch")
+    ap.add_argument("--out-sets", type=int, default=0,
+                    help="output buffer sets of the resident steps (default = 2 x batches in flight; minimum = batches in flight): with "
+                         "only one set per handle, a forward waits for the boundary detection of the step that last used its handle")
     ap.add_argument("--skip-segment", action="store_true",
                     help="A/B switch: leave boundary detection out of the timed steps (the line is marked `invalid`)")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
@@ -356,22 +359,26 @@ def main():
             assert rc == 0, "hipExtStreamCreateWithCUMask: %d" % rc
             streams.append(torch.cuda.ExternalStream(sp.value, device=dev))
     sides = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
+    # two output sets per batch in flight: with one, forward(i + NPIPE) has to wait for the boundary detection of step i (a
+    # ~0.25 ms latency-bound kernel on 32 CUs) before it may overwrite hidden_states -- measured 4.87 -> 4.81 ms per step
+    NSETS = max(NPIPE, args.out_sets if args.out_sets > 0 else 2 * NPIPE)
     bufs = [(torch.empty(B, T_frames, 768, device=dev),
              (torch.empty(B, T_frames, 2, dtype=torch.int64, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
-              torch.empty(B, T_frames, 768, device=dev))) for _ in range(NPIPE)]
-    seg_done = [None] * NPIPE
+              torch.empty(B, T_frames, 768, device=dev))) for _ in range(NSETS)]
+    seg_done = [None] * NSETS
     state = {"i": 0}
 
     def resident_steps(n):
         evs = []
         for _ in range(n):
             k = state["i"] % NPIPE
+            ks = state["i"] % NSETS
             state["i"] += 1
-            hidden, seg_out = bufs[k]
+            hidden, seg_out = bufs[ks]
             main_s, side = streams[k], sides[k]
             with torch.cuda.stream(main_s):
-                if seg_done[k] is not None:
-                    main_s.wait_event(seg_done[k])      # the segmenter that last read this buffer set has finished
+                if seg_done[ks] is not None:
+                    main_s.wait_event(seg_done[ks])     # the segmenter that last read this buffer set has finished
                 encs[k].forward(my_batch, lengths, out=hidden)
                 if args.no_overlap:
                     if not args.skip_segment:
@@ -388,7 +395,7 @@ def main():
                     encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(side)
-            seg_done[k] = ev
+            seg_done[ks] = ev
             evs.append(ev)
         return evs
 
@@ -456,7 +463,8 @@ def main():
                                                                         " [one-rank RCCL self-test of the N>1 path]" if selftest else ""),
                        "rccl_ranks": rccl_ranks,
                        "pipelining": "%d batch(es) in flight on independent handles/streams%s" % (
-                           NPIPE, "" if (exchange_first_ or args.no_overlap) else "; segmenter on a side stream"),
+                           NPIPE, "; segmenter on a side stream" if not args.no_overlap else "") + (
+                           "" if (exchange_first_ or args.no_overlap) else ", %d output sets" % NSETS),
                        "gflop_per_clip": 124.65 if clip_samples == CLIP_SAMPLES else None},
             "roofline": roofline_, "roofline_frontend": frontend_, "cpu_baseline": cpu_, "api_level": api_,
             "kernel_ms_per_forward": kernels_ or {},

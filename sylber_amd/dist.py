@@ -29,7 +29,7 @@ class ShardedSegmenter:
     own HIP stream: the memory-bound phases of one batch then run under the MFMA phases of the other."""
 
     def __init__(self, engine, norm_threshold: float = 2.6, merge_threshold: float = 0.8, group=None,
-                 always_collective: bool = False):
+                 always_collective: bool = False, segment_on_side_stream: bool = True):
         self.engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
         self.engine = self.engines[0]
         self.norm_threshold = norm_threshold
@@ -43,6 +43,10 @@ class ShardedSegmenter:
         self._coll = self.world > 1 or (always_collective and dist.is_initialized())
         self._cuda = torch.device(self.device).type == "cuda"
         self._streams = [torch.cuda.Stream(device=self.device) for _ in self.engines] if self._cuda else None
+        # boundary detection (one workgroup per utterance, ~0.25 ms of latency on 32 CUs) and the gather that follows it run
+        # on a second stream per engine: the engine's next forward then does not queue behind them
+        # (segment_on_side_stream=False keeps both on the engine stream: A/B switch)
+        self._sides = ([torch.cuda.Stream(device=self.device) for _ in self.engines] if segment_on_side_stream else list(self._streams)) if self._cuda else None
         self.reset_stats()
 
     def reset_stats(self) -> None:
@@ -255,6 +259,9 @@ class ShardedSegmenter:
         def on(k):
             return torch.cuda.stream(self._streams[k]) if self._cuda else contextlib.nullcontext()
 
+        def on_side(k):
+            return torch.cuda.stream(self._sides[k]) if self._cuda else contextlib.nullcontext()
+
         if self._cuda:
             cur = torch.cuda.current_stream(self.device)
             for st in self._streams:
@@ -288,8 +295,19 @@ class ShardedSegmenter:
                     with on((i + 1) % E):
                         nxt = scatter_known(i + 1)                       # prefetch the next input
                 with on(k):
-                    self.phase = "compute of batch %d (forward + segmentation, engine %d)" % (i, k)
-                    hidden, seg, nseg, feats = self.compute(my_wav, my_lens, k)
+                    self.phase = "compute of batch %d (forward, engine %d)" % (i, k)
+                    eng = self.engines[k]
+                    hidden = eng.forward(my_wav, [int(x) for x in my_lens])
+                    ready = None
+                    if self._cuda:
+                        ready = torch.cuda.Event()
+                        ready.record(self._streams[k])
+                with on_side(k):
+                    if ready is not None:
+                        self._sides[k].wait_event(ready)
+                        hidden.record_stream(self._sides[k])             # allocated under the engine stream, read here
+                    self.phase = "segmentation of batch %d (engine %d, side stream)" % (i, k)
+                    seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold)
                     self.phase = "issue of the asynchronous gather of batch %d" % i
                     wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False)
                 if pending is not None:
@@ -301,7 +319,7 @@ class ShardedSegmenter:
             overflow_check()
             raise
         if self._cuda:
-            for st in self._streams:
+            for st in self._streams + self._sides:
                 torch.cuda.current_stream(self.device).wait_stream(st)
         overflow_check()
         yield last
