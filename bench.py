@@ -79,6 +79,7 @@ def parse_args():
     ap.add_argument("--out-sets", type=int, default=0,
                     help="output buffer sets of the resident steps (default = 2 x batches in flight; minimum = batches in flight): with "
                          "only one set per handle, a forward waits for the boundary detection of the step that last used its handle")
+    ap.add_argument("--plain-streams", action="store_true", help="A/B switch: take the pipeline's streams from the pool without the hardware-queue probe")
     ap.add_argument("--skip-segment", action="store_true",
                     help="A/B switch: leave boundary detection out of the timed steps (the line is marked `invalid`)")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
@@ -342,7 +343,11 @@ def main():
     # of consecutive batches overlap on the chip; boundary detection of batch i (one workgroup per utterance) runs on a
     # side stream.  Every step is one full pass over one B-clip batch; all work is complete before the closing
     # device synchronize of the timed region.
-    streams = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
+    # HIP streams are multiplexed onto 4 hardware queues; two streams on the same queue run one after the other, so the
+    # streams of the pipeline are PROBED for concurrency (sylber_amd/streams.py) instead of taken as they come
+    from sylber_amd.streams import concurrent_streams
+    pool_st = concurrent_streams(2 * NPIPE, dev) if not args.plain_streams else [torch.cuda.Stream(device=dev) for _ in range(2 * NPIPE)]
+    streams = pool_st[:NPIPE]
     if args.cu_split != "none" and NPIPE == 2:
         import ctypes
         hip = ctypes.CDLL("libamdhip64.so")
@@ -358,7 +363,7 @@ def main():
             rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(sp), len(words), words)
             assert rc == 0, "hipExtStreamCreateWithCUMask: %d" % rc
             streams.append(torch.cuda.ExternalStream(sp.value, device=dev))
-    sides = [torch.cuda.Stream(device=dev) for _ in range(NPIPE)]
+    sides = pool_st[NPIPE:]
     # two output sets per batch in flight: with one, forward(i + NPIPE) has to wait for the boundary detection of step i (a
     # ~0.25 ms latency-bound kernel on 32 CUs) before it may overwrite hidden_states -- measured 4.87 -> 4.81 ms per step
     NSETS = max(NPIPE, args.out_sets if args.out_sets > 0 else 2 * NPIPE)

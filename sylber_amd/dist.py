@@ -42,11 +42,16 @@ class ShardedSegmenter:
         # anyway (scatter / gather to self) so that the RCCL code path can be exercised on a one-GPU box
         self._coll = self.world > 1 or (always_collective and dist.is_initialized())
         self._cuda = torch.device(self.device).type == "cuda"
-        self._streams = [torch.cuda.Stream(device=self.device) for _ in self.engines] if self._cuda else None
+        # streams that share a hardware queue run one after the other (sylber_amd/streams.py): probe for independent ones
+        pool = None
+        if self._cuda:
+            from .streams import concurrent_streams
+            pool = concurrent_streams(2 * len(self.engines), self.device)
+        self._streams = pool[:len(self.engines)] if self._cuda else None
         # boundary detection (one workgroup per utterance, ~0.25 ms of latency on 32 CUs) and the gather that follows it run
         # on a second stream per engine: the engine's next forward then does not queue behind them
         # (segment_on_side_stream=False keeps both on the engine stream: A/B switch)
-        self._sides = ([torch.cuda.Stream(device=self.device) for _ in self.engines] if segment_on_side_stream else list(self._streams)) if self._cuda else None
+        self._sides = (pool[len(self.engines):] if segment_on_side_stream else list(self._streams)) if self._cuda else None
         self.reset_stats()
 
     def reset_stats(self) -> None:

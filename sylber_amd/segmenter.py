@@ -7,6 +7,7 @@ import ctypes
 import os
 import collections
 import threading
+import time
 import weakref
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence, Union
@@ -286,7 +287,8 @@ class Segmenter:
         # __call__ is synchronous: ONE batch in flight on this handle, where the residual GEMMs' K loops prefetching all three
         # fragment columns of the residual rows is the faster setting (-1.0 % of the forward; with two batches in flight on
         # two handles, as bench.py's pipeline runs, one column is: profiles/r04_resln_prefetch.md).  Bit-identical either way.
-        self.speech_model.set_option(6, int(kwargs.get("resln_prefetch", 3)))
+        self._resln_prefetch = int(kwargs.get("resln_prefetch", 3))
+        self.speech_model.set_option(6, self._resln_prefetch)
         self.norm_threshold = norm_threshold
         self.merge_threshold = merge_threshold
         # where __call__'s numpy results live: "pinned" (default) = views of leased page-locked blocks, at most
@@ -330,9 +332,8 @@ class Segmenter:
             batch_wavs = wav if is_batch else [wav]
         return batch_wavs, is_batch
 
-    def encode_batch(self, batch_wavs: Sequence[torch.Tensor]):
-        """Pads to the batch max (sylber.py:93-118) and runs the HIP forward.  Returns the device
-        hidden states [B,T,768] (full padded T, like the reference) and the per-row lengths."""
+    @staticmethod
+    def _rows(batch_wavs: Sequence[torch.Tensor]):
         rows, lengths = [], []
         for w in batch_wavs:
             if not torch.is_tensor(w) or w.dim() != 2:
@@ -340,6 +341,12 @@ class Segmenter:
             for ch in range(w.shape[0]):              # torch.cat(dim=0) makes every channel a batch row
                 rows.append(w[ch])
                 lengths.append(int(w.shape[1]))
+        return rows, lengths
+
+    def encode_batch(self, batch_wavs: Sequence[torch.Tensor]):
+        """Pads to the batch max (sylber.py:93-118) and runs the HIP forward.  Returns the device
+        hidden states [B,T,768] (full padded T, like the reference) and the per-row lengths."""
+        rows, lengths = self._rows(batch_wavs)
         lmax = max(lengths)
         dev = self.speech_model.device
         if all(not r.is_cuda for r in rows):
@@ -433,8 +440,12 @@ class Segmenter:
         return features, segments, avg_fts
 
     def __call__(self, wav_file=None, wav=None, in_second=True):
+        tr = self.__dict__.get("_trace")                     # tools/api_timeline.py: list of (label, host time) marks
+        mark = (lambda name: tr.append((name, time.perf_counter()))) if tr is not None else (lambda name: None)
+        mark("enter")
         batch_wavs, is_batch = self._collect(wav_file, wav)
         hidden, _ = self.encode_batch(batch_wavs)
+        mark("padded, H2D and forward issued")
         # D2H (sylber.py:122-138's .cpu().numpy()) into ONE leased page-locked block (PinnedOutputPool: persistent blocks, no
         # page-locking per call); the numpy results are views of that block -- no second host copy of the 49 MB of hidden
         # states per 32 x 10 s batch -- and the block goes back to the pool when the caller drops them.
@@ -472,7 +483,9 @@ class Segmenter:
         nseg_pin.copy_(nseg, non_blocking=True)
         counted = self.__dict__.setdefault("_ev_counts", torch.cuda.Event())
         counted.record(cur)
+        mark("lease, segmenter issued")
         counted.synchronize()                                # the counts are on the host
+        mark("counts on the host (forward + boundary detection done)")
         nseg_h = nseg_pin.numpy().copy()
         nmax = int(nseg_h.max()) if len(nseg_h) else 0
         k = max(nmax, 1)
@@ -494,6 +507,7 @@ class Segmenter:
         tblk[o_feat:o_feat + B * k * D * 4].view(torch.float32).view(B, k, D).copy_(feats[:, :k], non_blocking=True)
         cur.wait_stream(copy_s)
         cur.synchronize()
+        mark("all D2H done")
         hidden_h = owner[:B * T * D * 4].view(np.float32).reshape(B, T, D)
         seg_h = towner[o_seg:o_seg + B * k * 2 * 8].view(np.int64).reshape(B, k, 2)
         feats_h = towner[o_feat:o_feat + B * k * D * 4].view(np.float32).reshape(B, k, D)
@@ -503,9 +517,11 @@ class Segmenter:
             segments = seg_h[i, :n].copy() if n > 0 else np.array([])
             outputs.append({
                 "segments": segments * 1.0 / FRAME_RATE if in_second else segments,
-                "segment_features": feats_h[i, :n].copy() if n > 0 else np.array([]),
+                # (a view of the leased block, like hidden_states; a scratch block is reused by the next call, so its rows are copied)
+                "segment_features": (feats_h[i, :n] if handed else feats_h[i, :n].copy()) if n > 0 else np.array([]),
                 "hidden_states": hidden_h[i] if handed else hidden_h[i].copy(),
             })
+        mark("dicts built")
         return outputs if is_batch else outputs[0]
 
     def _nseg_pinned(self, B: int) -> torch.Tensor:

@@ -1,0 +1,70 @@
+"""HIP streams that really run concurrently.
+
+ROCm multiplexes a process's HIP streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default); two streams that
+land on the SAME hardware queue execute strictly one after the other, whatever the program's dependencies say.  Which streams
+share a queue depends on the order in which the process first used its streams (measured on MI355X / ROCm 7.2,
+tools/stream_queue_probe.py: of ten pool streams, {0,7} {1,6,null} {2,5,9} {3,4,8} serialise).  A two-batches-in-flight
+pipeline whose two compute streams share a queue silently degenerates into one batch at a time: the first ``Segmenter`` of a
+process ran its two half-batches back to back (8.0 ms per call), every later one overlapped them (7.1 ms).
+
+``concurrent_streams`` therefore PROBES: it draws streams from PyTorch's pool and keeps those on which two spin kernels
+(``torch.cuda._sleep``) finish in the time of one against every stream already kept.
+"""
+from __future__ import annotations
+
+import time
+from typing import List, Optional, Sequence
+
+import torch
+
+_PROBE_CYCLES = 250_000          # ~0.1 ms on MI355X: long against launch + synchronise jitter, short enough to be free
+
+
+def _pair_ms(a: torch.cuda.Stream, b: Optional[torch.cuda.Stream], device) -> float:
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(_PROBE_CYCLES)
+        if b is not None:
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(_PROBE_CYCLES)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def serialised(a: torch.cuda.Stream, b: torch.cuda.Stream, device=None) -> bool:
+    """True when kernels on ``a`` and ``b`` run one after the other (same hardware queue)"""
+    device = a.device if device is None else device
+    one = _pair_ms(a, None, device)
+    return _pair_ms(a, b, device) > 1.5 * one
+
+
+def concurrent_streams(n: int, device, avoid: Sequence[torch.cuda.Stream] = (), candidates: int = 16) -> List[torch.cuda.Stream]:
+    """``n`` streams on ``device`` that run concurrently with each other and with every stream in ``avoid``.  Best effort: with
+    fewer hardware queues than requested (or without ``torch.cuda._sleep``) the remaining slots are filled with plain pool
+    streams -- correct, just not concurrent."""
+    device = torch.device(device)
+    drawn = [torch.cuda.Stream(device=device) for _ in range(max(candidates, n))]
+    if not hasattr(torch.cuda, "_sleep") or n <= 0:
+        return drawn[:n]
+    with torch.cuda.device(device):
+        for s in drawn:                                   # a stream gets its hardware queue when it is first used
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(1000)
+        torch.cuda.synchronize(device)
+        kept: List[torch.cuda.Stream] = []
+        for s in drawn:
+            if len(kept) == n:
+                break
+            if all(not serialised(s, o, device) for o in list(avoid) + kept):
+                kept.append(s)
+        for s in drawn:                                   # not enough independent queues: fill up
+            if len(kept) == n:
+                break
+            if s not in kept:
+                kept.append(s)
+    return kept

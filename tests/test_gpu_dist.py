@@ -165,3 +165,15 @@ def test_watchdog_line_is_complete_and_names_the_phase():
     err = line["exchange_error"]
     assert "watchdog" in err and "rank 0 was in:" in err
     assert any(w in err for w in ("scatter", "gather", "compute", "idle")), err
+
+
+def test_pipeline_streams_are_on_different_hardware_queues():
+    """sylber_amd/streams.py: the streams the two-batches-in-flight pipelines use must run kernels concurrently (HIP streams that
+    share a hardware queue run one after the other, whatever the program's dependencies say)"""
+    import torch
+    from sylber_amd.streams import concurrent_streams, serialised
+    st = concurrent_streams(4, "cuda:0")
+    assert len(st) == 4 and len({s.cuda_stream for s in st}) == 4
+    assert not serialised(st[0], st[1])                      # the two compute streams
+    assert sum(serialised(st[i], st[j]) for i in range(4) for j in range(i + 1, 4)) <= 1   # (4 hardware queues by default)
+    assert serialised(st[0], st[0])                          # the probe itself: one stream against itself is serial

@@ -1,0 +1,23 @@
+"""host timeline of one Segmenter.__call__ (32 x 10 s host tensors): where the call's milliseconds go"""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sylber_amd import Segmenter
+from sylber_amd.synth import noise_batch
+from sylber_amd.weights import synthetic_state_dict
+S = Segmenter(model_ckpt=synthetic_state_dict(0))
+wavs = [w[None, :].clone() for w in noise_batch(32, 160000, seed=1000)]
+for _ in range(3):
+    S(wav=wavs)
+runs = []
+for _ in range(15):
+    S._trace = []
+    out = S(wav=wavs)
+    runs.append(S._trace)
+    del out
+names = [n for n, _ in runs[0]]
+for i in range(1, len(names)):
+    d = [(r[i][1] - r[i - 1][1]) * 1e3 for r in runs]
+    print("%-58s median %.2f  min %.2f  max %.2f ms" % (names[i], statistics.median(d), min(d), max(d)))
+tot = [(r[-1][1] - r[0][1]) * 1e3 for r in runs]
+print("%-58s median %.2f" % ("total", statistics.median(tot)))
