@@ -342,6 +342,8 @@ def main():
         # time is the distance to the completion P steps later, divided by P
         P = max(1, NPIPE)
         gaps = [evs[i].elapsed_time(evs[i + P]) / P for i in range(len(evs) - P)] if evs and len(evs) > P else []
+        if os.environ.get("SYLBER_BENCH_DEBUG") and evs:
+            sys.stderr.write("step completion times (ms after the first): %s\n" % [round(evs[0].elapsed_time(e), 2) for e in evs])
         return elapsed, (statistics.median(gaps) if gaps else None)
 
     # ---- resident shards: NPIPE encoder handles (own workspace + HIP stream) take the steps round-robin, so kernels
