@@ -178,9 +178,13 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *   SYLBER_OPT_RESLN_PREFETCH          the K loops of the attention out-projection and FFN2 request the rows of the fp32 residual stream
  *                                      they update while they run (csrc/gemm_asm.hip, bit-identical outputs): 1..3 = fragment columns
  *                                      (of 3 per wave) prefetched, -1 = none (the epilogue loads them), 0 = the default (1: measured
- *                                      best with two batches in flight; 3 is best with one, profiles/r04_resln_prefetch.md) */
+ *                                      best with two batches in flight; 3 is best with one, profiles/r04_resln_prefetch.md)
+ *   SYLBER_OPT_FP8_ATTENTION           SYLBER_FP8 only: 1 (and 0 = the default) = the attention core on MXFP8 operands too -- the q / k / v projection
+ *                                      quantises its outputs (e4m3, one power-of-two scale per 32 features of q / k and per 32 keys of v),
+ *                                      P is e4m3: BASELINE configs[4] as worded; where the batch shape has no whole 256-row tiles the bf16
+ *                                      core runs instead; -1 = always the bf16 core (q, k, v, P in bf16; round-3 behaviour) */
 enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3, SYLBER_OPT_FUSE_OUTPROJ_LN = 4,
-       SYLBER_OPT_CONV0_VALU = 5, SYLBER_OPT_RESLN_PREFETCH = 6 };
+       SYLBER_OPT_CONV0_VALU = 5, SYLBER_OPT_RESLN_PREFETCH = 6, SYLBER_OPT_FP8_ATTENTION = 7 };
 int sylber_set_option(sylber_t h, int32_t key, int32_t value);
 
 /* the `features is not None` branch of resynthesize (segment_synthesis.py:135-140): features_dev [rows, input_dim] frame
@@ -234,7 +238,8 @@ int sylber_op_mx_quantize(const float* x_dev, int32_t R, int32_t K, uint8_t* dat
 int sylber_op_layernorm(const float* x_dev, const float* res_dev, const float* g_dev, const float* b_dev,
                         float* y_dev, int32_t M, int32_t D, void* stream);
 /* softmax(q k^T / 8 + key mask) v ; q,k,v,o: [B,T,768] fp32 (12 heads x 64); valid_dev [B] int32;
- * queries_per_wave: 0 = automatic, 32 or 64 */
+ * queries_per_wave: 0 = automatic, 32 or 64; precision: SYLBER_BF16 (bf16 q, k, v, P) or SYLBER_FP8 (q, k, v quantised to MXFP8
+ * -- e4m3 with one power-of-two scale per 32 features of q / k and per 32 keys of v -- and P to e4m3: BASELINE configs[4]) */
 int sylber_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const int32_t* valid_dev,
                         float* o_dev, int32_t B, int32_t T, int32_t precision, int32_t queries_per_wave, void* stream);
 

@@ -19,6 +19,9 @@ int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_
  * loop): out20 = 2 x 10 shader-cycle counters of workgroup 0's waves 0 and 4 (csrc/api.hip sylber_debug_gemm_trace) */
 int sylber_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, unsigned long long* out20,
                             float* ms_out);
+/* average ms of one launch of the attention core (12 heads x 64, B utterances of T frames, no key mask) on pseudo-random packed
+ * operands; precision: SYLBER_BF16 (bf16 operands) or SYLBER_FP8 (MXFP8 q / k / V^T, e4m3 P) */
+int sylber_debug_attention_bench(int32_t B, int32_t T, int32_t precision, int32_t iters, float* ms_out);
 #ifdef __cplusplus
 }
 #endif

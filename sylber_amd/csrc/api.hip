@@ -87,6 +87,7 @@ struct sylber_ctx {
     int opt_gemm_cfg = 0, opt_attn_qw = 0, opt_gemm_persist = 0;   // sylber_set_option (0 = automatic)
     int opt_fuse_ln = 0;                                           // out-projection + LayerNorm in one launch: 0 auto, 1 always, -1 never
     int opt_conv0_valu = 0;                                        // 1: conv0 of the 16-bit modes on the VALU kernel (A/B switch)
+    int opt_attn8 = 0;                                             // SYLBER_FP8: attention core on MXFP8 operands (0 / 1 on, -1 off)
     int opt_resln_pre = 0;                                         // residual prefetch of the out-proj / FFN2 K loops: 0 default, -1 off, 1..3 columns
     bool graph_mode = false;
     std::vector<GraphEntry> graphs; unsigned long long graph_clock = 0;
@@ -285,6 +286,7 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
         case SYLBER_OPT_FUSE_OUTPROJ_LN: c->opt_fuse_ln = value > 0 ? 1 : (value < 0 ? -1 : 0); break;
         case SYLBER_OPT_CONV0_VALU: c->opt_conv0_valu = value > 0 ? 1 : 0; break;
         case SYLBER_OPT_RESLN_PREFETCH: c->opt_resln_pre = value < 0 ? -1 : (value <= 3 ? value : 0); break;
+        case SYLBER_OPT_FP8_ATTENTION: c->opt_attn8 = value < 0 ? -1 : (value > 0 ? 1 : 0); break;
         default: syl_set_error("sylber_set_option", "unknown option key"); return 1;
     }
     if (c->graph_mode) { for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec); c->graphs.clear(); }   // captured launches are stale
@@ -536,11 +538,21 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         const bool last = (l == c->num_layers - 1) || (c->stop_stage == 3 + l);
         bool fused_ln1 = false;
         // one launch for q, k and v (N = 2304): the q / k thirds leave head-major, the v third transposed (EPI_QK)
+        // SYLBER_FP8, attention core on MXFP8 operands: the q / k / V^T regions hold e4m3 bytes in their first halves and the block
+        // scales behind them (k: one 64-key tile of slack in between, read by the last key tile of an utterance and masked)
+        uint8_t* q8 = (uint8_t*)q; uint8_t* k8 = (uint8_t*)k; uint8_t* v8 = (uint8_t*)vt;
+        uint8_t* q8s = q8 + (size_t)M * 768; uint8_t* k8s = k8 + (size_t)M * 768 + 4096; uint8_t* v8s = v8 + (size_t)B * 768 * p.Tpv;
+        bool attn8 = false;
         if (f8) {
             GemmF8Args g = {};
             g.g.M = M; g.g.N = 2304; g.g.K = 768; g.g.bias = d.bqkv; g.g.out0 = q; g.g.out1 = k; g.g.out2 = vt;
             g.g.Tp = p.Tp; g.g.Tpv = p.Tpv; g.g.T = p.T;
             g.X8 = h8; g.ldx8 = 768; g.XS = h8s; g.xs_rows = Mp; g.W8 = d.wqkvq; g.WS = d.wqkvs; g.ws_rows = 2304;
+            attn8 = c->opt_attn8 >= 0 && gemm_asm_f8_tile(EPI_QK8, g) != 0;
+            if (attn8) {
+                g.g.out0 = q8; g.g.out1 = k8; g.g.out2 = v8; g.qs = q8s; g.ks = k8s; g.vs = v8s;
+                RUN("gemm_qkv", launch_gemm_mxfp8(EPI_QK8, g, s));
+            } else
             RUN("gemm_qkv", launch_gemm_mxfp8(EPI_QK, g, s));
         } else {
             GemmArgs g = {};
@@ -551,6 +563,8 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             RUN("gemm_qkv", launch_gemm_bf16(EPI_QK, g, s));
         }
         if (f8) {
+            if (attn8) RUN("attention", launch_attention_f8(q8, q8s, k8, k8s, v8, v8s, valid, ctx8, ctx8s, Mp, B, p.T, p.Tp, p.Tpv, s));
+            else
             RUN("attention", launch_attention_f8out(q, k, vt, valid, ctx8, ctx8s, Mp, B, p.T, p.Tp, p.Tpv, c->opt_attn_qw, s));
             GemmF8Args o = {};
             o.g.M = M; o.g.N = 768; o.g.K = 768; o.g.bias = d.bo; o.g.out0 = pre; o.g.ld0 = 768; o.g.res = pre; o.g.ldres = 768;
@@ -919,11 +933,88 @@ __global__ void pack_qkv_kernel(const float* __restrict__ q, const float* __rest
     }
 }
 
+// q,k [B,T,768] f32 -> MXFP8 head-major q (x0.125), k: e4m3 [B,H,Tp,64] + one E8M0 scale per 32 features [B,H,Tp,2].
+// One 32-lane group per (token, head, 32-feature block).
+__global__ void pack_qk_f8_kernel(const float* __restrict__ q, const float* __restrict__ k, uint8_t* __restrict__ q8, uint8_t* __restrict__ qs,
+                                  uint8_t* __restrict__ k8, uint8_t* __restrict__ ks, int T, int Tp) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    for (int c = threadIdx.x; c < 768; c += 256) {
+        const int head = c >> 6, d = c & 63;
+        const size_t src = ((size_t)b * T + t) * 768 + c;
+        const size_t row = ((size_t)b * 12 + head) * Tp + t;
+        const float v[2] = {q[src] * 0.125f, k[src]};
+        uint8_t* dst[2] = {q8, k8};
+        uint8_t* sc[2] = {qs, ks};
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            float amax = fabsf(v[w]);
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+            const unsigned e = mx_e8m0(amax);
+            dst[w][row * 64 + d] = (uint8_t)(pack_fp8x4(v[w] * mx_inv_scale(e), 0.f, 0.f, 0.f) & 0xffu);
+            if ((d & 31) == 0) sc[w][row * 2 + (d >> 5)] = (uint8_t)e;
+        }
+    }
+}
+// v [B,T,768] f32 -> V^T MXFP8: e4m3 [B,H,64,Tpv] (natural key order) + one E8M0 scale per 32 keys [B,H,64,Tpv/32]; keys >= T are zero.
+// One thread per (feature, 32-key block).
+__global__ void pack_vt_f8_kernel(const float* __restrict__ v, uint8_t* __restrict__ v8, uint8_t* __restrict__ vs, int T, int Tpv) {
+    const int b = blockIdx.y, kb = blockIdx.x;           // 32-key block
+    for (int c = threadIdx.x; c < 768; c += 256) {
+        const int head = c >> 6, d = c & 63;
+        float x[32];
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int t = kb * 32 + i;
+            x[i] = t < T ? v[((size_t)b * T + t) * 768 + c] : 0.f;
+            amax = fmaxf(amax, fabsf(x[i]));
+        }
+        const unsigned e = mx_e8m0(amax);
+        const float inv = mx_inv_scale(e);
+        const size_t row = ((size_t)b * 12 + head) * 64 + d;
+        unsigned* dst = (unsigned*)(v8 + row * Tpv + kb * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = pack_fp8x4(x[4 * i] * inv, x[4 * i + 1] * inv, x[4 * i + 2] * inv, x[4 * i + 3] * inv);
+        vs[row * (Tpv / 32) + kb] = (uint8_t)e;
+    }
+}
+
+struct AttnF8Bufs {
+    TmpBuf q8, qs, k8, ks, v8, vs, cb;
+    int alloc(int B, int Tp, int Tpv) {
+        const size_t n = (size_t)B * Tp * 768;
+        // (k and its scales: one 64-key tile of slack, as in the bf16 path)
+        return q8.alloc(n) || qs.alloc(n / 32) || k8.alloc(n + 64 * 64) || ks.alloc(n / 32 + 128) || v8.alloc((size_t)B * 768 * Tpv) ||
+               vs.alloc((size_t)B * 768 * (Tpv / 32)) || cb.alloc(n * 2);
+    }
+    int clear(int B, int Tp, int Tpv, hipStream_t s) {
+        const size_t n = (size_t)B * Tp * 768;
+        HIP_TRY(hipMemsetAsync(q8.p, 0, n, s)); HIP_TRY(hipMemsetAsync(qs.p, 127, n / 32, s));
+        HIP_TRY(hipMemsetAsync(k8.p, 0, n + 64 * 64, s)); HIP_TRY(hipMemsetAsync(ks.p, 127, n / 32 + 128, s));
+        HIP_TRY(hipMemsetAsync(v8.p, 0, (size_t)B * 768 * Tpv, s)); HIP_TRY(hipMemsetAsync(vs.p, 127, (size_t)B * 768 * (Tpv / 32), s));
+        HIP_TRY(hipMemsetAsync(cb.p, 0, n * 2, s));
+        return 0;
+    }
+};
+
 extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const float* v_dev, const int32_t* valid_dev,
                                    float* o_dev, int32_t B, int32_t T, int32_t precision, int32_t queries_per_wave, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (precision != SYLBER_BF16) { syl_set_error("sylber_op_attention", "only bf16"); return 1; }
+    if (precision != SYLBER_BF16 && precision != SYLBER_FP8) { syl_set_error("sylber_op_attention", "precision: SYLBER_BF16 or SYLBER_FP8"); return 1; }
     const int Tp = (T + 31) & ~31, Tpv = (Tp + 63) & ~63;
+    if (precision == SYLBER_FP8) {
+        AttnF8Bufs f;
+        if (f.alloc(B, Tp, Tpv)) { syl_set_error("sylber_op_attention", "alloc"); return 1; }
+        if (f.clear(B, Tp, Tpv, s)) return 1;
+        hipLaunchKernelGGL(pack_qk_f8_kernel, dim3(T, B), dim3(256), 0, s, q_dev, k_dev, (uint8_t*)f.q8.p, (uint8_t*)f.qs.p, (uint8_t*)f.k8.p, (uint8_t*)f.ks.p, T, Tp);
+        hipLaunchKernelGGL(pack_vt_f8_kernel, dim3(Tpv / 32, B), dim3(256), 0, s, v_dev, (uint8_t*)f.v8.p, (uint8_t*)f.vs.p, T, Tpv);
+        if (launch_attention_f8((uint8_t*)f.q8.p, (uint8_t*)f.qs.p, (uint8_t*)f.k8.p, (uint8_t*)f.ks.p, (uint8_t*)f.v8.p, (uint8_t*)f.vs.p, valid_dev,
+                                f.cb.p, nullptr, 0, B, T, Tp, Tpv, s)) return 1;
+        if (launch_bf16_to_f32_rows((bf16_t*)f.cb.p, 768, o_dev, B, Tp, T, 768, s)) return 1;
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }
     const int qw = queries_per_wave == 32 ? 1 : (queries_per_wave == 64 ? 2 : 0);
     TmpBuf qb, kb, vb, cb;
     const size_t n = (size_t)B * Tp * 768;
@@ -938,6 +1029,55 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
     return 0;
 }
 
+
+__global__ void fill_random_bf16(bf16_t* p, size_t n, unsigned seed);
+// kernel-only timing of the attention core on random packed operands (development aid): precision SYLBER_BF16 or SYLBER_FP8
+extern "C" int sylber_debug_attention_bench(int32_t B, int32_t T, int32_t precision, int32_t iters, float* ms_out) {
+    const int Tp = (T + 31) & ~31, Tpv = (Tp + 63) & ~63;
+    const size_t n = (size_t)B * Tp * 768;
+    TmpBuf qin;
+    if (qin.alloc((size_t)B * T * 768 * 4 * 3)) { syl_set_error("sylber_debug_attention_bench", "alloc"); return 1; }
+    float* q = (float*)qin.p; float* k = q + (size_t)B * T * 768; float* v = k + (size_t)B * T * 768;
+    {   // pseudo-random fp32 q, k, v in [-1, 1) via the bf16 filler (values irrelevant for timing beyond being finite)
+        TmpBuf tmp;
+        if (tmp.alloc((size_t)B * T * 768 * 3 * 2)) { syl_set_error("sylber_debug_attention_bench", "alloc"); return 1; }
+        hipLaunchKernelGGL(fill_random_bf16, dim3(2048), dim3(256), 0, 0, (bf16_t*)tmp.p, (size_t)B * T * 768 * 3, 7u);
+        if (launch_bf16_to_f32_rows((bf16_t*)tmp.p, 768, q, 3 * B, T, T, 768, 0)) return 1;
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    int rc = 0;
+    if (precision == SYLBER_FP8) {
+        AttnF8Bufs f;
+        if (f.alloc(B, Tp, Tpv) || f.clear(B, Tp, Tpv, 0)) { syl_set_error("sylber_debug_attention_bench", "alloc"); return 1; }
+        hipLaunchKernelGGL(pack_qk_f8_kernel, dim3(T, B), dim3(256), 0, 0, q, k, (uint8_t*)f.q8.p, (uint8_t*)f.qs.p, (uint8_t*)f.k8.p, (uint8_t*)f.ks.p, T, Tp);
+        hipLaunchKernelGGL(pack_vt_f8_kernel, dim3(Tpv / 32, B), dim3(256), 0, 0, v, (uint8_t*)f.v8.p, (uint8_t*)f.vs.p, T, Tpv);
+        auto run = [&]() { return launch_attention_f8((uint8_t*)f.q8.p, (uint8_t*)f.qs.p, (uint8_t*)f.k8.p, (uint8_t*)f.ks.p, (uint8_t*)f.v8.p, (uint8_t*)f.vs.p,
+                                                      nullptr, f.cb.p, nullptr, 0, B, T, Tp, Tpv, 0); };
+        for (int i = 0; i < 3 && !rc; ++i) rc = run();
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < iters && !rc; ++i) rc = run();
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+    } else {
+        TmpBuf qb, kb, vb, cb;
+        if (qb.alloc(n * 2) || kb.alloc(n * 2 + 64 * 64 * 2) || vb.alloc((size_t)B * 768 * Tpv * 2) || cb.alloc(n * 2)) { syl_set_error("sylber_debug_attention_bench", "alloc"); return 1; }
+        HIP_TRY(hipMemset(qb.p, 0, n * 2)); HIP_TRY(hipMemset(kb.p, 0, n * 2 + 64 * 64 * 2)); HIP_TRY(hipMemset(vb.p, 0, (size_t)B * 768 * Tpv * 2));
+        hipLaunchKernelGGL(pack_qkv_kernel, dim3(T, B), dim3(256), 0, 0, q, k, v, (bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, T, Tp, Tpv);
+        auto run = [&]() { return launch_attention((bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, nullptr, (bf16_t*)cb.p, B, T, Tp, Tpv, 0, 0); };
+        for (int i = 0; i < 3 && !rc; ++i) rc = run();
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < iters && !rc; ++i) rc = run();
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+    }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / (iters > 0 ? iters : 1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
+}
 
 // ------------------------------------------------------------------------------------------------
 // GEMM micro-benchmark (development aid): times `iters` launches of the bf16 GEMM on pseudo-random

@@ -45,23 +45,27 @@ __device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l
             // scale block: 16 values in this lane, 16 in lane ^ 32; the halves swap two runs so that each lane stores
             // 16 contiguous bytes (a whole 32-byte sector per lane pair); the two scales of a (token, head) are the
             // adjacent pair of the K-pair-major layout
-            uint8_t* dst8 = (uint8_t*)ctx + ((size_t)b * Tp + (q < T ? q : 0)) * SYL_HIDDEN + head * 64;
+            // rows [T, Tp) of an utterance (padded queries) are written too, as zeros with scale 1: the context buffer aliases the FFN
+            // intermediate, and a stale byte read as an E8M0 scale (up to 2^127) would overflow the out-projection row, whose V^T
+            // column then turns the NEXT layer's P.V into NaN for every query (0 x inf) -- found with a batch-shape change on one handle
+            const bool live = q < T, inrow = q < Tp;
+            uint8_t* dst8 = (uint8_t*)ctx + ((size_t)b * Tp + (inrow ? q : 0)) * SYL_HIDDEN + head * 64;
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds) {
                 float amax = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(oacc[ds][r] * inv));
+                for (int r = 0; r < 16; ++r) amax = fmaxf(amax, live ? fabsf(oacc[ds][r] * inv) : 0.f);
                 amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
                 const unsigned e = mx_e8m0(amax);
-                const float sc = inv * mx_inv_scale(e);
+                const float sc = live ? inv * mx_inv_scale(e) : 0.f;
                 unsigned w[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    w[g] = pack_fp8x4(oacc[ds][4 * g + 0] * sc, oacc[ds][4 * g + 1] * sc, oacc[ds][4 * g + 2] * sc, oacc[ds][4 * g + 3] * sc);
+                    w[g] = live ? pack_fp8x4(oacc[ds][4 * g + 0] * sc, oacc[ds][4 * g + 1] * sc, oacc[ds][4 * g + 2] * sc, oacc[ds][4 * g + 3] * sc) : 0u;
                 const unsigned s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];
                 const unsigned g0 = (unsigned)__shfl_xor((int)s0, 32, 64), g1 = (unsigned)__shfl_xor((int)s1, 32, 64);
                 const uint4 out = h ? make_uint4(g0, w[2], g1, w[3]) : make_uint4(w[0], g0, w[1], g1);
-                if (q < T) {
+                if (inrow) {
                     *(uint4*)(dst8 + 32 * ds + 16 * h) = out;
                     if (h == 0) ctx_scale[mx_scale_index((long)b * Tp + q, 2 * head + ds, scale_rows)] = (uint8_t)e;
                 }
@@ -323,6 +327,190 @@ __global__ __launch_bounds__(256, FMT == FMT_SPLIT ? 2 : (QW == 2 ? 3 : 4)) void
     // ---- finalize: 1/l, store ctx[b*Tp + q][head*64 + d]
 #pragma unroll
     for (int qs = 0; qs < QW; ++qs) attn_finalize<F8, FMT>(oacc[qs], l_run[qs], ctx, ctx_scale, scale_rows, b, head, q0 + 32 * qs, ql, h, T, Tp, lo_ctx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same attention on MXFP8 operands (BASELINE configs[4] as worded: "fp8 MFMA for attention + FFN GEMMs").
+//   q8, k8: [B,H,Tp,64] e4m3 bytes + E8M0 scales [B,H,Tp,2] (one per 32 features: the contraction of QK^T);
+//   vt8:    [B,H,64,Tpv] e4m3 bytes in NATURAL key order + scales [B,H,64,Tpv/32] (one per 32 keys: the contraction of PV);
+//   P is quantised in registers to e4m3 with a bias of 2^7 (see the loop): its normals cover 2^-13 <= p <= 2.
+// v_mfma_scale_f32_32x32x64_f8f6f4 operand layout (gemm_mxfp8.hip, probed): lane (r, h) supplies row r, bytes
+// k = 16 h .. 16 h + 15 (registers 0-3) and 32 + 16 h .. + 15 (registers 4-7) of the 64-wide contraction, and the scale of
+// (row r, 32-block h).  A 64-key tile is two S^T MFMAs (keys [32 m, 32 m + 32), m = 0, 1; 64 features each) instead of eight,
+// and two P.V MFMAs (32 features each, 64 keys) instead of eight.  MFMA row rho of S^T m is key
+// 32 m + 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3): then lane (q, h) receives, in register order, the scores of keys
+// 32 m + 16 h .. + 15 -- which are exactly the contraction slots 16 h .. (m = 0) and 32 + 16 h .. (m = 1) of its P operand,
+// so P needs no cross-lane traffic and V^T no key permutation.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4v_t __attribute__((ext_vector_type(4)));
+#define AT8_TILE 4096    // bytes of one K or V^T tile (64 rows x 64 bytes)
+
+template <bool F8OUT>
+__global__ __launch_bounds__(256, 4) void attention_f8_kernel(const uint8_t* __restrict__ Q8, const uint8_t* __restrict__ Qs,
+                                                              const uint8_t* __restrict__ K8, const uint8_t* __restrict__ Ks,
+                                                              const uint8_t* __restrict__ V8, const uint8_t* __restrict__ Vs,
+                                                              const int* __restrict__ valid, bf16_t* __restrict__ ctx, int T, int Tp, int Tpv,
+                                                              uint8_t* __restrict__ ctx_scale, long scale_rows) {
+    __shared__ __attribute__((aligned(256))) char smem[4 * AT8_TILE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nqb = (T + 127) / 128;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vid / (nqb * SYL_HEADS);
+    const int head = (vid / nqb) % SYL_HEADS;
+    const int q0 = (vid % nqb) * 128 + wave * 32;
+    const int ql = lane & 31, h = lane >> 5;
+    int nvalid = valid ? valid[b] : T;
+    nvalid = nvalid < T ? nvalid : T;
+    const size_t bh = (size_t)b * SYL_HEADS + head;
+    const uint8_t* Qb = Q8 + bh * Tp * 64;
+    const uint8_t* Kb = K8 + bh * Tp * 64;
+    const uint8_t* Vb = V8 + bh * 64 * Tpv;
+    const uint8_t* Ksb = Ks + bh * Tp * 2;
+    const uint8_t* Vsb = Vs + bh * 64 * (Tpv / 32);
+
+    // Q operand (B of S^T): lane (q, h): features 16 h .. and 32 + 16 h ..; its scale = block h of its row
+    i32x8_t qf;
+    int qsc;
+    {
+        int qr = q0 + ql; qr = qr < Tp ? qr : Tp - 1;
+        const i32x4v_t lo = *(const i32x4v_t*)(Qb + (size_t)qr * 64 + 16 * h), hi = *(const i32x4v_t*)(Qb + (size_t)qr * 64 + 32 + 16 * h);
+        qf = i32x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        qsc = Qs[(bh * Tp + qr) * 2 + h];
+    }
+    // staging: wave w fills rows [16 w, 16 w + 16) of the K tile and of the V^T tile, ONE 16-byte piece per lane and operand;
+    // chunk c of row r lands at position c ^ ((r >> 1) & 3) (bank swizzle of the 64-byte rows)
+    const __amdgpu_buffer_rsrc_t rk = make_rsrc_a(Kb), rv = make_rsrc_a(Vb);
+    int kvoff, vvoff;
+    {
+        const int r = wave * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 1) & 3);
+        kvoff = r * 64 + c * 16;                     // + key tile * 64 rows in the scalar offset
+        vvoff = r * Tpv + c * 16;                    // + first key of the tile
+    }
+    const int lds_piece = wave * 1024;
+    // fragment rows: S^T m: key row of MFMA row ql; P.V ds: feature row 32 ds + ql.  Chunks h and 2 + h of the row.
+    int kaddr[2][2], vaddr[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int kr = 32 * m + 16 * ((ql >> 2) & 1) + 4 * (ql >> 3) + (ql & 3);
+        const int vr = 32 * m + ql;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            kaddr[m][j] = kr * 64 + (((2 * j + h) ^ ((kr >> 1) & 3)) << 4);
+            vaddr[m][j] = vr * 64 + (((2 * j + h) ^ ((vr >> 1) & 3)) << 4);
+        }
+    }
+    const int krow[2] = {16 * ((ql >> 2) & 1) + 4 * (ql >> 3) + (ql & 3), 32 + 16 * ((ql >> 2) & 1) + 4 * (ql >> 3) + (ql & 3)};
+
+    f32x16_t oacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float LOG2E = 1.44269504088896341f;
+    const int nt = (nvalid + AT_KV - 1) / AT_KV;
+    const int vsp = Tpv / 32;
+
+    int ksc[2], vsc[2];                               // scales of the tile about to be used (requested one tile ahead)
+    auto request = [&](int t, char* stage) {
+        const int kv = t * AT_KV;
+        glds16a(rk, kvoff, kv * 64, stage + lds_piece);
+        glds16a(rv, vvoff, kv, stage + AT8_TILE + lds_piece);
+    };
+    auto scales = [&](int t, int (&ks)[2], int (&vs)[2]) {
+        const int kv = t * AT_KV;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ks[m] = Ksb[(size_t)(kv + krow[m]) * 2 + h];
+            vs[m] = Vsb[(size_t)(32 * m + ql) * vsp + (kv >> 5) + h];
+        }
+    };
+    request(0, smem);
+    scales(0, ksc, vsc);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int ksn[2] = {127, 127}, vsn[2] = {127, 127};
+        if (t + 1 < nt) { request(t + 1, smem + ((t + 1) & 1) * 2 * AT8_TILE); scales(t + 1, ksn, vsn); }
+        const char* kb = smem + (t & 1) * 2 * AT8_TILE;
+        const char* vb = kb + AT8_TILE;
+        const int kv0 = t * AT_KV;
+        const bool TAIL = kv0 + AT_KV > nvalid;
+        // ---- S^T: two MFMAs, keys [0, 32) and [32, 64) of the tile
+        f32x16_t sacc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[m][r] = 0.f;
+            const i32x4v_t lo = *(const i32x4v_t*)(kb + kaddr[m][0]), hi = *(const i32x4v_t*)(kb + kaddr[m][1]);
+            const i32x8_t kf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            sacc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, sacc[m], 0, 0, 0, ksc[m], 0, qsc);
+        }
+        if (TAIL) {
+            asm volatile("; key-padding mask (last tile only)");
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + 32 * m + 16 * h + r >= nvalid) sacc[m][r] = -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[m][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // lazy maximum as in the 16-bit kernel, but P is an e4m3 operand: its normal range starts at 2^-6, so the probabilities are
+        // carried with a bias of 2^7 (l and O carry it too: O / l is unchanged) and the maximum may lag by at most 2^1:
+        // 2^-13 <= p <= 2^1 maps to e4m3's normals 2^-6 .. 2^8 = 256 <= 448
+        const bool need = (mx - m_run) * LOG2E > 1.0f;
+        if (__builtin_amdgcn_ballot_w64(need)) {
+            const float m_new = need ? mx : m_run;
+            const float alpha = need ? __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E) : 1.0f;
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
+        const float mb = m_run * LOG2E - 7.0f;
+        float psum = 0.f;
+        int pw[8];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[m][4 * g + 0], LOG2E, -mb));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[m][4 * g + 1], LOG2E, -mb));
+                const float p2 = __builtin_amdgcn_exp2f(fmaf(sacc[m][4 * g + 2], LOG2E, -mb));
+                const float p3 = __builtin_amdgcn_exp2f(fmaf(sacc[m][4 * g + 3], LOG2E, -mb));
+                psum += p0; psum += p1; psum += p2; psum += p3;
+                pw[4 * m + g] = (int)pack_fp8x4(p0, p1, p2, p3);
+            }
+        l_run += psum;
+        const i32x8_t pf = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
+        // ---- O^T += V^T . P^T: two MFMAs (features [0, 32) and [32, 64)), 64 keys each
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+            const i32x4v_t lo = *(const i32x4v_t*)(vb + vaddr[ds][0]), hi = *(const i32x4v_t*)(vb + vaddr[ds][1]);
+            const i32x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            oacc[ds] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, oacc[ds], 0, 0, 0, vsc[ds], 0, 127);
+        }
+        ksc[0] = ksn[0]; ksc[1] = ksn[1]; vsc[0] = vsn[0]; vsc[1] = vsn[1];
+    }
+    attn_finalize<F8OUT, FMT_BF16>(oacc, l_run, ctx, ctx_scale, scale_rows, b, head, q0, ql, h, T, Tp);
+}
+
+int launch_attention_f8(const uint8_t* q8, const uint8_t* qs, const uint8_t* k8, const uint8_t* ks, const uint8_t* v8, const uint8_t* vs,
+                        const int* valid, void* ctx, uint8_t* ctx_scale, long scale_rows, int B, int T, int Tp, int Tpv, hipStream_t s) {
+    if (Tpv % 64 != 0 || Tpv < T || Tp % 32 != 0) { syl_set_error("launch_attention_f8", "Tp % 32 == 0, Tpv % 64 == 0, Tpv >= T"); return 1; }
+    const dim3 grid(((T + 127) / 128) * SYL_HEADS * B);
+    if (ctx_scale) hipLaunchKernelGGL((attention_f8_kernel<true>), grid, dim3(256), 0, s, q8, qs, k8, ks, v8, vs, valid, (bf16_t*)ctx, T, Tp, Tpv, ctx_scale, scale_rows);
+    else hipLaunchKernelGGL((attention_f8_kernel<false>), grid, dim3(256), 0, s, q8, qs, k8, ks, v8, vs, valid, (bf16_t*)ctx, T, Tp, Tpv, nullptr, 0L);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, void* ctx, uint8_t* ctx_scale,

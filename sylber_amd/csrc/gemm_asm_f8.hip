@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, 1) void gemmf8_kernel(const GemmF8Args a) {
     constexpr int XT = BM * RB, WS_ = BN * RB;
     constexpr int XRING = 3 * XT;
     constexpr int NPW = (BM + BN) / 8 / 4, NXW = 8;
-    constexpr bool STAGED = (EPI == EPI_QK || EPI == EPI_MXFP8);
+    constexpr bool STAGED = (EPI == EPI_QK || EPI == EPI_MXFP8 || EPI == EPI_QK8);
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256, 1) void gemmf8_kernel(const GemmF8Args a) {
             float4 bias[FN][4];
             load_colvec<FN>(a.g.bias, nw, lane >> 5, N, bias);
             if (more) { setup(next, nxt); scales0(nxt); stage_x(nxt, 0, 0); stage_w(nxt, 0, 0); }
-            char* my = smem + XT + wave * (EPI == EPI_MXFP8 ? StagedF8<FN>::BYTES : StagedEpi<FN, EPI>::BYTES);   // X slots 1 and 2
+            constexpr int MYB = EPI == EPI_MXFP8 ? StagedF8<FN>::BYTES : (EPI == EPI_QK8 ? StagedQK8<FN>::BYTES : StagedEpi<FN, EPI == EPI_QK8 ? EPI_QK : EPI>::BYTES);
+            static_assert(4 * MYB <= 2 * XT, "epilogue staging must fit X slots 1 and 2");
+            char* my = smem + XT + wave * MYB;   // X slots 1 and 2
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) {
                 f32x16_t blk[FN];
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void gemmf8_kernel(const GemmF8Args a) {
                         blk[fn][r] = v;
                     }
                 if constexpr (EPI == EPI_MXFP8) epilogue_mxfp8_rows32<FN, ACT>(a, blk, bias, mw + fm * 32, nw, my, lane);
+                else if constexpr (EPI == EPI_QK8) epilogue_qk8_rows32<FN>(a, blk, bias, mw + fm * 32, nw, my, lane);
                 else epilogue_rows32<FN, EPI, ACT, FMT_BF16>(a.g, blk, bias, mw + fm * 32, nw, my, lane);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -209,7 +212,8 @@ static int launch_f8a(const GemmF8Args& a, hipStream_t s) {
 int gemm_asm_f8_tile(int epi, const GemmF8Args& a) {
     if (a.g.K % 256 != 0 || a.g.K < 512 || a.g.M % 256 != 0 || (a.ldx8 & 15)) return 0;
     if (a.xs_rows < a.g.M || a.ws_rows < a.g.N) return 0;
-    if (epi != EPI_MXFP8 && epi != EPI_F32 && epi != EPI_F32_RESLN && epi != EPI_QK) return 0;
+    if (epi != EPI_MXFP8 && epi != EPI_F32 && epi != EPI_F32_RESLN && epi != EPI_QK && epi != EPI_QK8) return 0;
+    if (epi == EPI_QK8) return a.g.N == 3 * SYL_HIDDEN && a.g.Tp % 32 == 0 ? 91 : 0;       // the 256x192 tile only
     const bool n256 = a.g.N % 256 == 0, n192 = a.g.N % 192 == 0;
     if (!n256 && !n192) return 0;
     if (n256 && n192) {                                       // fewer rounds over 256 CUs wins (ties: the larger tile)
@@ -236,6 +240,7 @@ int launch_gemm_asm_f8(int epi, const GemmF8Args& a, hipStream_t s, int tile) {
         case EPI_F32: return a.g.act == 1 ? launch_f8a<EPI_F32, 1, 3, true>(a, s) : launch_f8a<EPI_F32, 0, 3, true>(a, s);
         case EPI_F32_RESLN: return launch_f8a<EPI_F32_RESLN, 0, 3, true>(a, s);
         case EPI_QK: return launch_f8a<EPI_QK, 0, 3, true>(a, s);
+        case EPI_QK8: return launch_f8a<EPI_QK8, 0, 3, true>(a, s);
     }
     else switch (epi) {
         case EPI_MXFP8: return a.g.act == 1 ? launch_f8a<EPI_MXFP8, 1, 3>(a, s) : launch_f8a<EPI_MXFP8, 0, 3>(a, s);

@@ -473,6 +473,9 @@ int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s) {
             return launch_f8_t<EPI_F32, 0>(a, s);
         case EPI_F32_RESLN: return launch_f8_t<EPI_F32_RESLN, 0>(a, s);
         case EPI_QK: return launch_f8_t<EPI_QK, 0>(a, s);
+        case EPI_QK8:                                          // MXFP8 q / k / V^T for the fp8 attention core: the asm 256x192 tile only
+            if (!gemm_asm_f8_tile(EPI_QK8, a)) { syl_set_error("launch_gemm_mxfp8", "EPI_QK8 needs whole 256-row tiles, N = 2304, K % 256 == 0"); return 1; }
+            return launch_gemm_asm_f8(EPI_QK8, a, s, 91);
     }
     syl_set_error("launch_gemm_mxfp8", "unsupported epilogue");
     return 1;

@@ -17,6 +17,9 @@ enum GemmEpi {
                         // [B,H,64,Tpv] bf16 with the key axis bit-swapped, transposed through LDS
     EPI_PROJ = 4,       // feature projection: zero padded frames; out0 f32 [M][768]; out1 bf16 xpad
     EPI_MXFP8 = 7,      // MXFP8 GEMM only: out0 e4m3 [M][ld0] + out_scale e8m0 [M][N/32] = mx(act(acc + bias))
+    EPI_QK8 = 8,        // MXFP8 GEMM only (gemm_asm_f8.hip, 256x192 tile): EPI_QK with MXFP8 outputs for the fp8 attention core:
+                        // q (x0.125) -> out0, k -> out1: e4m3 [B,H,Tp,64] + scales qs / ks [B,H,Tp,2] (per 32 features);
+                        // v -> out2 = Vt e4m3 [B,H,64,Tpv], natural key order, + scales vs [B,H,64,Tpv/32] (per 32 keys)
     EPI_F32_RESLN = 6,  // out0 f32 = acc + bias + LN(res[m][n]) with LN = (x - mean[m]) * rstd[m] * gamma[n] + beta[n]
                         // (the residual IS a LayerNorm output that is never materialised in fp32; out0 may alias res)
 };
@@ -69,6 +72,7 @@ struct GemmF8Args {
     const uint8_t* W8;              // [N][K]
     const uint8_t* WS; long ws_rows;
     uint8_t* out_scale; long os_rows;  // EPI_MXFP8: scales of the output, pitch os_rows
+    uint8_t* qs; uint8_t* ks; uint8_t* vs;   // EPI_QK8: scales of q, k and V^T
 };
 int launch_gemm_mxfp8(int epi, const GemmF8Args& a, hipStream_t s);   // epi: EPI_MXFP8, EPI_F32, EPI_F32_RESLN, EPI_QK, EPI_V (g.tune_cfg as above)
 // the hand-scheduled X3 loop for MXFP8 operands (gemm_asm_f8.hip): which tile it has for this launch (0 = none), and the launch
@@ -132,6 +136,10 @@ int launch_layernorm(const LnArgs& a, hipStream_t s);
 // fmt FMT_SPLIT: q / k / vt / ctx are hi planes, their lo planes lo_qk (q, k), lo_vt and lo_ctx elements further on
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, bf16_t* ctx, int B, int T,
                      int Tp, int Tpv, int qw, hipStream_t s, int fmt = 0, long lo_qk = 0, long lo_vt = 0, long lo_ctx = 0);
+// the attention core on MXFP8 operands (configs[4]): q8 / k8 [B,H,Tp,64] e4m3 + scales [B,H,Tp,2]; vt8 [B,H,64,Tpv] e4m3 (natural key
+// order) + scales [B,H,64,Tpv/32]; ctx bf16 [B*Tp][768], or MXFP8 when ctx_scale is given.  k8 / its scales need one 64-key tile of slack.
+int launch_attention_f8(const uint8_t* q8, const uint8_t* qs, const uint8_t* k8, const uint8_t* ks, const uint8_t* v8, const uint8_t* vs,
+                        const int* valid, void* ctx, uint8_t* ctx_scale, long scale_rows, int B, int T, int Tp, int Tpv, hipStream_t s);
 int launch_attention_f8out(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const int* valid, uint8_t* ctx8, uint8_t* ctx_scale,
                            long scale_rows, int B, int T, int Tp, int Tpv, int qw, hipStream_t s);   // context as MXFP8 (SYLBER_FP8)
 int launch_attention_f32(const float* q, const float* k, const float* v, const int* valid, float* ctx, int B, int T,
