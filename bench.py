@@ -443,7 +443,7 @@ def main():
 
     def build_line(value_, elapsed_, med_, exchange_first_, roofline_=None, frontend_=None, cpu_=None, api_=None, kernels_=None,
                    seg_stats_=None):
-        dtype = {"bf16": "bf16", "fp8": "bf16 + mxfp8 (e4m3, E8M0 block scales) weight GEMMs", "fp32": "f32", "fp16": "f16 (IEEE half operands, f32 accumulate)",
+        dtype = {"bf16": "bf16", "fp8": "bf16 + mxfp8 (e4m3, E8M0 block scales) weight GEMMs and attention core", "fp32": "f32", "fp16": "f16 (IEEE half operands, f32 accumulate)",
                  "mixed16": "f16 conv stack + bf16 encoder (f32 accumulate)",
                  "split16": "f16 hi/lo operand pairs, three MFMA passes per contraction (f32 accumulate, erf GELU)"}[args.precision]
         # which BASELINE.json configuration this run IS (the label follows the arguments, not the default)
