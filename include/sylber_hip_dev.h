@@ -1,11 +1,12 @@
 /*
  * sylber_hip_dev.h -- development aids exported by libsylber_hip.so that are NOT part of the drop-in C-ABI
  * (include/sylber_hip.h): micro-benchmarks used by tools/.  Nothing on the product path or in the parity tests
- * needs them, and they keep no process-global state.
+ * needs them (one GPU test uses the workspace-poisoning aid), and they keep no process-global state.
  */
 #ifndef SYLBER_HIP_DEV_H
 #define SYLBER_HIP_DEV_H
 #include <stdint.h>
+#include "sylber_hip.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -19,6 +20,9 @@ int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_
  * loop): out20 = 2 x 10 shader-cycle counters of workgroup 0's waves 0 and 4 (csrc/api.hip sylber_debug_gemm_trace) */
 int sylber_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, unsigned long long* out20,
                             float* ms_out);
+/* test aid: fill the handle's activation workspace with `byte` (0xFF = NaN patterns) and force the next forward to redo the zeroing it
+ * does after a batch-shape change; results must not change (tests/test_gpu_encoder.py) */
+int sylber_debug_poison_workspace(sylber_t h, int32_t byte);
 /* average ms of one launch of the attention core (12 heads x 64, B utterances of T frames, no key mask) on pseudo-random packed
  * operands; precision: SYLBER_BF16 (bf16 operands) or SYLBER_FP8 (MXFP8 q / k / V^T, e4m3 P) */
 int sylber_debug_attention_bench(int32_t B, int32_t T, int32_t precision, int32_t iters, float* ms_out);

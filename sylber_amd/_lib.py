@@ -82,6 +82,7 @@ DEV_EXPORTS = {
     "sylber_debug_gemm_bench": (c_int, [c_int32] * 8 + [POINTER(c_float)]),
     "sylber_debug_gemm_trace": (c_int, [c_int32] * 6 + [POINTER(ctypes.c_uint64), POINTER(c_float)]),
     "sylber_debug_attention_bench": (c_int, [c_int32] * 4 + [POINTER(c_float)]),
+    "sylber_debug_poison_workspace": (c_int, [c_void_p, c_int32]),
 }
 OPT_GEMM_TILE, OPT_ATTN_QUERIES_PER_WAVE, OPT_GEMM_PERSISTENT = 1, 2, 3
 

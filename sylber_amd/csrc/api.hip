@@ -1031,6 +1031,19 @@ extern "C" int sylber_op_attention(const float* q_dev, const float* k_dev, const
 
 
 __global__ void fill_random_bf16(bf16_t* p, size_t n, unsigned seed);
+// test aid: every byte of the handle's activation workspace becomes `byte` (0xFF: NaN patterns in every format), and the next forward
+// re-runs the zeroing of the regions that are read without being written (as after a batch-shape change).  A forward that then
+// returns the same bits as before reads nothing it has not written -- stale data can never leak into a result.
+extern "C" int sylber_debug_poison_workspace(sylber_t c, int32_t byte) {
+    if (!c) { syl_set_error("sylber_debug_poison_workspace", "null handle"); return 1; }
+    GUARD_DEVICE(c->device);
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->ws) HIP_TRY(hipMemset(c->ws, byte & 0xff, c->ws_bytes));
+    c->ws_B = 0; c->ws_Lmax = 0;
+    if (c->graph_mode) { for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec); c->graphs.clear(); }
+    return 0;
+}
+
 // kernel-only timing of the attention core on random packed operands (development aid): precision SYLBER_BF16 or SYLBER_FP8
 extern "C" int sylber_debug_attention_bench(int32_t B, int32_t T, int32_t precision, int32_t iters, float* ms_out) {
     const int Tp = (T + 31) & ~31, Tpv = (Tp + 63) & ~63;

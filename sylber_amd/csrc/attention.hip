@@ -74,7 +74,10 @@ __device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l
             // the store tail is store-ISSUE bound (16 dwordx2 per lane): the lane halves swap one 4-feature run per pair
             // of runs, so that each lane stores 8 consecutive features = 8 dwordx4 per lane, whole 32-byte sectors per
             // lane pair (lane h = 0: d = 16p .. 16p+7, lane h = 1: d = 16p+8 .. 16p+15)
-            bf16_t* dst = ctx + ((size_t)b * Tp + (q < T ? q : 0)) * SYL_HIDDEN + head * 64;
+            // (rows [T, Tp) are written as zeros: the buffer aliases other activations, and a stale NaN pattern there would come back
+            //  through the next layer's V^T as 0 x NaN for every query; tests/test_gpu_encoder.py poisons the workspace to check)
+            const bool live = q < T, inrow = q < Tp;
+            bf16_t* dst = ctx + ((size_t)b * Tp + (inrow ? q : 0)) * SYL_HIDDEN + head * 64;
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds)
 #pragma unroll
@@ -87,8 +90,8 @@ __device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l
                     const uint2 keep = h ? rb : ra, send = h ? ra : rb;
                     uint2 got;
                     got.x = (unsigned)__shfl_xor((int)send.x, 32, 64); got.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
-                    const uint4 out = h ? make_uint4(got.x, got.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, got.x, got.y);
-                    if (q < T) *(uint4*)(dst + 32 * ds + 16 * pr + 8 * h) = out;
+                    const uint4 out = !live ? make_uint4(0u, 0u, 0u, 0u) : (h ? make_uint4(got.x, got.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, got.x, got.y));
+                    if (inrow) *(uint4*)(dst + 32 * ds + 16 * pr + 8 * h) = out;
                     if constexpr (FMT == FMT_SPLIT) {
                         // the lo halves of the same eight values, exchanged the same way
                         uint2 la, lb;
@@ -99,8 +102,8 @@ __device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l
                         const uint2 keepl = h ? lb : la, sendl = h ? la : lb;
                         uint2 gl;
                         gl.x = (unsigned)__shfl_xor((int)sendl.x, 32, 64); gl.y = (unsigned)__shfl_xor((int)sendl.y, 32, 64);
-                        const uint4 outl = h ? make_uint4(gl.x, gl.y, keepl.x, keepl.y) : make_uint4(keepl.x, keepl.y, gl.x, gl.y);
-                        if (q < T) *(uint4*)(dst + lo_ctx + 32 * ds + 16 * pr + 8 * h) = outl;
+                        const uint4 outl = !live ? make_uint4(0u, 0u, 0u, 0u) : (h ? make_uint4(gl.x, gl.y, keepl.x, keepl.y) : make_uint4(keepl.x, keepl.y, gl.x, gl.y));
+                        if (inrow) *(uint4*)(dst + lo_ctx + 32 * ds + 16 * pr + 8 * h) = outl;
                     }
                 }
         }

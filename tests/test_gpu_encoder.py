@@ -249,3 +249,27 @@ def test_nan_utterance_does_not_leak_into_neighbours(enc):
         ref = segment_oracle.get_segment(np.ascontiguousarray(h[i]), 2.6, 0.8).reshape(-1, 2)
         assert nseg[i] == len(ref)
         assert np.array_equal(seg[i, : nseg[i]].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp8", "split16", "fp32"])
+def test_forward_reads_nothing_it_has_not_written(precision):
+    """every byte of the activation workspace is overwritten with 0xFF (NaN patterns in every operand format), then the same
+    forward runs again: the result must be the same bits.  Guards the aliasing of the workspace regions (q / k / V^T / context share
+    memory with the FFN intermediate) and the regions that are read without being written (halo rows, key tails, slack rows, the
+    padded query rows [T, Tp) of the attention context): a stale NaN there comes back as 0 x NaN in the next layer's P.V --
+    found in the fp8 mode after a batch-shape change on one handle, fixed in csrc/attention.hip attn_finalize."""
+    import ctypes
+    from sylber_amd import HubertEncoderHIP, _lib
+    from sylber_amd.synth import syllable_wave
+    from sylber_amd.weights import synthetic_state_dict
+    e = HubertEncoderHIP(synthetic_state_dict(0), precision=precision)
+    shapes = [(8, 48000, [48000, 30000, 48000, 9000, 48000, 48000, 20000, 41000]),        # 149 frames: 11 padded rows per utterance
+              (3, 40000, None), (2, 16400, [16400, 12000])]
+    for B, n, lens in shapes:
+        wav = torch.cat([syllable_wave(n, 90 + i) for i in range(B)], 0).cuda()
+        ref = e.forward(wav, lens).clone()
+        assert torch.isfinite(ref).all()
+        for byte in (0xFF, 0x7F):
+            _lib.check(e.lib.sylber_debug_poison_workspace(e.handle, byte), "poison")
+            got = e.forward(wav, lens)
+            assert torch.equal(got, ref), (precision, B, n, hex(byte))
