@@ -1039,6 +1039,7 @@ extern "C" int sylber_debug_poison_workspace(sylber_t c, int32_t byte) {
     GUARD_DEVICE(c->device);
     HIP_TRY(hipDeviceSynchronize());
     if (c->ws) HIP_TRY(hipMemset(c->ws, byte & 0xff, c->ws_bytes));
+    if (c->seg_scratch) HIP_TRY(hipMemset(c->seg_scratch, byte & 0xff, c->seg_scratch_floats * 4));   // (long-utterance bookkeeping slab of sylber_segment)
     c->ws_B = 0; c->ws_Lmax = 0;
     if (c->graph_mode) { for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec); c->graphs.clear(); }
     return 0;

@@ -60,6 +60,14 @@ def test_random_batches_vs_oracle(enc):
             assert nseg[j] == len(exp) and np.array_equal(seg[j, :nseg[j]], exp), (T, mode, j)
             if len(exp):
                 assert np.array_equal(feats[j, :nseg[j]], segment_oracle.mean_pool(st, exp), equal_nan=True)
+        # the slab holds nothing the kernel reads before writing it: poisoned with NaN / 0x7F patterns, same results
+        from sylber_amd import _lib
+        for byte in (0xFF, 0x7F):
+            _lib.check(enc.lib.sylber_debug_poison_workspace(enc.handle, byte), "poison")
+            seg2, nseg2, feats2 = _run(enc, sts, 2.6, 0.8)
+            assert np.array_equal(nseg2, nseg)
+            for j in range(len(sts)):
+                assert np.array_equal(seg2[j, :nseg[j]], seg[j, :nseg[j]]) and np.array_equal(feats2[j, :nseg[j]], feats[j, :nseg[j]], equal_nan=True)
 
 
 def test_properties_full_size(enc):
