@@ -273,3 +273,23 @@ def test_forward_reads_nothing_it_has_not_written(precision):
             _lib.check(e.lib.sylber_debug_poison_workspace(e.handle, byte), "poison")
             got = e.forward(wav, lens)
             assert torch.equal(got, ref), (precision, B, n, hex(byte))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_a_non_finite_utterance_stays_in_its_rows(precision):
+    """utterances are independent units on this path: a clip of NaN / inf samples must not change one bit of its
+    batch neighbours' hidden states -- no kernel may mix rows of different utterances, not even through a multiplication by zero"""
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.synth import syllable_wave
+    from sylber_amd.weights import synthetic_state_dict
+    e = HubertEncoderHIP(synthetic_state_dict(0), precision=precision)
+    lens = [48000, 30000, 48000, 9000, 48000, 48000, 20000, 41000]
+    wav = torch.cat([syllable_wave(48000, 120 + i) for i in range(8)], 0).cuda()
+    ref = e.forward(wav, lens).clone()
+    for bad, val in ((2, float("nan")), (5, float("inf")), (7, -1e30)):
+        w2 = wav.clone()
+        w2[bad, 100:20000] = val
+        got = e.forward(w2, lens)
+        keep = [i for i in range(8) if i != bad]
+        assert torch.equal(got[keep], ref[keep]), (precision, bad, val)
+    assert torch.equal(e.forward(wav, lens), ref)
