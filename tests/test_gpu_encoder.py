@@ -293,3 +293,19 @@ def test_a_non_finite_utterance_stays_in_its_rows(precision):
         keep = [i for i in range(8) if i != bad]
         assert torch.equal(got[keep], ref[keep]), (precision, bad, val)
     assert torch.equal(e.forward(wav, lens), ref)
+
+
+def test_batch_beyond_4gb_matches_small_batches():
+    """addressing beyond 32-bit byte offsets: a 48 x 30 s batch (conv0 output 4.7 GB, workspace ~8 GB) reproduces row for row and bit
+    for bit what the same clips give in batches of 8 (tools/big_batch_check.py runs 128 x 30 s / 16 x 150 s: 21 / 13 GB)"""
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.synth import noise_batch
+    from sylber_amd.weights import synthetic_state_dict
+    e = HubertEncoderHIP(synthetic_state_dict(0))
+    B, N = 48, 480000
+    x = noise_batch(B, N, seed=5).cuda()
+    lens = [N - 1000 * (i % 7) for i in range(B)]
+    big = e.forward(x, lens)
+    assert torch.isfinite(big).all() and e.workspace_bytes() > (1 << 32)
+    for i in range(0, B, 8):
+        assert torch.equal(e.forward(x[i:i + 8].contiguous(), lens[i:i + 8]), big[i:i + 8]), i
