@@ -243,3 +243,28 @@ def _is_pool_view(arr, S):
     while getattr(base, "base", None) is not None:
         base = base.base
     return isinstance(base, np.ndarray) and base.dtype == np.uint8 and base.nbytes % S.out_pool.GRANULE == 0 and base.nbytes >= arr.nbytes and base is not arr
+
+
+def test_ragged_serving_loop_is_history_independent(sd):
+    """a serving loop with a new batch size and a new maximum length per call (the workspace layout changes every time) returns,
+    call by call, the bits of a handle whose workspace was filled with NaN patterns just before that call: no result depends on
+    what the handle did before (graph replay included)"""
+    from sylber_amd import Segmenter, _lib
+    rng = np.random.default_rng(11)
+    A = Segmenter(model_ckpt=sd)
+    Bs = Segmenter(model_ckpt=sd)
+    G = Segmenter(model_ckpt=sd)
+    G.speech_model.set_graph_mode(True)
+    for call in range(24):
+        nb = int(rng.integers(1, 9))
+        wavs = [syllable_wave(int(rng.integers(4000, 70000)), 700 + 10 * call + i) for i in range(nb)]
+        if call % 5 == 4:
+            wavs = wavs * 2                                   # a repeated shape now and then: the graph entry is replayed
+        got = A(wav=wavs, in_second=False)
+        _lib.check(Bs.speech_model.lib.sylber_debug_poison_workspace(Bs.speech_model.handle, 0xFF), "poison")
+        exp = Bs(wav=wavs, in_second=False)
+        gg = G(wav=wavs, in_second=False)
+        for g, e, h in zip(got, exp, gg):
+            assert np.array_equal(g["hidden_states"], e["hidden_states"]) and np.array_equal(h["hidden_states"], e["hidden_states"]), call
+            assert np.array_equal(g["segments"], e["segments"]) and np.array_equal(h["segments"], e["segments"]), call
+            assert np.array_equal(g["segment_features"], e["segment_features"], equal_nan=True), call
