@@ -37,6 +37,19 @@ static std::map<int, IngestTable*> g_tabs;     // never freed: async H2D copies 
 
 static int igcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
+// a rate is supported when its polyphase table is small: 16000 / gcd phases x (2 width + sr / gcd) taps <= 2^26 floats (every common rate:
+// 8 / 11.025 / 22.05 / 24 / 32 / 44.1 / 48 / 96 kHz are <= 1e5).  A corrupt header (or a rate coprime to 16000) would otherwise ask for
+// tens of GB of host memory here -- and a C++ exception must not cross the C ABI.
+static bool rate_supported(int sr_in) {
+    if (sr_in < 1) return false;
+    if (sr_in == 16000) return true;
+    const int g = igcd(sr_in, 16000);
+    const long orig = sr_in / g, neu = 16000 / g;
+    const double base = (double)(orig < neu ? orig : neu) * 0.99;
+    const long width = (long)std::ceil(6.0 * orig / base);
+    return neu * (2 * width + orig) <= (1L << 26);
+}
+
 static const IngestTable* get_table(int sr_in) {
     std::lock_guard<std::mutex> lk(g_tab_mu);
     auto it = g_tabs.find(sr_in);
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(256) void ingest_normalize_kernel(float* __restrict
 }
 
 extern "C" int64_t sylber_ingest_num_frames(int64_t frames_in, int32_t sr_in) {
-    if (sr_in <= 0 || frames_in < 0) return -1;
+    if (!rate_supported(sr_in) || frames_in < 0) return -1;
     if (sr_in == 16000) return frames_in;
     const int g = igcd(sr_in, 16000);
     const int64_t orig = sr_in / g, neu = 16000 / g;
@@ -164,7 +177,7 @@ extern "C" int64_t sylber_ingest_num_frames(int64_t frames_in, int32_t sr_in) {
 }
 
 extern "C" int64_t sylber_ingest_workspace_bytes(int32_t sr_in) {
-    if (sr_in <= 0) return -1;
+    if (!rate_supported(sr_in)) return -1;
     size_t bytes = 2 * ING_PARTIALS * sizeof(double);
     if (sr_in != 16000) {
         const IngestTable* t = get_table(sr_in);
@@ -181,6 +194,7 @@ extern "C" int sylber_ingest(const void* pcm_dev, int32_t sample_width, int32_t 
         syl_set_error("sylber_ingest", "sample width must be 1..4 bytes (integer PCM) or -4 / -8 (IEEE float32 / float64)"); return 1;
     }
     if (channels < 1 || channels > 65535 || frames_in < 1 || sr_in < 1) { syl_set_error("sylber_ingest", "bad channels / frames / rate"); return 1; }
+    if (!rate_supported(sr_in)) { syl_set_error("sylber_ingest", "unsupported sample rate (its resampling table to 16 kHz would exceed 2^26 taps)"); return 1; }
     const unsigned char* pcm = (const unsigned char*)pcm_dev;
     double* part_sum = (double*)workspace_dev;
     double* part_sq = part_sum + ING_PARTIALS;

@@ -75,7 +75,11 @@ def ingest_pcm(pcm: PcmFile, device, normalize: bool = True) -> torch.Tensor:
     if not torch.cuda.is_available():
         raise _lib.SylberHipError("no MI355X visible to PyTorch-ROCm; the HIP path has no CPU fallback")
     dev = torch.device(device)
+    if not (0 < pcm.sample_rate < 2 ** 31):
+        raise ValueError("sample rate %d out of range" % pcm.sample_rate)
     n_out = num_frames_16k(pcm.frames, pcm.sample_rate)
+    if n_out < 1:
+        raise ValueError("sample rate %d Hz is not supported (no compact polyphase table to 16 kHz)" % pcm.sample_rate)
     raw = torch.from_numpy(np.ascontiguousarray(pcm.data)).to(dev)
     out = torch.empty(pcm.channels, n_out, dtype=torch.float32, device=dev)
     ws = torch.empty(int(lib.sylber_ingest_workspace_bytes(pcm.sample_rate)) // 8 + 1, dtype=torch.float64, device=dev)

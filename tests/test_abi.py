@@ -86,3 +86,12 @@ def test_no_packed_fp32_valu_in_the_library(lib):
     n_dma = len(re.findall(r"\bbuffer_load_dwordx4\b[^\n]*\blds\b", text)) + len(re.findall(r"\bglobal_load_lds_dwordx4\b", text))
     assert len(re.findall(r"\bv_mfma_", text)) > 1000 and n_dma > 1000          # LDS-DMA staging (buffer descriptors since round 3)
     assert check_isa.banned_instructions(_lib.LIB_PATH) == {}
+
+
+def test_ingest_rejects_rates_without_a_compact_resampling_table(lib):
+    """host arithmetic only (no GPU): a corrupt WAVE header must not make the resampler plan a multi-GB polyphase table (a C++
+    bad_alloc would cross the C ABI); common rates stay supported"""
+    for sr, n16 in ((16000, 100000), (8000, 200000), (44100, 36282), (48000, 33334), (22050, 72563), (96000, 16667), (11025, 145125)):
+        assert lib.sylber_ingest_num_frames(100000, sr) == n16 and lib.sylber_ingest_workspace_bytes(sr) > 0
+    for sr in (0, -5, 44101, 15999, 2147483647):
+        assert lib.sylber_ingest_num_frames(100000, sr) == -1 and lib.sylber_ingest_workspace_bytes(sr) == -1
