@@ -524,6 +524,186 @@ class Segmenter:
         mark("dicts built")
         return outputs if is_batch else outputs[0]
 
+    # -- a stream of batches: the PCIe-inclusive path at (nearly) the resident rate -----------------------
+    def stream(self, batches, in_second=True):
+        """Generator over an iterable of batches (each what ``__call__`` takes as ``wav=``: a list of host ``[channels, N]`` tensors).
+        Yields, in order, exactly what ``self(wav=batch, in_second=in_second)`` returns for each of them (same bits: the same
+        kernels on the same data) -- but a synchronous call spends ~2.5 of its ~7.6 ms (32 x 10 s) outside the GPU's forward
+        (padding + H2D in front, D2H + slicing behind), and here those run under the NEIGHBOURING batches' forwards: batch
+        i + 1 is padded and uploaded on a copy stream while batch i computes, batch i's results leave on a second copy stream
+        while batch i + 1 computes, and the host slices batch i - 1 meanwhile.  The reference has no counterpart (its
+        ``__call__`` is one synchronous batch, sylber.py:76-138); a corpus loop over it is what this replaces."""
+        it = iter(batches)
+        dev = self.speech_model.device
+        cur = torch.cuda.current_stream(dev)
+        st = self.__dict__.get("_stream_streams")
+        if st is None or st[0].device != dev:
+            from .streams import concurrent_streams
+            st = self._stream_streams = concurrent_streams(2, dev, avoid=[cur])        # H2D, D2H
+        h2d, d2h = st
+        counter = {"in": 0}
+
+        def ring_set(j):
+            ring = self.__dict__.setdefault("_stream_dev", [None, None, None])
+            if ring[j] is None:
+                ring[j] = {"in_free": None, "out_free": None}
+            return ring[j]
+
+        def flat(d, key, numel, dtype):
+            buf = d.get(key)
+            if buf is None or buf.numel() < numel or buf.device != dev:
+                if buf is not None:
+                    torch.cuda.synchronize(dev)               # (grow-only: a larger batch shape than any before)
+                buf = d[key] = torch.empty(int(numel * 1.25) + 64, dtype=dtype, device=dev)
+            return buf[:numel]
+
+        def issue_input(batch_wavs):
+            rows, lengths = self._rows(batch_wavs if isinstance(batch_wavs, (list, tuple)) else [batch_wavs])
+            if any(r.is_cuda for r in rows):
+                raise ValueError("Segmenter.stream takes host tensors (device batches have nothing to overlap: use __call__)")
+            lmax = max(lengths)
+            stage, slot = self._stage_buffer((len(rows), lmax))
+            stage_np = stage.numpy()
+
+            def fill(lo, hi):
+                for i in range(lo, hi):
+                    src = rows[i].detach()
+                    stage_np[i, : lengths[i]] = (src if src.dtype == torch.float32 else src.to(torch.float32)).numpy()
+                    stage_np[i, lengths[i]:] = 0.0
+            n = len(rows)
+            if self._fill_threads > 1 and n >= 16:
+                fut = self._fill_pool().submit(fill, 0, n // 2)
+                fill(n // 2, n)
+                fut.result()
+            else:
+                fill(0, n)
+            tr = self.__dict__.get("_trace")
+            if tr is not None:
+                tr.append(("padded", time.perf_counter()))
+            # device buffers come from a ring of three grow-only sets with explicit events, not from the caching allocator: blocks
+            # handed between streams with record_stream come back late, and the hipMalloc that then happens every third batch
+            # synchronises the device (measured: GPU gaps 5.3 / 5.3 / 6.9 ms, tools/api_timeline.py)
+            d = ring_set(counter["in"] % 3)
+            counter["in"] += 1
+            with torch.cuda.stream(h2d):
+                if d["in_free"] is not None:
+                    h2d.wait_event(d["in_free"])
+                batch = flat(d, "in", n * lmax, torch.float32).view(n, lmax)
+                batch.copy_(stage, non_blocking=True)
+                slot["event"].record(h2d)
+                ev = torch.cuda.Event()
+                ev.record(h2d)
+            return {"batch": batch, "lengths": lengths, "uploaded": ev, "single": not isinstance(batch_wavs, (list, tuple)), "set": d}
+
+        def issue_compute(t, slot_id):
+            batch, lengths, d = t["batch"], t["lengths"], t["set"]
+            cur.wait_event(t["uploaded"])
+            if d["out_free"] is not None:
+                cur.wait_event(d["out_free"])             # the copies of the batch that last used this set have left
+            B_, T_ = batch.shape[0], self.speech_model.num_frames(batch.shape[1])
+            hidden = self.speech_model.forward(batch, lengths, out=flat(d, "hid", B_ * T_ * 768, torch.float32).view(B_, T_, 768))
+            out = (flat(d, "seg", B_ * T_ * 2, torch.int64).view(B_, T_, 2), flat(d, "nseg", B_, torch.int32),
+                   flat(d, "feat", B_ * T_ * 768, torch.float32).view(B_, T_, 768))
+            seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold, out=out)
+            tr = self.__dict__.get("_trace")                  # tools/api_timeline.py STREAM=1: (label, host time[, event]) marks
+            done = torch.cuda.Event(enable_timing=tr is not None)
+            done.record(cur)
+            if tr is not None:
+                tr.append(("compute issued", time.perf_counter(), done))
+            B, T, D = hidden.shape
+
+            def al(n):
+                return (n + 255) & ~255
+            kcap = min(T, self._kcap_seen)
+            o_cnt = al(B * T * D * 4)
+            o_seg = o_cnt + al(B * 4)
+            o_feat = o_seg + al(B * kcap * 2 * 8)
+            need = o_feat + al(B * kcap * D * 4)
+            lease = self.out_pool.lease(need) if self.output_memory == "pinned" else None
+            handed = lease is not None
+            if handed:
+                owner, blk = lease
+            else:                                         # pageable mode / pool exhausted: one private bounce block per in-flight slot (three)
+                ring = self.__dict__.setdefault("_stream_scratch", [None, None, None])
+                if ring[slot_id] is None or ring[slot_id].numel() < need:
+                    ring[slot_id] = torch.empty((need + (1 << 20) - 1) >> 20 << 20, dtype=torch.uint8, pin_memory=True)
+                blk = ring[slot_id]
+                owner = blk.numpy()
+            with torch.cuda.stream(d2h):
+                d2h.wait_event(done)
+                blk[:B * T * D * 4].view(torch.float32).view(B, T, D).copy_(hidden, non_blocking=True)
+                blk[o_cnt:o_cnt + B * 4].view(torch.int32).copy_(nseg, non_blocking=True)
+                blk[o_seg:o_seg + B * kcap * 2 * 8].view(torch.int64).view(B, kcap, 2).copy_(seg[:, :kcap], non_blocking=True)
+                blk[o_feat:o_feat + B * kcap * D * 4].view(torch.float32).view(B, kcap, D).copy_(feats[:, :kcap], non_blocking=True)
+                out_ev = torch.cuda.Event()
+                out_ev.record(d2h)
+            d["in_free"], d["out_free"] = done, out_ev
+            t.update(dict(shape=(B, T, D), kcap=kcap, offs=(o_cnt, o_seg, o_feat), owner=owner, handed=handed, out_ev=out_ev,
+                          dev=(seg, feats)))
+            t.pop("batch")
+            return t
+
+        def finish(t):
+            tr = self.__dict__.get("_trace")
+            if tr is not None:
+                tr.append(("finish enter", time.perf_counter()))
+            t["out_ev"].synchronize()
+            if tr is not None:
+                tr.append(("results on the host", time.perf_counter()))
+            B, T, D = t["shape"]
+            o_cnt, o_seg, o_feat = t["offs"]
+            owner, handed, kslots = t["owner"], t["handed"], t["kcap"]
+            nseg_h = owner[o_cnt:o_cnt + B * 4].view(np.int32).copy()
+            k = max(int(nseg_h.max()) if B else 0, 1)
+            towner = owner
+            if k > kslots:                                # more segments than any batch before: fetch the tables again (rare)
+                seg, feats = t["dev"]
+                self._kcap_seen = min(T, (k + 63) & ~63)
+                kslots = self._kcap_seen
+                o_seg, o_feat = 0, (B * kslots * 2 * 8 + 255) & ~255
+                pb = torch.empty(o_feat + B * kslots * D * 4, dtype=torch.uint8, pin_memory=True)
+                pb[o_seg:o_seg + B * kslots * 2 * 8].view(torch.int64).view(B, kslots, 2).copy_(seg[:, :kslots], non_blocking=True)
+                pb[o_feat:o_feat + B * kslots * D * 4].view(torch.float32).view(B, kslots, D).copy_(feats[:, :kslots], non_blocking=True)
+                torch.cuda.current_stream(dev).synchronize()
+                towner, tcopy = pb.numpy(), False
+            else:
+                tcopy = not handed
+            t.pop("dev")
+            hidden_h = owner[:B * T * D * 4].view(np.float32).reshape(B, T, D)
+            seg_h = towner[o_seg:o_seg + B * kslots * 2 * 8].view(np.int64).reshape(B, kslots, 2)
+            feats_h = towner[o_feat:o_feat + B * kslots * D * 4].view(np.float32).reshape(B, kslots, D)
+            outputs = []
+            for i in range(B):
+                n = int(nseg_h[i])
+                segments = seg_h[i, :n].copy() if n > 0 else np.array([])
+                outputs.append({
+                    "segments": segments * 1.0 / FRAME_RATE if in_second else segments,
+                    "segment_features": (feats_h[i, :n].copy() if tcopy else feats_h[i, :n]) if n > 0 else np.array([]),
+                    "hidden_states": hidden_h[i] if handed else hidden_h[i].copy(),
+                })
+            return outputs[0] if t["single"] else outputs
+
+        try:
+            first = next(it)
+        except StopIteration:
+            return
+        # two batches are issued ahead of the one being handed out: the D2H of batch i - 1 takes most of batch i's forward (the
+        # copies share the chip with 160-KiB-LDS GEMM workgroups), so waiting for it before ISSUING batch i + 1 left the GPU idle
+        # now and then (tools/api_timeline.py; 5.98 -> 5.4 ms per batch)
+        nxt = issue_input(first)
+        pending, i = [], 0
+        while nxt is not None:
+            pending.append(issue_compute(nxt, i % 3))
+            try:
+                nxt = issue_input(next(it))               # padded + uploaded under the forward just issued
+            except StopIteration:
+                nxt = None
+            if len(pending) > 2:
+                yield finish(pending.pop(0))
+            i += 1
+        while pending:
+            yield finish(pending.pop(0))
+
     def _nseg_pinned(self, B: int) -> torch.Tensor:
         buf = self.__dict__.get("_nseg_pin")
         if buf is None or buf.numel() < B:

@@ -268,3 +268,40 @@ def test_ragged_serving_loop_is_history_independent(sd):
             assert np.array_equal(g["hidden_states"], e["hidden_states"]) and np.array_equal(h["hidden_states"], e["hidden_states"]), call
             assert np.array_equal(g["segments"], e["segments"]) and np.array_equal(h["segments"], e["segments"]), call
             assert np.array_equal(g["segment_features"], e["segment_features"], equal_nan=True), call
+
+
+def test_stream_of_batches_equals_calls(sd):
+    """Segmenter.stream (padding + H2D of batch i + 1 and D2H + slicing of batch i - 1 under batch i's forward) yields, batch by batch,
+    the bits of the synchronous __call__: ragged batches of changing size, a single-tensor item, both output modes, a batch with
+    more segments than any before it (the tables' second fetch), and a consumer that keeps every result"""
+    from sylber_amd import Segmenter
+    rng = np.random.default_rng(21)
+    batches = []
+    for j in range(7):
+        nb = int(rng.integers(1, 7))
+        batches.append([syllable_wave(int(rng.integers(6000, 60000)), 900 + 10 * j + i) for i in range(nb)])
+    batches.insert(3, syllable_wave(30000, 77))                               # a bare tensor: one dict, not a list
+    batches.append([syllable_wave(200000, 78 + i) for i in range(3)])          # long clips: many segments
+    ref_seg = Segmenter(model_ckpt=sd)
+    ref = [ref_seg(wav=b, in_second=False) for b in batches]
+    for mode in ("pinned", "pageable"):
+        S = Segmenter(model_ckpt=sd, output_memory=mode, max_pinned_batches=3)
+        S._kcap_seen = 16                                                     # force the overflow path early
+        kept = []
+        for got, exp in zip(S.stream(batches, in_second=False), ref):
+            kept.append(got)
+            got_l, exp_l = (got if isinstance(got, list) else [got]), (exp if isinstance(exp, list) else [exp])
+            assert isinstance(got, list) == isinstance(exp, list) and len(got_l) == len(exp_l)
+            for g, e in zip(got_l, exp_l):
+                _check_contract(g, False)
+                assert np.array_equal(g["hidden_states"], e["hidden_states"])
+                assert np.array_equal(g["segments"], e["segments"])
+                assert np.array_equal(g["segment_features"], e["segment_features"], equal_nan=True)
+        assert len(kept) == len(batches)
+        for got, exp in zip(kept, ref):                                       # nothing was overwritten by later batches
+            got_l, exp_l = (got if isinstance(got, list) else [got]), (exp if isinstance(exp, list) else [exp])
+            for g, e in zip(got_l, exp_l):
+                assert np.array_equal(g["hidden_states"], e["hidden_states"]) and np.array_equal(g["segment_features"], e["segment_features"], equal_nan=True)
+    assert list(Segmenter(model_ckpt=sd).stream([])) == []
+    sec = list(Segmenter(model_ckpt=sd).stream(batches[:2], in_second=True))
+    assert all(np.array_equal(a["segments"], b["segments"] / 50.0) for a, b in zip(sec[0], ref[0]))
