@@ -690,19 +690,26 @@ class Segmenter:
         # two batches are issued ahead of the one being handed out: the D2H of batch i - 1 takes most of batch i's forward (the
         # copies share the chip with 160-KiB-LDS GEMM workgroups), so waiting for it before ISSUING batch i + 1 left the GPU idle
         # now and then (tools/api_timeline.py; 5.98 -> 5.4 ms per batch)
-        nxt = issue_input(first)
-        pending, i = [], 0
-        while nxt is not None:
-            pending.append(issue_compute(nxt, i % 3))
-            try:
-                nxt = issue_input(next(it))               # padded + uploaded under the forward just issued
-            except StopIteration:
-                nxt = None
-            if len(pending) > 2:
+        # the three batches in flight hold a leased block each: they must not eat the consumer's `max_pinned_batches` budget, or every
+        # third batch falls back to a pageable copy of its 49 MB of hidden states (a 5 ms host stall, seen as a 7 ms GPU gap)
+        budget = self.out_pool.max_leased
+        self.out_pool.max_leased = budget + 3
+        try:
+            nxt = issue_input(first)
+            pending, i = [], 0
+            while nxt is not None:
+                pending.append(issue_compute(nxt, i % 3))
+                try:
+                    nxt = issue_input(next(it))           # padded + uploaded under the forward just issued
+                except StopIteration:
+                    nxt = None
+                if len(pending) > 2:
+                    yield finish(pending.pop(0))
+                i += 1
+            while pending:
                 yield finish(pending.pop(0))
-            i += 1
-        while pending:
-            yield finish(pending.pop(0))
+        finally:
+            self.out_pool.max_leased = budget
 
     def _nseg_pinned(self, B: int) -> torch.Tensor:
         buf = self.__dict__.get("_nseg_pin")
