@@ -658,10 +658,16 @@ def main():
         for _o in seg_api.stream([host_wavs] * 8, in_second=True):
             pass
         n_stream = 40
+        if os.environ.get("SYLBER_BENCH_DEBUG"):
+            seg_api._trace = []
         t0 = time.perf_counter()
         for _o in seg_api.stream([host_wavs] * n_stream, in_second=True):
             pass
         dt_stream = (time.perf_counter() - t0) / n_stream
+        if os.environ.get("SYLBER_BENCH_DEBUG"):
+            evs_ = [m[2] for m in seg_api._trace if m[0] == "compute issued"]
+            sys.stderr.write("stream GPU gaps (ms): %s\n" % [round(evs_[i].elapsed_time(evs_[i + 1]), 1) for i in range(len(evs_) - 1)])
+            seg_api._trace = None
         del _o
         api = {"value": round(B * clip_seconds / dt, 1), "unit": "audio-sec/s", "ms_per_call": round(dt * 1e3, 2),
                "stream": {"value": round(B * clip_seconds / dt_stream, 1), "unit": "audio-sec/s", "ms_per_batch": round(dt_stream * 1e3, 2),

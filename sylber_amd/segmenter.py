@@ -542,9 +542,10 @@ class Segmenter:
             st = self._stream_streams = concurrent_streams(2, dev, avoid=[cur])        # H2D, D2H
         h2d, d2h = st
         counter = {"in": 0}
+        NSET = 3                                              # device buffer sets = batches issued ahead + 1
 
         def ring_set(j):
-            ring = self.__dict__.setdefault("_stream_dev", [None, None, None])
+            ring = self.__dict__.setdefault("_stream_dev", [None] * 8)
             if ring[j] is None:
                 ring[j] = {"in_free": None, "out_free": None}
             return ring[j]
@@ -583,7 +584,7 @@ class Segmenter:
             # device buffers come from a ring of three grow-only sets with explicit events, not from the caching allocator: blocks
             # handed between streams with record_stream come back late, and the hipMalloc that then happens every third batch
             # synchronises the device (measured: GPU gaps 5.3 / 5.3 / 6.9 ms, tools/api_timeline.py)
-            d = ring_set(counter["in"] % 3)
+            d = ring_set(counter["in"] % NSET)
             counter["in"] += 1
             with torch.cuda.stream(h2d):
                 if d["in_free"] is not None:
@@ -624,7 +625,7 @@ class Segmenter:
             if handed:
                 owner, blk = lease
             else:                                         # pageable mode / pool exhausted: one private bounce block per in-flight slot (three)
-                ring = self.__dict__.setdefault("_stream_scratch", [None, None, None])
+                ring = self.__dict__.setdefault("_stream_scratch", [None] * 8)
                 if ring[slot_id] is None or ring[slot_id].numel() < need:
                     ring[slot_id] = torch.empty((need + (1 << 20) - 1) >> 20 << 20, dtype=torch.uint8, pin_memory=True)
                 blk = ring[slot_id]
@@ -693,17 +694,17 @@ class Segmenter:
         # the three batches in flight hold a leased block each: they must not eat the consumer's `max_pinned_batches` budget, or every
         # third batch falls back to a pageable copy of its 49 MB of hidden states (a 5 ms host stall, seen as a 7 ms GPU gap)
         budget = self.out_pool.max_leased
-        self.out_pool.max_leased = budget + 3
+        self.out_pool.max_leased = budget + NSET
         try:
             nxt = issue_input(first)
             pending, i = [], 0
             while nxt is not None:
-                pending.append(issue_compute(nxt, i % 3))
+                pending.append(issue_compute(nxt, i % NSET))
                 try:
                     nxt = issue_input(next(it))           # padded + uploaded under the forward just issued
                 except StopIteration:
                     nxt = None
-                if len(pending) > 2:
+                if len(pending) > NSET - 1:
                     yield finish(pending.pop(0))
                 i += 1
             while pending:
