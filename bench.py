@@ -655,8 +655,8 @@ def main():
             sys.stderr.write("api call times (ms): %s\n" % [round(x * 1e3, 1) for x in t_api])
         dt = statistics.median(t_api)
         # the same batches through Segmenter.stream: padding + H2D of batch i + 1 and D2H + slicing of batch i - 1 under batch i's forward
-        for _o in seg_api.stream([host_wavs] * 8, in_second=True):
-            pass
+        for _o in seg_api.stream([host_wavs] * 40, in_second=True):      # (warm-up: the page-locked output blocks are allocated one by one,
+            pass                                                          #  tens of ms each, until the pool holds what the loop keeps in flight)
         n_stream = 40
         if os.environ.get("SYLBER_BENCH_DEBUG"):
             seg_api._trace = []
