@@ -583,7 +583,7 @@ class Segmenter:
                 tr.append(("padded", time.perf_counter()))
             # device buffers come from a ring of three grow-only sets with explicit events, not from the caching allocator: blocks
             # handed between streams with record_stream come back late, and the hipMalloc that then happens every third batch
-            # synchronises the device (measured: GPU gaps 5.3 / 5.3 / 6.9 ms, tools/api_timeline.py)
+            # synchronises the device (measured: GPU gaps 5.3 / 5.3 / 6.9 ms, tools/api_stream_timeline.py)
             d = ring_set(counter["in"] % NSET)
             counter["in"] += 1
             with torch.cuda.stream(h2d):
@@ -606,7 +606,7 @@ class Segmenter:
             out = (flat(d, "seg", B_ * T_ * 2, torch.int64).view(B_, T_, 2), flat(d, "nseg", B_, torch.int32),
                    flat(d, "feat", B_ * T_ * 768, torch.float32).view(B_, T_, 768))
             seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold, out=out)
-            tr = self.__dict__.get("_trace")                  # tools/api_timeline.py STREAM=1: (label, host time[, event]) marks
+            tr = self.__dict__.get("_trace")                  # tools/api_stream_timeline.py: (label, host time[, event]) marks
             done = torch.cuda.Event(enable_timing=tr is not None)
             done.record(cur)
             if tr is not None:
@@ -690,7 +690,7 @@ class Segmenter:
             return
         # two batches are issued ahead of the one being handed out: the D2H of batch i - 1 takes most of batch i's forward (the
         # copies share the chip with 160-KiB-LDS GEMM workgroups), so waiting for it before ISSUING batch i + 1 left the GPU idle
-        # now and then (tools/api_timeline.py; 5.98 -> 5.4 ms per batch)
+        # now and then (tools/api_stream_timeline.py)
         # the three batches in flight hold a leased block each: they must not eat the consumer's `max_pinned_batches` budget, or every
         # third batch falls back to a pageable copy of its 49 MB of hidden states (a 5 ms host stall, seen as a 7 ms GPU gap)
         budget = self.out_pool.max_leased
