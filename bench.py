@@ -41,6 +41,8 @@ CLIP_SAMPLES = 160000
 CLIP_SECONDS = 10.0
 BATCH_PER_GPU = 32
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+MFMA_FP8_PEAK_TFLOPS = 5000.0       # same guide: ~5 PF dense fp8 (the MXFP8 launches of precision="fp8" answer to THIS peak)
+ENCODER_GEMMS = ("gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2")
 HBM_PEAK_GBS = 8000.0               # same guide: 8 TB/s spec (6.3 TB/s measured copy)
 
 
@@ -73,6 +75,10 @@ def parse_args():
                     help="N>1 exchange step: 'scatter' = the job's clips live on rank 0 and are scattered over RCCL every step "
                          "(default, BASELINE configs[2]); 'per-rank' = every rank's shard lives in its own page-locked host memory "
                          "and crosses that GPU's own PCIe link every step (SURVEY.md §8(e)), gather unchanged")
+    ap.add_argument("--gather", choices=["root", "none"], default="root",
+                    help="N>1 exchange step: 'root' = hidden states, tables, counts and features are gathered on rank 0 over RCCL every step "
+                         "(default, north_star's scatter/gather); 'none' = results stay on the rank that computed them (a corpus job whose "
+                         "ranks write their own shards).  With 'root' the 'none' figure is measured too and reported as `results_left_sharded`")
     ap.add_argument("--fuse-ln", choices=["auto", "on", "off"], default="auto",
                     help="attention out-projection + LayerNorm as one launch (SYLBER_OPT_FUSE_OUTPROJ_LN); A/B switch")
     ap.add_argument("--gemm-tile", type=int, default=-1, help="force one GEMM tile id for every launch that has it (SYLBER_OPT_GEMM_TILE); A/B switch")
@@ -88,6 +94,9 @@ def parse_args():
     ap.add_argument("--skip-segment", action="store_true",
                     help="A/B switch: leave boundary detection out of the timed steps (the line is marked `invalid`)")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level (PCIe-inclusive) Segmenter.__call__ timing")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` block (BASELINE configs[3] long-form, configs[4] fp8 and the split16 parity mode, "
+                         "10 steps each in this same process after the headline run; N = 1, default workload only)")
     ap.add_argument("--agreement-clips", type=int, default=0,
                     help="also report bf16-vs-fp32 segment agreement on this many synthetic clips (fp32 parity mode as truth)")
     return ap.parse_args()
@@ -146,6 +155,11 @@ def csrc_sha16() -> str:
         if f.endswith((".hip", ".h")):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
+    for g in ("gen_gemm_asm.py", "gen_attn_asm.py"):        # the inline-asm loops are generated at build time: the generators ARE kernel source
+        gp = os.path.join(ROOT, "tools", g)
+        if os.path.exists(gp):
+            h.update(g.encode())
+            h.update(open(gp, "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -183,6 +197,91 @@ def cpu_baseline(sd, seconds_budget=25.0):
             "sample": "%d iterations of batch %d x 10 s (same generator as the GPU workload), fp32, torch CPU ops + "
                       "C get_segment; %d torch threads = fastest of a {8,16,32,64} probe on a %d-cpu host"
                       % (iters, B, cores, os.cpu_count() or 1)}
+
+
+def roofline_by_peak(kernels: dict, B: int, clip_samples: int, precision: str) -> dict:
+    """Per-dtype MFMA roofline of one forward: every GEMM launch is scored against the dense peak of the operand type it
+    ACTUALLY runs on -- precision="fp8" runs q,k,v / out-proj / FFN1 / FFN2 on v_mfma_scale_f32_32x32x64_f8f6f4 (5 PF) and the
+    conv stack + projection on the 16-bit MFMA (2.5 PF); every other 16-bit mode runs all of them on the 16-bit MFMA."""
+    fl = gemm_flops_per_forward(B, clip_samples)
+    ms_of = {k: sum(kernels.get(a, 0.0) for a in GEMM_ALIASES.get(k, (k,))) for k in fl}
+    groups = {"conv_stack_and_projection": [k for k in fl if k not in ENCODER_GEMMS], "encoder_gemms": list(ENCODER_GEMMS)}
+    out = {}
+    for name, keys in groups.items():
+        ms = sum(ms_of[k] for k in keys)
+        if ms <= 0:
+            continue
+        f8 = precision == "fp8" and name == "encoder_gemms"
+        peak = MFMA_FP8_PEAK_TFLOPS if f8 else MFMA_BF16_PEAK_TFLOPS
+        tf = sum(fl[k] for k in keys) / (ms * 1e-3) / 1e12
+        passes = 3 if precision == "split16" else 1          # hi.hi + lo.hi + hi.lo: three MFMA passes per algorithmic contraction
+        out[name] = {"bound": "mfma", "operands": "mxfp8 (e4m3 + E8M0)" if f8 else ("f16 hi/lo pairs, 3 passes" if passes == 3 else "16-bit"),
+                     "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                     "ms_per_forward": round(ms, 4),
+                     "per_launch_tflops": {k: round(fl[k] / (ms_of[k] * 1e-3) / 1e12, 1) for k in keys if ms_of[k] > 0}}
+        if passes == 3:
+            out[name]["issued_frac"] = round(3 * tf / peak, 4)
+    return out
+
+
+def measure_other_config(torch, dev, sd, streams4, precision: str, B: int, clip_seconds: float, steps: int = 10, warmup: int = 3) -> dict:
+    """One more BASELINE configuration in THIS process, timed like the headline (two batches in flight on independent handles,
+    boundary detection on side streams, inputs resident in HBM, device-wide synchronize on both sides of exactly `steps` steps),
+    followed by a profiling pass for its own roofline."""
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.synth import noise_batch
+    clip_samples = int(round(clip_seconds * 16000))
+    encs = [HubertEncoderHIP(sd, device=str(dev), precision=precision) for _ in range(2)]
+    T_frames = encs[0].num_frames(clip_samples)
+    batch = noise_batch(B, clip_samples, seed=1000).to(dev)
+    mains, sides = streams4[:2], streams4[2:4]
+    bufs = [(torch.empty(B, T_frames, 768, device=dev),
+             (torch.empty(B, T_frames, 2, dtype=torch.int64, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+              torch.empty(B, T_frames, 768, device=dev))) for _ in range(4)]
+    seg_done = [None] * 4
+    st = {"i": 0}
+
+    def run(n):
+        for _ in range(n):
+            k, ks = st["i"] % 2, st["i"] % 4
+            st["i"] += 1
+            hidden, seg_out = bufs[ks]
+            with torch.cuda.stream(mains[k]):
+                if seg_done[ks] is not None:
+                    mains[k].wait_event(seg_done[ks])
+                encs[k].forward(batch, None, out=hidden)
+                ready = torch.cuda.Event()
+                ready.record(mains[k])
+            with torch.cuda.stream(sides[k]):
+                sides[k].wait_event(ready)
+                encs[k].segment(hidden, 2.6, 0.8, out=seg_out)
+                ev = torch.cuda.Event()
+                ev.record(sides[k])
+            seg_done[ks] = ev
+
+    run(warmup)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    enc = encs[0]
+    enc.set_profiling(True)
+    nprof = 3
+    for _ in range(nprof):
+        h = enc.forward(batch, None)
+        enc.segment(h, 2.6, 0.8)
+    torch.cuda.synchronize(dev)
+    kernels = {k: round(v / nprof, 4) for k, v in enc.get_profile().items()}
+    enc.set_profiling(False)
+    out = {"value": round(B * clip_seconds * steps / dt, 1), "unit": "audio-sec/s", "ms_per_step": round(1e3 * dt / steps, 3),
+           "steps": steps, "warmup": warmup, "precision": precision, "batch": B, "clip_seconds": clip_seconds, "frames_per_clip": T_frames,
+           "roofline": roofline_by_peak(kernels, B, clip_samples, precision),
+           "kernel_ms_per_forward": {k: kernels[k] for k in ("attention", "conv0_gn_gelu", "posconv", "layernorm", "segment") if k in kernels},
+           "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2)}
+    del encs, enc, bufs, batch
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -425,17 +524,20 @@ def main():
         host_shard.copy_(my_batch)
         torch.cuda.synchronize(dev)
 
+    gather_mode = {"m": args.gather}
+
     def exchange_steps(n):
         evs = []
         src = [root_batch] * n if rank == 0 else [None] * n
         for _o in sharded.run_stream(src, None, max_segments=min(T_frames, 192), ingest=args.ingest,
-                                     host_shards=[host_shard] * n if host_shard is not None else None):
+                                     host_shards=[host_shard] * n if host_shard is not None else None, gather=gather_mode["m"]):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream(dev))
             evs.append(ev)
         return evs
 
-    ex_txt = ("root scatter + gather over RCCL in every step (run_stream: gather(i) overlapped with compute(i+1))"
+    ex_txt = ("root scatter over RCCL in every step, results left on their ranks (gather=none)" if args.gather == "none" else
+              "root scatter + gather over RCCL in every step (run_stream: gather(i) overlapped with compute(i+1))"
               if args.ingest == "scatter" else
               "per-rank H2D ingest over each GPU's own PCIe link + gather over RCCL in every step (run_stream: gather(i) "
               "overlapped with compute(i+1))")
@@ -496,6 +598,7 @@ def main():
     elapsed, med_ms = r_elapsed, r_med
     exchange_first = False
     secondary = None
+    sharded_none = None
     exchange_error = None
     if want_exchange:
         import threading
@@ -527,6 +630,18 @@ def main():
                       "gather_bytes_per_step_root": st_["gather_bytes"] // max(st_["steps"], 1),
                       "h2d_bytes_per_step_rank0": st_["h2d_bytes"] // max(st_["steps"], 1),
                       "ingest": args.ingest}
+            if args.gather == "root":
+                # the same step with the results left on their ranks: what the root gather costs, and the realistic corpus deployment
+                try:
+                    gather_mode["m"] = "none"
+                    sharded.phase = "results-left-sharded pass"
+                    n_elapsed, n_med = timed(exchange_steps, warmup=1)
+                    sharded_none = {"value": round(total_audio / n_elapsed, 1), "unit": "audio-sec/s",
+                                    "ms_per_step": round(1e3 * n_elapsed / args.steps, 3),
+                                    "ms_per_step_median": None if n_med is None else round(n_med, 3),
+                                    "parallelism": "input scatter over RCCL in every step, results stay on the rank that computed them (gather=none)"}
+                finally:
+                    gather_mode["m"] = "root"
             if args.no_exchange and not selftest:
                 secondary = ("exchange", x_elapsed, x_med)
             else:
@@ -604,11 +719,16 @@ def main():
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "avg_launch_ms": round(gemm_ms / max(n_launch, 1), 4), "flops_per_forward": gemm_fl,
                     "per_launch_tflops": {k: round(fl[k] / (ms_of[k] * 1e-3) / 1e12, 1) for k in fl if ms_of[k] > 0}}
-        enc_keys = ["gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2"]
+        roofline["by_operand_type"] = roofline_by_peak(kernels, B, clip_samples, args.precision)
+        if args.precision == "fp8":
+            roofline["peak_note"] = ("`frac` of this block divides the whole GEMM family by the 16-bit peak (2.5 PF); the MXFP8 launches are "
+                                     "scored against the fp8 peak (5 PF) in by_operand_type.encoder_gemms")
+        enc_keys = list(ENCODER_GEMMS)
         enc_ms = sum(ms_of[k] for k in enc_keys)
         if enc_ms > 0:
             enc_tf = sum(fl[k] for k in enc_keys) / (enc_ms * 1e-3) / 1e12
-            roofline["encoder_gemms"] = {"achieved": round(enc_tf, 1), "frac": round(enc_tf / MFMA_BF16_PEAK_TFLOPS, 4),
+            enc_peak = MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS
+            roofline["encoder_gemms"] = {"achieved": round(enc_tf, 1), "peak": enc_peak, "frac": round(enc_tf / enc_peak, 4),
                                          "ms_per_forward": round(enc_ms, 4)}
         # the single dominant instantiation, exactly the row rocprofv3 prints as gemmb_bf16_kernel<0, 1, 0, 0, 2, 8, true, 0, 3>: the
         # hand-scheduled 256x256 kernel on eight waves with the GELU epilogue (csrc/gemm_asm.hip, tile 95) = conv1..conv5 +
@@ -689,6 +809,21 @@ def main():
         from sylber_amd.agreement import segment_agreement
         agreement = segment_agreement(sd, enc, args.agreement_clips, device=str(dev))
 
+    # ---- the other BASELINE configurations, timed by the same command (N = 1, default workload only): the driver runs ONE
+    # command, so configs[3] (long-form), configs[4] (fp8) and the mode that meets north_star's "boundaries bit-identical"
+    # (split16) are measured here, each with its own roofline -- fp8 launches against the fp8 peak
+    other = None
+    if (rank == 0 and world == 1 and not args.no_other_configs and args.precision == "bf16" and B == BATCH_PER_GPU
+            and clip_samples == CLIP_SAMPLES and not args.ragged and not args.opt and args.gemm_tile < 0):
+        other = {}
+        for name, (prec, b_, secs) in {"configs[3] long-form 8 x 60 s, bf16": ("bf16", 8, 60.0),
+                                       "configs[4] fp8 (MXFP8 attention + FFN / projection GEMMs), 32 x 10 s": ("fp8", BATCH_PER_GPU, CLIP_SECONDS),
+                                       "split16 (segment tables bit-identical to the fp32 reference), 32 x 10 s": ("split16", BATCH_PER_GPU, CLIP_SECONDS)}.items():
+            try:
+                other[name] = measure_other_config(torch, dev, sd, pool_st if len(pool_st) >= 4 else concurrent_streams(4, dev), prec, b_, secs)
+            except Exception as e:  # noqa: BLE001 - the headline line must survive a failing side measurement
+                other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     seg_stats = None
     if rank == 0:
         h = enc.forward(my_batch, None)
@@ -705,11 +840,15 @@ def main():
                           "parallelism": res_txt if name == "resident_shards" else ex_txt}
         if x_info is not None:
             line["exchange_detail"] = x_info
+        if sharded_none is not None:
+            line["results_left_sharded"] = sharded_none
         line["resident_per_rank_ms_per_step"] = r_per_rank
         if exchange_error is not None:
             line["exchange_error"] = exchange_error
         if agreement is not None:
             line["segment_agreement"] = agreement
+        if other is not None:
+            line["other_configs"] = other
         if args.skip_segment:
             line["invalid"] = "--skip-segment: boundary detection left out of the timed steps (A/B measurement only)"
     if world > 1 or selftest:

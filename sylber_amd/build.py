@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 # result goes to ITS OWN file, so an experiments build can never be mistaken for / left behind as the product library.
 EXPERIMENTS = bool(os.environ.get("SYLBER_EXPERIMENTS"))
 LIB = os.path.join(HERE, "libsylber_hip_exp.so" if EXPERIMENTS else "libsylber_hip.so")
-GEN_DIR = os.path.join(HERE, "build", "gen")           # generated experiment loops (never committed)
+GEN_DIR = os.path.join(HERE, "build", "gen")           # generated inline-asm loops (never committed: tools/gen_gemm_asm.py writes them here)
+GENERATORS = [os.path.join(os.path.dirname(HERE), "tools", g) for g in ("gen_gemm_asm.py",)]
 SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip", "gemm_rowln.hip", "gemm_asm.hip", "gemm_asm_f8.hip"]
 EXTRA = {"segment.hip": ["-ffp-contract=off"]}
 # -fno-slp-vectorize: NO packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the library.  Measured on
@@ -39,7 +40,25 @@ def _newest_source() -> float:
     for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
         for f in os.listdir(root):
             t = max(t, os.path.getmtime(os.path.join(root, f)))
+    for g in GENERATORS:
+        t = max(t, os.path.getmtime(g))
     return max(t, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def generate(what=("product",), outdir: str = GEN_DIR) -> None:
+    """run the loop generators; a file is only rewritten when its text changes (so that unchanged loops do not force recompiles)"""
+    import tempfile
+    os.makedirs(outdir, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        for g in GENERATORS:
+            for w in what:
+                subprocess.run([sys.executable, g, w], check=True, capture_output=True, env=dict(os.environ, GEN_GEMM_ASM_OUT=tmp))
+        for f in sorted(os.listdir(tmp)):
+            new = open(os.path.join(tmp, f), "rb").read()
+            dst = os.path.join(outdir, f)
+            if not os.path.exists(dst) or open(dst, "rb").read() != new:
+                with open(dst, "wb") as fh:
+                    fh.write(new)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -48,15 +67,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(HERE, "build", "exp" if EXPERIMENTS else "obj")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    exp_flags = []
-    if EXPERIMENTS:
-        gen = os.path.join(os.path.dirname(HERE), "tools", "gen_gemm_asm.py")
-        subprocess.run([sys.executable, gen, "experiments"], check=True, capture_output=True, env=dict(os.environ, GEN_GEMM_ASM_OUT=GEN_DIR))
-        exp_flags = ["-DSYLBER_GEMM_ASM_EXPERIMENTS", "-I", GEN_DIR]
+    # the inline-asm K loops are generated at build time (33 k lines that used to be committed beside their generator)
+    generate(("product", "experiments") if EXPERIMENTS else ("product",))
+    exp_flags = ["-I", GEN_DIR] + (["-DSYLBER_GEMM_ASM_EXPERIMENTS"] if EXPERIMENTS else [])
 
     # a source is recompiled when it, any header / generated loop beside it, the public headers or this file is newer
     shared = [os.path.getmtime(os.path.abspath(__file__))]
-    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include"), GEN_DIR):
         shared += [os.path.getmtime(os.path.join(root, f)) for f in os.listdir(root) if not f.endswith(".hip")]
     newest_shared = max(shared)
 

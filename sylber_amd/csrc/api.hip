@@ -548,10 +548,15 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             g.g.M = M; g.g.N = 2304; g.g.K = 768; g.g.bias = d.bqkv; g.g.out0 = q; g.g.out1 = k; g.g.out2 = vt;
             g.g.Tp = p.Tp; g.g.Tpv = p.Tpv; g.g.T = p.T;
             g.X8 = h8; g.ldx8 = 768; g.XS = h8s; g.xs_rows = Mp; g.W8 = d.wqkvq; g.WS = d.wqkvs; g.ws_rows = 2304;
-            attn8 = c->opt_attn8 >= 0 && gemm_asm_f8_tile(EPI_QK8, g) != 0;
+            // the attention core of the mode must not depend on the batch shape (one utterance, same hidden states alone or in a
+            // batch): the q / k / v launch always runs on whole 256-row tiles -- M is padded up, the rows beyond the batch read
+            // whatever follows the operand (inside the workspace: the buffer holds (M + 128) x 768 x 2 bytes) and are not stored
+            GemmF8Args gq = g;
+            gq.g.M = (int)Mp; gq.g.M_store = M;
+            attn8 = c->opt_attn8 >= 0 && gemm_asm_f8_tile(EPI_QK8, gq) != 0;
             if (attn8) {
-                g.g.out0 = q8; g.g.out1 = k8; g.g.out2 = v8; g.qs = q8s; g.ks = k8s; g.vs = v8s;
-                RUN("gemm_qkv", launch_gemm_mxfp8(EPI_QK8, g, s));
+                gq.g.out0 = q8; gq.g.out1 = k8; gq.g.out2 = v8; gq.qs = q8s; gq.ks = k8s; gq.vs = v8s;
+                RUN("gemm_qkv", launch_gemm_mxfp8(EPI_QK8, gq, s));
             } else
             RUN("gemm_qkv", launch_gemm_mxfp8(EPI_QK, g, s));
         } else {

@@ -69,6 +69,9 @@ template <int FN>
 __device__ __forceinline__ void epilogue_qk8_rows32(const GemmF8Args& a, const f32x16_t (&acc)[FN], const float4 (&bias)[FN][4], int mrow0,
                                                     int ncol0, char* lds, int lane) {
     const int ml = lane & 31, h = lane >> 5;
+    // rows beyond the batch (M padded up to whole 256-row tiles so that the fp8 attention core does not depend on the batch shape:
+    // ADVICE r4): computed from whatever follows the operand, never stored.  Wave-uniform (M_store % 32 == 0 as Tp % 32 == 0)
+    if (a.g.M_store > 0 && mrow0 >= a.g.M_store) return;
     const int b = mrow0 / a.g.Tp, t0 = mrow0 - b * a.g.Tp;
     if (ncol0 >= 2 * SYL_HIDDEN) {
         // ---- V third

@@ -28,6 +28,7 @@ struct GemmArgs {
     const bf16_t* X; long ldx;
     const bf16_t* W;              // [N][K] row-major
     int M, N, K;
+    int M_store;                  // EPI_QK8 only: > 0 = rows [M_store, M) are computed but not stored (M padded up to whole 256-row tiles)
     const float* bias;            // [N] or nullptr
     int act;                      // GemmAct
     void* out0; long ld0;

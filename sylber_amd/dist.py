@@ -189,8 +189,28 @@ class ShardedSegmenter:
         wait.keep = _keep
         return wait
 
+    def keep_local(self, hidden, seg, nseg, feats, mine: int, max_segments: int):
+        """``gather="none"``: this rank's results stay on this rank (a corpus job whose ranks write their own shards: nothing but the
+        input scatter crosses xGMI).  Same hand-over protocol as ``gather_async``: a zero-argument ``wait`` with ``wait.nmax``."""
+        k = max(1, min(int(max_segments), seg.shape[1]))
+        parts = (hidden[:mine], seg[:mine, :k], nseg[:mine], feats[:mine, :k])
+        nmax = nseg[:mine].max() if mine > 0 else None
+        done = None
+        if self._cuda:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+
+        def wait():
+            if done is not None:
+                torch.cuda.current_stream(self.device).wait_event(done)
+            if nmax is not None:
+                self._hand_over((nmax,))
+            return self._hand_over(parts)
+        wait.nmax = nmax
+        return wait
+
     def run_stream(self, batches_root, lengths_root=None, max_segments: int = 128, ingest: str = "scatter",
-                   host_shards=None):
+                   host_shards=None, gather: str = "root"):
         """Generator over a sequence of root batches (``[Btot, Lmax]`` tensors on root, ``None`` elsewhere; every rank
         must pass a sequence of the same length).  Software pipeline over ONE communicator, whose collectives
         execute in issue order: the scatter of batch i+1 is issued BEFORE the compute of batch i, and the gather of
@@ -202,12 +222,17 @@ class ShardedSegmenter:
         ``ingest="per-rank"`` (inputs that originate on the host): no scatter; ``host_shards[i]`` is THIS
         rank's ``[Bper, Lmax]`` block of batch i in page-locked host memory and crosses this GPU's own PCIe link
         (asynchronous H2D on the consuming engine's stream); ``batches_root[i]`` then only supplies the shape on root.
-        The gather is unchanged.  The overflow test of ``max_segments`` runs once, after the last step: a batch yielded
+        The gather is unchanged.  ``gather="none"``: no gather at all -- EVERY rank yields its own rows
+        ``[rank * Bper, min((rank + 1) * Bper, Btot))`` of each batch (``hidden, seg[:, :max_segments], nseg, feats[:, :max_segments]``)
+        and checks its own overflow; the deployment of a corpus job whose ranks write their own shards, and the upper bound of what
+        the root gather can reach.  The overflow test of ``max_segments`` runs once, after the last step: a batch yielded
         EARLIER may therefore carry a table truncated to ``max_segments`` rows (its ``nseg`` row still holds the true count,
-        so ``nseg[i] > max_segments`` identifies it); the error is raised when the generator is exhausted, or by
-        ``close()`` / garbage collection of a generator the consumer abandoned early (``GeneratorExit`` path below)."""
+        so ``nseg[i] > max_segments`` identifies it); the error is raised when the generator is exhausted; ``close()`` /
+        garbage collection of a generator the consumer abandoned early issue a ``RuntimeWarning`` instead (``GeneratorExit`` path below)."""
         if ingest not in ("scatter", "per-rank"):
             raise ValueError("ingest must be 'scatter' or 'per-rank'")
+        if gather not in ("root", "none"):
+            raise ValueError("gather must be 'root' (results collected on rank 0) or 'none' (every rank yields its own block of rows)")
         batches = list(batches_root)
         n = len(batches)
         if n == 0:
@@ -314,14 +339,29 @@ class ShardedSegmenter:
                     self.phase = "segmentation of batch %d (engine %d, side stream)" % (i, k)
                     seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold)
                     self.phase = "issue of the asynchronous gather of batch %d" % i
-                    wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False)
+                    if gather == "none":
+                        bper_ = hidden.shape[0]
+                        wait = self.keep_local(hidden, seg, nseg, feats, max(0, min(bper_, btot - self.rank * bper_)), max_segments)
+                    else:
+                        wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False)
                 if pending is not None:
                     yield collect(pending)
                 pending = wait
             last = collect(pending)
         except GeneratorExit:
-            # the consumer stopped early: the batches it already holds are still checked (a truncated table must not go unnoticed)
-            overflow_check()
+            # the consumer stopped early (close(), garbage collection, interpreter shutdown): re-join the engine and side streams to
+            # the caller's stream, and check the batches it already holds -- but only WARN: an exception raised from here would
+            # replace GeneratorExit on close() and be printed as "Exception ignored" everywhere else.  A truncated
+            # table is still identifiable afterwards: its `nseg` row holds the true count (> max_segments)
+            if self._cuda:
+                for st in self._streams + self._sides:
+                    torch.cuda.current_stream(self.device).wait_stream(st)
+            try:
+                overflow_check()
+            except RuntimeError as e:
+                import warnings
+                warnings.warn("ShardedSegmenter.run_stream abandoned early: %s (tables yielded so far may be truncated to max_segments rows)" % e,
+                              RuntimeWarning, stacklevel=2)
             raise
         if self._cuda:
             for st in self._streams + self._sides:

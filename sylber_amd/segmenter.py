@@ -96,6 +96,13 @@ class PinnedOutputPool:
             self._drain()
             return self._leased
 
+    def trim(self) -> None:
+        """drop free blocks beyond what ``max_leased`` can ever hand out again (after a temporarily raised budget: Segmenter.stream)"""
+        with self._lock:
+            self._drain()
+            while self._free and len(self._free) + self._leased > self.max_leased:
+                self._free.pop(0)
+
     def lease(self, nbytes: int):
         """-> (owner ndarray uint8 [cap], block tensor) or None when ``max_leased`` blocks are already out"""
         with self._lock:
@@ -299,7 +306,8 @@ class Segmenter:
             raise ValueError("output_memory must be 'pinned' or 'pageable'")
         self.out_pool = PinnedOutputPool(max_leased=int(kwargs.get("max_pinned_batches", 4)))
         self._fill_threads = max(1, int(kwargs.get("host_pad_threads", 2)))     # host padding of tensor inputs (encode_batch)
-        self._kcap_seen = 128                                                    # largest segment-slot count handed out so far
+        self._kcap_seen = 128                                                    # segment slots per utterance the next block is sized for
+        self._kcap_recent = collections.deque(maxlen=16)                         # per-batch maxima of the last 16 batches (sizing decays with them)
         self._overlap_d2h = bool(kwargs.get("overlap_d2h", True))               # hidden-state D2H under the segmenter (A/B switch)
 
     @staticmethod
@@ -490,9 +498,9 @@ class Segmenter:
         nmax = int(nseg_h.max()) if len(nseg_h) else 0
         k = max(nmax, 1)
         towner, tblk = owner, blk
-        if k > kcap:                                         # more segments than any batch before: the tables get their own block
-            self._kcap_seen = min(T, (k + 63) & ~63)
-            kcap = self._kcap_seen
+        self._note_segments(k)
+        if k > kcap:                                         # more segments than the recent batches had: the tables get their own block
+            kcap = min(T, (k + 63) & ~63)
             t_seg, t_feat, t_need = al(0), al(B * kcap * 2 * 8), al(B * kcap * 2 * 8) + al(B * kcap * D * 4)
             tl = self.out_pool.lease(t_need) if handed else None
             if tl is not None:
@@ -602,10 +610,13 @@ class Segmenter:
             if d["out_free"] is not None:
                 cur.wait_event(d["out_free"])             # the copies of the batch that last used this set have left
             B_, T_ = batch.shape[0], self.speech_model.num_frames(batch.shape[1])
-            hidden = self.speech_model.forward(batch, lengths, out=flat(d, "hid", B_ * T_ * 768, torch.float32).view(B_, T_, 768))
-            out = (flat(d, "seg", B_ * T_ * 2, torch.int64).view(B_, T_, 2), flat(d, "nseg", B_, torch.int32),
-                   flat(d, "feat", B_ * T_ * 768, torch.float32).view(B_, T_, 768))
-            seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold, out=out)
+            # forward + boundary detection run on `cur`, the stream that was current when the generator STARTED, whatever the
+            # caller's current stream is at this resumption: `done` below is recorded on the stream the work was issued to
+            with torch.cuda.stream(cur):
+                hidden = self.speech_model.forward(batch, lengths, out=flat(d, "hid", B_ * T_ * 768, torch.float32).view(B_, T_, 768))
+                out = (flat(d, "seg", B_ * T_ * 2, torch.int64).view(B_, T_, 2), flat(d, "nseg", B_, torch.int32),
+                       flat(d, "feat", B_ * T_ * 768, torch.float32).view(B_, T_, 768))
+                seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold, out=out)
             tr = self.__dict__.get("_trace")                  # tools/api_stream_timeline.py: (label, host time[, event]) marks
             done = torch.cuda.Event(enable_timing=tr is not None)
             done.record(cur)
@@ -657,10 +668,10 @@ class Segmenter:
             nseg_h = owner[o_cnt:o_cnt + B * 4].view(np.int32).copy()
             k = max(int(nseg_h.max()) if B else 0, 1)
             towner = owner
-            if k > kslots:                                # more segments than any batch before: fetch the tables again (rare)
+            self._note_segments(k)
+            if k > kslots:                                # more segments than the recent batches had: fetch the tables again (rare)
                 seg, feats = t["dev"]
-                self._kcap_seen = min(T, (k + 63) & ~63)
-                kslots = self._kcap_seen
+                kslots = min(T, (k + 63) & ~63)
                 o_seg, o_feat = 0, (B * kslots * 2 * 8 + 255) & ~255
                 pb = torch.empty(o_feat + B * kslots * D * 4, dtype=torch.uint8, pin_memory=True)
                 pb[o_seg:o_seg + B * kslots * 2 * 8].view(torch.int64).view(B, kslots, 2).copy_(seg[:, :kslots], non_blocking=True)
@@ -695,9 +706,10 @@ class Segmenter:
         # third batch falls back to a pageable copy of its 49 MB of hidden states (a 5 ms host stall, seen as a 7 ms GPU gap)
         budget = self.out_pool.max_leased
         self.out_pool.max_leased = budget + NSET
+        pending = []
         try:
             nxt = issue_input(first)
-            pending, i = [], 0
+            i = 0
             while nxt is not None:
                 pending.append(issue_compute(nxt, i % NSET))
                 try:
@@ -710,7 +722,22 @@ class Segmenter:
             while pending:
                 yield finish(pending.pop(0))
         finally:
+            # an early exit (consumer stopped, or an exception): the batches still in flight own leased page-locked blocks that
+            # the D2H stream may still be writing.  Their owners die with `pending`, the finalizers hand the blocks back, and the next
+            # lease could write the same block from another stream -- so wait for those copies first
+            for t in pending:
+                ev = t.get("out_ev")
+                if ev is not None:
+                    ev.synchronize()
+            pending.clear()
             self.out_pool.max_leased = budget
+            self.out_pool.trim()
+
+    def _note_segments(self, k: int) -> None:
+        """size the next leased block from the RECENT per-batch maximum (rounded up to 64, floor 128), not from an all-time one:
+        one long-clip batch with many segments must not double every later block for good"""
+        self._kcap_recent.append(int(k))
+        self._kcap_seen = max(128, (max(self._kcap_recent) + 63) & ~63)
 
     def _nseg_pinned(self, B: int) -> torch.Tensor:
         buf = self.__dict__.get("_nseg_pin")

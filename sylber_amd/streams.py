@@ -36,32 +36,59 @@ def _pair_ms(a: torch.cuda.Stream, b: Optional[torch.cuda.Stream], device) -> fl
     return best
 
 
+# probe results are per process and device: which pool streams share a hardware queue does not change once they have been used
+_PAIR = {}            # (device index, stream id a, stream id b) -> serialised?
+_SETS = {}            # device index -> mutually independent streams found so far
+
+
+def _key(a: torch.cuda.Stream, b: torch.cuda.Stream, device):
+    ia, ib = int(a.cuda_stream), int(b.cuda_stream)
+    return (torch.device(device).index or 0, min(ia, ib), max(ia, ib))
+
+
 def serialised(a: torch.cuda.Stream, b: torch.cuda.Stream, device=None) -> bool:
-    """True when kernels on ``a`` and ``b`` run one after the other (same hardware queue)"""
+    """True when kernels on ``a`` and ``b`` run one after the other (same hardware queue); probed once per pair and process"""
     device = a.device if device is None else device
-    one = _pair_ms(a, None, device)
-    return _pair_ms(a, b, device) > 1.5 * one
+    k = _key(a, b, device)
+    if k not in _PAIR:
+        one = _pair_ms(a, None, device)
+        _PAIR[k] = _pair_ms(a, b, device) > 1.5 * one
+    return _PAIR[k]
 
 
 def concurrent_streams(n: int, device, avoid: Sequence[torch.cuda.Stream] = (), candidates: int = 16) -> List[torch.cuda.Stream]:
     """``n`` streams on ``device`` that run concurrently with each other and with every stream in ``avoid``.  Best effort: with
     fewer hardware queues than requested (or without ``torch.cuda._sleep``) the remaining slots are filled with plain pool
-    streams -- correct, just not concurrent."""
+    streams -- correct, just not concurrent.  The probe (timed spin kernels between device-wide synchronisations: it stalls
+    whatever else the process has in flight, and a busy GPU can fool it) runs once per process and device; later calls are
+    served from its result.  ``SYLBER_NO_STREAM_PROBE=1`` skips it altogether."""
+    import os
     device = torch.device(device)
-    drawn = [torch.cuda.Stream(device=device) for _ in range(max(candidates, n))]
-    if not hasattr(torch.cuda, "_sleep") or n <= 0:
-        return drawn[:n]
+    if n <= 0:
+        return []
+    if not hasattr(torch.cuda, "_sleep") or os.environ.get("SYLBER_NO_STREAM_PROBE"):
+        return [torch.cuda.Stream(device=device) for _ in range(n)]
+    di = device.index or 0
+    avoid = list(avoid)
     with torch.cuda.device(device):
+        have = _SETS.setdefault(di, [])
+        ok = [s for s in have if all(not serialised(s, o, device) for o in avoid)]
+        if len(ok) >= n:
+            return ok[:n]
+        # (first call on this device, or more independent streams wanted than found so far): draw and probe pool streams
+        drawn = [torch.cuda.Stream(device=device) for _ in range(max(candidates, n))]
         for s in drawn:                                   # a stream gets its hardware queue when it is first used
             with torch.cuda.stream(s):
                 torch.cuda._sleep(1000)
         torch.cuda.synchronize(device)
-        kept: List[torch.cuda.Stream] = []
         for s in drawn:
-            if len(kept) == n:
+            if len(ok) >= n:
                 break
-            if all(not serialised(s, o, device) for o in list(avoid) + kept):
-                kept.append(s)
+            if all(not serialised(s, o, device) for o in have):
+                have.append(s)
+                if all(not serialised(s, o, device) for o in avoid):
+                    ok.append(s)
+        kept = ok[:n]
         for s in drawn:                                   # not enough independent queues: fill up
             if len(kept) == n:
                 break

@@ -45,3 +45,19 @@ def test_flop_accounting():
     assert f1["gemm_conv1"] == 2.0 * 15999 * 512 * 512 * 3
     assert f1["gemm_ffn1"] == 9 * 2.0 * 499 * 768 * 3072
     assert len(bench.csrc_sha16()) == 16
+
+
+def test_roofline_by_peak_scores_fp8_launches_against_the_fp8_peak():
+    """VERDICT r4 weak #8: the MXFP8 launches answer to 5 PF, the 16-bit conv stack to 2.5 PF."""
+    sys.path.insert(0, ROOT)
+    import bench
+    fl = bench.gemm_flops_per_forward(32)
+    # every launch at exactly 1000 TFLOP/s
+    kernels = {k: fl[k] / 1000e12 * 1e3 for k in fl}
+    r8 = bench.roofline_by_peak(kernels, 32, bench.CLIP_SAMPLES, "fp8")
+    assert r8["encoder_gemms"]["peak"] == 5000.0 and abs(r8["encoder_gemms"]["frac"] - 0.2) < 1e-3
+    assert r8["conv_stack_and_projection"]["peak"] == 2500.0 and abs(r8["conv_stack_and_projection"]["frac"] - 0.4) < 1e-3
+    r16 = bench.roofline_by_peak(kernels, 32, bench.CLIP_SAMPLES, "bf16")
+    assert r16["encoder_gemms"]["peak"] == 2500.0 and abs(r16["encoder_gemms"]["frac"] - 0.4) < 1e-3
+    rs = bench.roofline_by_peak(kernels, 32, bench.CLIP_SAMPLES, "split16")
+    assert abs(rs["encoder_gemms"]["issued_frac"] - 1.2) < 1e-3        # three MFMA passes per algorithmic contraction

@@ -100,15 +100,16 @@ def _worker(rank, world, port, q):
     except RuntimeError as e:
         raised = "max_segments=1" in str(e)
     ok &= raised if rank == 0 else True
-    # a consumer that stops early (every rank after the same step) still gets the overflow error, from close()
-    raised = False
+    # a consumer that stops early (every rank after the same step) is told too -- by a RuntimeWarning: close() must end with
+    # GeneratorExit, not with another exception (and one raised during garbage collection would only be printed)
+    import warnings
     g = S.run_stream(batches, lens, max_segments=1)
     next(g)
-    try:
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
         g.close()
-    except RuntimeError as e:
-        raised = "max_segments=1" in str(e)
-    ok &= raised if rank == 0 else True
+    warned = any("max_segments=1" in str(w.message) and issubclass(w.category, RuntimeWarning) for w in caught)
+    ok &= warned if rank == 0 else True
     dist.barrier()
     if rank == 0:
         for b, c in zip(streamed, streamed2):
@@ -165,3 +166,87 @@ def test_single_process_degenerate_path():
     for o, r in zip(out, ref):
         assert np.array_equal(o["segments"], r["segments"])
         assert np.abs(o["hidden_states"] - r["hidden_states"]).max() < 2e-5
+
+
+# ---- world size 4: odd ragged batches (a rank with an EMPTY real block, a padded tail), run_stream with two
+# engines, gather="none" (results stay sharded), an early close() on every rank, then the communicator is used again
+LENS4 = [[12000, 9000, 16000, 7000, 11000],          # 5 utterances over 4 ranks: Bper = 2, rank 2 holds one real row, rank 3 none
+         [8000, 15000, 6000],                        # 3 over 4 ranks: Bper = 1, rank 3 holds only padding
+         [10000, 10000, 9000, 12000, 7000, 14000, 9500]]
+
+
+def _worker4(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import warnings
+    from sylber_amd.dist import ShardedSegmenter
+    sd = synthetic_state_dict(0, num_layers=1)
+    S = ShardedSegmenter([OracleEngine(sd), OracleEngine(sd)], norm_threshold=2.6, merge_threshold=0.8)
+    for e in S.engines:                                  # (one encoder layer keeps the four single-thread ranks quick)
+        e.forward = (lambda eng: (lambda wav, lengths: hubert_ref.forward(eng.sd, wav, lengths, num_layers=1)["hidden"].contiguous()))(e)
+    batches = lens = [None] * len(LENS4)
+    if rank == 0:
+        lens = [list(ls) for ls in LENS4]
+        batches = []
+        for j, ls in enumerate(LENS4):
+            b = torch.zeros(len(ls), max(ls))
+            for i, n in enumerate(ls):
+                b[i, :n] = syllable_wave(n, 200 + 10 * j + i)[0]
+            batches.append(b)
+    with torch.no_grad():
+        rooted = list(S.run_stream(batches, lens, max_segments=64))
+        local = list(S.run_stream(batches, lens, max_segments=64, gather="none"))
+        # early close on every rank after the first batch, then the same communicator serves a synchronous step
+        g = S.run_stream(batches, lens, max_segments=64)
+        next(g)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                 # no overflow here: close() must be silent
+            g.close()
+        again = S.step(batches[1], lens[1])
+    # every rank ships its local rows to the parent, which stitches them and compares with root's gather
+    npy = lambda out: tuple(t.numpy().copy() for t in out)       # (numpy: a torch tensor in the queue is a file descriptor of a process that exits)
+    q.put((rank, [npy(out) for out in local], [npy(out) for out in rooted] if rank == 0 else None, npy(again) if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_sharding_ragged_odd_batches_and_local_results():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    W = 4
+    procs = [ctx.Process(target=_worker4, args=(r, W, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(W):
+        rank, mine, rooted, again = q.get(timeout=600)
+        got[rank] = (mine, rooted, again)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rooted, again = got[0][1], got[0][2]
+    sd = synthetic_state_dict(0, num_layers=1)
+    for j, ls in enumerate(LENS4):
+        btot = len(ls)
+        bper = (btot + W - 1) // W
+        # gather="none": rank r yields rows [r * bper, min((r + 1) * bper, btot)) -- possibly none at all
+        rows = [got[r][0][j] for r in range(W)]
+        for r in range(W):
+            assert rows[r][0].shape[0] == max(0, min(bper, btot - r * bper)), (j, r)
+        for part in range(4):
+            stitched = np.concatenate([rows[r][part] for r in range(W)], 0)
+            assert np.array_equal(stitched, rooted[j][part]), (j, part)
+        # and root's gather is the single-process result (same Lmax padding: sylber.py:93-97)
+        ref = SegmenterRef(sd, encoding_layer=1)([syllable_wave(n, 200 + 10 * j + i) for i, n in enumerate(ls)], in_second=False)
+        hid, seg, nseg, _ = rooted[j]
+        for i, r_ in enumerate(ref):
+            t = r_["hidden_states"].shape[0]
+            assert np.abs(hid[i, :t] - r_["hidden_states"]).max() < 2e-5
+            n = int(nseg[i])
+            assert n == len(r_["segments"]) and (n == 0 or np.array_equal(seg[i, :n], r_["segments"]))
+    assert np.array_equal(again[0], rooted[1][0]) and np.array_equal(again[2], rooted[1][2])

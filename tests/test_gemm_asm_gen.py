@@ -1,45 +1,50 @@
-"""The inline-asm K loops in sylber_amd/csrc/gemm_asm*.inc are GENERATED (tools/gen_gemm_asm.py): the committed files must be
-exactly what the committed generator writes, so that the schedule documented in the generator is the one that ships."""
-import filecmp
+"""The inline-asm K loops (gemm_asm*.inc) are GENERATED at build time by tools/gen_gemm_asm.py into sylber_amd/build/gen/ (round 5:
+the 33 k generated lines are no longer committed).  What IS committed is the generator and a hash per loop
+(tools/gemm_asm_hashes.json): a change of the generator that changes a shipped schedule has to update the list in the same commit,
+so the schedule documented in the generator stays the one that ships.  `python tools/gen_gemm_asm.py hashes` rewrites the list."""
+import hashlib
+import json
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "tools", "gen_gemm_asm.py")
 
 
-def test_generated_loops_are_current(tmp_path):
+def _generate(tmp_path, what):
     env = dict(os.environ, GEN_GEMM_ASM_OUT=str(tmp_path))
-    gen = os.path.join(ROOT, "tools", "gen_gemm_asm.py")
-    subprocess.run([sys.executable, gen, "product"], check=True, env=env, capture_output=True)
-    made = sorted(os.listdir(tmp_path))
+    subprocess.run([sys.executable, GEN, what], check=True, env=env, capture_output=True)
+    return sorted(os.listdir(tmp_path))
+
+
+def test_generated_loops_match_the_committed_hashes(tmp_path):
+    made = _generate(tmp_path, "product")
     assert len(made) >= 7 and "gemm_asm_x3_w8.inc" in made and "gemm_asm_k64.inc" in made and "gemm_asm_loop.inc" in made
-    csrc = os.path.join(ROOT, "sylber_amd", "csrc")
-    shipped = sorted(f for f in os.listdir(csrc) if f.startswith("gemm_asm") and f.endswith(".inc"))
-    assert shipped == made, (set(shipped) ^ set(made))
+    want = json.load(open(os.path.join(ROOT, "tools", "gemm_asm_hashes.json")))
+    assert sorted(want) == made, (set(want) ^ set(made))
     for f in made:
-        assert filecmp.cmp(os.path.join(tmp_path, f), os.path.join(csrc, f), shallow=False), f
+        got = hashlib.sha256(open(os.path.join(tmp_path, f), "rb").read()).hexdigest()
+        assert got == want[f], "%s: the generator's output changed; if intended, run `python tools/gen_gemm_asm.py hashes`" % f
+    # nothing generated is committed beside the sources any more
+    csrc = os.path.join(ROOT, "sylber_amd", "csrc")
+    assert not [f for f in os.listdir(csrc) if f.endswith(".inc")]
 
 
 def test_experiment_loops_are_generated_not_committed(tmp_path):
     """the knock-out / schedule variants (timing only, results wrong by construction) are generated into the build directory by a
     SYLBER_EXPERIMENTS=1 build; none of them lives in csrc/"""
-    env = dict(os.environ, GEN_GEMM_ASM_OUT=str(tmp_path))
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gemm_asm.py"), "experiments"], check=True, env=env, capture_output=True)
-    made = sorted(os.listdir(tmp_path))
+    made = _generate(tmp_path, "experiments")
     assert len(made) >= 21 and all("_v" in f for f in made), made
-    csrc = os.path.join(ROOT, "sylber_amd", "csrc")
-    assert not [f for f in os.listdir(csrc) if f.startswith("gemm_asm") and "_v" in f]
 
 
-def test_every_loop_keeps_its_hazard_rules():
+def test_every_loop_keeps_its_hazard_rules(tmp_path):
     """static checks of the generated text: an LDS-DMA never follows its M0 write without an instruction in between, every
     barrier is preceded by the waits that make it meaningful, and the X3 loops never use an instruction offset on a DMA"""
-    csrc = os.path.join(ROOT, "sylber_amd", "csrc")
-    for f in sorted(os.listdir(csrc)):
-        if not (f.startswith("gemm_asm") and f.endswith(".inc")):
+    for f in _generate(tmp_path, "product"):
+        if not f.startswith("gemm_asm"):
             continue
-        lines = [ln.strip() for ln in open(os.path.join(csrc, f)) if ln.strip().startswith(('"', "MF"))]
+        lines = [ln.strip() for ln in open(os.path.join(tmp_path, f)) if ln.strip().startswith(('"', "MF"))]
         ins = [ln for ln in lines if not ln.startswith('"; ')]
         for i, ln in enumerate(ins):
             if "buffer_load_dword" in ln and " lds" in ln:

@@ -305,3 +305,40 @@ def test_stream_of_batches_equals_calls(sd):
     assert list(Segmenter(model_ckpt=sd).stream([])) == []
     sec = list(Segmenter(model_ckpt=sd).stream(batches[:2], in_second=True))
     assert all(np.array_equal(a["segments"], b["segments"] / 50.0) for a, b in zip(sec[0], ref[0]))
+
+
+def test_stream_abandoned_early_then_reused(sd):
+    """a consumer that stops early (break / close() / an exception) leaves batches in flight whose leased page-locked
+    blocks the D2H stream is still writing; the generator's exit waits for those copies before the leases go back, the budget and
+    the pool are restored, and what the consumer kept plus every later call / stream on the same Segmenter are the right bits.
+    Also: the generator keeps computing on the stream it started on when the caller's current stream changes between resumptions."""
+    from sylber_amd import Segmenter
+    batches = [[syllable_wave(48000 + 1000 * j, 500 + 10 * j + i) for i in range(6)] for j in range(6)]
+    ref_seg = Segmenter(model_ckpt=sd)
+    ref = [ref_seg(wav=b, in_second=False) for b in batches]
+    S = Segmenter(model_ckpt=sd, max_pinned_batches=2)
+    budget = S.out_pool.max_leased
+    for rounds in range(3):
+        gen = S.stream(batches, in_second=False)
+        first = next(gen)
+        gen.close()                                                            # two more batches were in flight
+        assert S.out_pool.max_leased == budget and len(S.out_pool._free) + S.out_pool.leased <= budget
+        again = S(wav=batches[3], in_second=False)                             # leases a block at once
+        for g, e in zip(first, ref[0]):
+            assert np.array_equal(g["hidden_states"], e["hidden_states"]) and np.array_equal(g["segments"], e["segments"])
+        for g, e in zip(again, ref[3]):
+            assert np.array_equal(g["hidden_states"], e["hidden_states"]) and np.array_equal(g["segments"], e["segments"])
+            assert np.array_equal(g["segment_features"], e["segment_features"], equal_nan=True)
+        del first, again
+    other = torch.cuda.Stream()
+    got = []
+    gen = S.stream(batches, in_second=False)
+    for j in range(len(batches)):
+        if j % 2:
+            with torch.cuda.stream(other):                                     # the caller's current stream changes between resumptions
+                got.append(next(gen))
+        else:
+            got.append(next(gen))
+    for out, exp in zip(got, ref):
+        for g, e in zip(out, exp):
+            assert np.array_equal(g["hidden_states"], e["hidden_states"]) and np.array_equal(g["segments"], e["segments"])

@@ -168,10 +168,11 @@ def test_fp8_forward_vs_reference_goldens(golden_dir):
         assert rel(e8.forward(wav, lengths, stop_stage=3 + l).cpu().numpy(), g[key]) < FP8_STAGE_TOL[key], key
     h = e8.forward(wav, lengths).cpu().numpy()
     assert np.isfinite(h).all() and rel(h, g["layer8"]) < FP8_STAGE_TOL["layer8"]
-    # the golden batch is 2 x 30 frames = 64 rows: no whole 256-row GEMM tile, so the forward above ran the bf16 attention core.
-    # Four copies of it (utterances are independent) are exactly one tile: the q / k / v projection then quantises its outputs
-    # and the attention core runs on MXFP8 operands (SYLBER_OPT_FP8_ATTENTION default) -- same goldens, same tolerances
+    # the golden batch is 2 x 30 frames = 64 rows: the q / k / v launch pads it to one 256-row tile and the attention core runs on
+    # MXFP8 operands (SYLBER_OPT_FP8_ATTENTION default) whatever the batch shape.  Four copies of it (utterances are independent)
+    # are exactly one tile -- same goldens, same tolerances, and the same bits per utterance
     wav4, len4 = wav.repeat(4, 1), lengths * 4
+    assert np.array_equal(e8.forward(wav4, len4).cpu().numpy()[:2], h)
     for l, key in [(0, "layer0"), (4, "layer4"), (8, "layer8")]:
         got = e8.forward(wav4, len4, stop_stage=(3 + l) if l < 8 else 0).cpu().numpy()
         assert np.isfinite(got).all()
@@ -253,10 +254,65 @@ def test_fp8_attention_core_in_the_forward():
         e8.set_option(7, 0)
         assert torch.isfinite(on).all() and not torch.equal(on, off)
         assert rel(on, off) < 4e-2, rel(on, off)                                           # measured 2.2e-2
-    small = wav[:3].contiguous()                                                           # 480 rows: no whole tiles -> the bf16 core either way
+    small = wav[:3].contiguous()                                                           # 480 rows: not whole 256-row tiles
     a = e8.forward(small, None).clone()
     # (regression: a smaller batch on a handle that served a larger one found stale scale bytes behind the padded query rows of
     #  the fp8 context and returned NaN from the second layer on -- csrc/attention.hip attn_finalize now writes those rows)
     assert torch.isfinite(a).all()
+    # the core of the mode does not depend on the batch shape -- the q / k / v launch pads M up to whole tiles (rows
+    # beyond the batch computed, not stored), so a ragged batch runs the MXFP8 core too and an utterance's hidden states are the
+    # same bits alone, in a batch of 3 and in the batch of 8
     e8.set_option(7, -1)
-    assert torch.equal(a, e8.forward(small, None))
+    assert not torch.equal(a, e8.forward(small, None))
+    e8.set_option(7, 0)
+    full = e8.forward(wav, None).clone()
+    assert torch.equal(a, full[:3])
+    one = e8.forward(wav[5:6].contiguous(), None)
+    assert torch.equal(one[0], full[5])
+
+
+def test_fp8_same_clip_alone_and_in_a_batch():
+    """one utterance, one result: ragged lengths, batch sizes that are / are not whole 256-row tiles, a poisoned workspace in between
+    (the padded rows of the q / k / v launch read whatever follows the operand: their results must never be stored)"""
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.synth import syllable_wave
+    from sylber_amd.weights import synthetic_state_dict
+    sd = synthetic_state_dict(0)
+    e8 = HubertEncoderHIP(sd, precision="fp8")
+    wav = torch.cat([syllable_wave(40000, 300 + i) for i in range(5)], 0).cuda()           # 5 x 124 frames -> 5 x 128 rows = 2.5 tiles
+    lens = [40000, 23000, 40000, 8000, 31000]
+    full = e8.forward(wav, lens).clone()
+    assert torch.isfinite(full).all()
+    from sylber_amd import _lib
+    _lib.check(e8.lib.sylber_debug_poison_workspace(e8.handle, 0xFF), "poison")
+    torch.cuda.synchronize()
+    assert torch.equal(e8.forward(wav, lens), full)
+    for i in (0, 3):
+        # same Lmax (the batch is padded to its maximum: sylber.py:93-97), one row
+        alone = e8.forward(wav[i:i + 1].contiguous(), [lens[i]])
+        assert torch.equal(alone[0], full[i]), i
+    pair = e8.forward(wav[1:3].contiguous(), lens[1:3])
+    assert torch.equal(pair, full[1:3])
+
+
+def test_fp8_full_size_config_vs_oracle_sample():
+    """BASELINE configs[4] at the configs[1] batch (32 x 10 s): finite, reproducible, batch-independent rows, and two rows against the
+    oracle within the mode's stated output tolerance (the fp8 mode had no counterpart of the bf16 full-size test)"""
+    from oracle import hubert_ref
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.synth import noise_batch
+    from sylber_amd.weights import synthetic_state_dict
+    sd = synthetic_state_dict(0)
+    e8 = HubertEncoderHIP(sd, precision="fp8")
+    x = noise_batch(32, 160000, seed=0)
+    xd = x.cuda()
+    out = e8.forward(xd).cpu().numpy()
+    assert out.shape == (32, 499, 768) and np.isfinite(out).all()
+    for _ in range(2):
+        assert np.array_equal(e8.forward(xd).cpu().numpy(), out)
+    part = e8.forward(xd[8:12].contiguous()).cpu().numpy()
+    assert np.array_equal(part, out[8:12])
+    ref = hubert_ref.forward(sd, x[[0, 31]], None)["hidden"].numpy().astype(np.float64)
+    for row, r in ((0, ref[0]), (31, ref[1])):
+        a = out[row].astype(np.float64)
+        assert float(np.sqrt(((a - r) ** 2).mean() / (r ** 2).mean())) < FP8_STAGE_TOL["layer8"], row

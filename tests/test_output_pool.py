@@ -98,3 +98,34 @@ def test_release_from_a_finalizer_inside_lease_does_not_deadlock():
     t.join(20)
     assert not t.is_alive(), "deadlock: _release waited for the pool lock"
     assert done and done[0] is not None and pool.leased == 1
+
+
+def test_trim_after_a_temporarily_raised_budget():
+    """Segmenter.stream raises max_leased by its batches in flight and restores it: the extra free blocks must not stay hoarded"""
+    pool = _pool(2)
+    pool.max_leased = 5
+    leases = [pool.lease(1 << 20) for _ in range(5)]
+    assert all(l is not None for l in leases) and pool.allocations == 5
+    del leases
+    gc.collect()
+    assert pool.leased == 0 and len(pool._free) == 5
+    pool.max_leased = 2
+    pool.trim()
+    assert len(pool._free) == 2
+    a = pool.lease(1 << 20); b = pool.lease(1 << 20)
+    assert a is not None and b is not None and pool.lease(1 << 20) is None and pool.allocations == 5
+
+
+def test_segment_slot_sizing_decays_with_the_recent_batches():
+    """Segmenter._note_segments: the block size follows the recent per-batch maximum (`_kcap_seen` only grew)"""
+    import collections
+    from sylber_amd.segmenter import Segmenter
+    s = Segmenter.__new__(Segmenter)
+    s._kcap_seen, s._kcap_recent = 128, collections.deque(maxlen=16)
+    s._note_segments(40)
+    assert s._kcap_seen == 128                     # floor
+    s._note_segments(700)                          # one long-clip batch
+    assert s._kcap_seen == 704
+    for _ in range(16):
+        s._note_segments(45)
+    assert s._kcap_seen == 128                     # ... forgotten 16 batches later

@@ -19,7 +19,7 @@ Slot (s+3)&3 = (s-1)&3 was last read during step s-2 and those reads were waited
 """
 import os
 
-OUTDIR = os.environ.get("GEN_GEMM_ASM_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sylber_amd", "csrc")
+OUTDIR = os.environ.get("GEN_GEMM_ASM_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sylber_amd", "build", "gen")
 
 FM = FN = 4
 SLOT = 32768
@@ -791,11 +791,22 @@ if __name__ == "__main__":
     import sys
     what = sys.argv[1] if len(sys.argv) > 1 else "product"
     if what == "product":
+        os.makedirs(OUTDIR, exist_ok=True)
         emit_product()
     elif what == "experiments":
         if not os.environ.get("GEN_GEMM_ASM_OUT"):
             OUTDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sylber_amd", "build", "gen")
         os.makedirs(OUTDIR, exist_ok=True)
         emit_experiments()
+    elif what == "hashes":
+        # rewrite tools/gemm_asm_hashes.json from the generator as it stands (tests/test_gemm_asm_gen.py checks against it)
+        import hashlib, json, tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            OUTDIR = tmp
+            emit_product()
+            h = {f: hashlib.sha256(open(os.path.join(tmp, f), "rb").read()).hexdigest() for f in sorted(os.listdir(tmp))}
+        dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_asm_hashes.json")
+        json.dump(h, open(dst, "w"), indent=1, sort_keys=True)
+        print("wrote", dst, len(h), "entries")
     else:
-        raise SystemExit("usage: gen_gemm_asm.py [product|experiments]   (GEN_GEMM_ASM_OUT overrides the directory)")
+        raise SystemExit("usage: gen_gemm_asm.py [product|experiments|hashes]   (GEN_GEMM_ASM_OUT overrides the directory)")
