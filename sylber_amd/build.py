@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 EXPERIMENTS = bool(os.environ.get("SYLBER_EXPERIMENTS"))
 LIB = os.path.join(HERE, "libsylber_hip_exp.so" if EXPERIMENTS else "libsylber_hip.so")
 GEN_DIR = os.path.join(HERE, "build", "gen")           # generated inline-asm loops (never committed: tools/gen_gemm_asm.py writes them here)
-GENERATORS = [os.path.join(os.path.dirname(HERE), "tools", g) for g in ("gen_gemm_asm.py",)]
+GENERATORS = [os.path.join(os.path.dirname(HERE), "tools", g) for g in ("gen_gemm_asm.py", "gen_attn_asm.py")]
 SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip", "gemm_rowln.hip", "gemm_asm.hip", "gemm_asm_f8.hip"]
 EXTRA = {"segment.hip": ["-ffp-contract=off"]}
 # -fno-slp-vectorize: NO packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the library.  Measured on

@@ -1084,7 +1084,9 @@ extern "C" int sylber_debug_attention_bench(int32_t B, int32_t T, int32_t precis
         if (qb.alloc(n * 2) || kb.alloc(n * 2 + 64 * 64 * 2) || vb.alloc((size_t)B * 768 * Tpv * 2) || cb.alloc(n * 2)) { syl_set_error("sylber_debug_attention_bench", "alloc"); return 1; }
         HIP_TRY(hipMemset(qb.p, 0, n * 2)); HIP_TRY(hipMemset(kb.p, 0, n * 2 + 64 * 64 * 2)); HIP_TRY(hipMemset(vb.p, 0, (size_t)B * 768 * Tpv * 2));
         hipLaunchKernelGGL(pack_qkv_kernel, dim3(T, B), dim3(256), 0, 0, q, k, v, (bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, T, Tp, Tpv);
-        auto run = [&]() { return launch_attention((bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, nullptr, (bf16_t*)cb.p, B, T, Tp, Tpv, 0, 0); };
+        // precision SYLBER_BF16: the default kernel (hand-scheduled key loop); 132 / 164: the compiler-scheduled kernels, 32 / 64 queries per wave
+        const int qw = precision == 132 ? 1 : (precision == 164 ? 2 : 0);
+        auto run = [&]() { return launch_attention((bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, nullptr, (bf16_t*)cb.p, B, T, Tp, Tpv, qw, 0); };
         for (int i = 0; i < 3 && !rc; ++i) rc = run();
         hipEventRecord(e0, 0);
         for (int i = 0; i < iters && !rc; ++i) rc = run();

@@ -506,6 +506,95 @@ __global__ __launch_bounds__(256, 4) void attention_f8_kernel(const uint8_t* __r
     attn_finalize<F8OUT, FMT_BF16>(oacc, l_run, ctx, ctx_scale, scale_rows, b, head, q0, ql, h, T, Tp);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same attention with a HAND-SCHEDULED key loop (round 5; tools/gen_attn_asm.py -> attn_asm_{bf16,f16}.inc): one inline-asm
+// statement per wave, software-pipelined over 32-key half-tiles -- S^T of half-tile i + 1 and O^T += V^T P^T of half-tile i - 1 alternate
+// on the matrix pipe while the softmax of half-tile i fills the gaps between them; fragments four MFMAs ahead through a register ring,
+// K / V^T tiles through a three-slot LDS ring (one barrier per 64-key tile), lazy maximum without a cross-lane exchange on the fast
+// path.  Geometry, operand layout and finalisation are attention_bf16_kernel<1>'s (32 queries per wave, "query = lane"), which stays
+// as the compiler-scheduled reference (SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 32 / 64).  156 fixed registers: three waves per SIMD.
+// The schedule is executed on the CPU by tools/attn_asm_emu.py (tests/test_attn_asm_gen.py) and checked for the issue hazards the
+// compiler cannot see inside an asm statement.
+typedef int i32x4a_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4a_t rsrc_words_a(const void* base) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4a_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xffffu));
+    r.z = (int)0xffffffffu;
+    r.w = 0x00020000;
+    return r;
+}
+
+#define ATA_SLOT 16384
+template <bool F8, int FMT>
+__global__ __launch_bounds__(256, 3) void attention_asm_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                               const bf16_t* __restrict__ Vt, const int* __restrict__ valid,
+                                                               bf16_t* __restrict__ ctx, int T, int Tp, int Tpv,
+                                                               uint8_t* __restrict__ ctx_scale, long scale_rows) {
+    static_assert(FMT == FMT_BF16 || FMT == FMT_F16, "16-bit single-plane formats");
+    __shared__ __attribute__((aligned(1024))) char smem[3 * ATA_SLOT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nqb = (T + 127) / 128;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vid / (nqb * SYL_HEADS);
+    const int head = (vid / nqb) % SYL_HEADS;
+    const int q0 = (vid % nqb) * 128 + wave * 32;
+    const int ql = lane & 31, h = lane >> 5;
+    int nvalid = valid ? valid[b] : T;
+    nvalid = nvalid < T ? nvalid : T;
+    nvalid = __builtin_amdgcn_readfirstlane(nvalid);
+    const size_t bh = (size_t)b * SYL_HEADS + head;
+    const bf16_t* Qb = Q + bh * Tp * 64;
+    const bf16_t* Kb = K + bh * Tp * 64;
+    const bf16_t* Vb = Vt + bh * 64 * Tpv;
+    f32x16_t oacc[2];
+    float lsum = 0.f;
+    const int nt = __builtin_amdgcn_readfirstlane((nvalid + 63) / 64);
+    if (nt > 0) {
+        bf16x8_t qf[4];
+        int qr = q0 + ql; qr = qr < Tp ? qr : Tp - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(Qb + (size_t)qr * 64 + ks * 16 + h * 8);
+        const int lds0 = (int)(unsigned)(unsigned long long)(lds_vptr)smem;
+        const int swz = (lane >> 1) & 7;
+        int off[4], kvoff[2], vvoff[2];
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) off[kx] = lds0 + ql * 128 + (((2 * kx + h) ^ swz) << 4);
+        const int srow = lane >> 3, spos = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wave * 16 + i * 8 + srow;
+            const int c = spos ^ ((r >> 1) & 7);
+            kvoff[i] = (r * 64 + c * 8) * 2;
+            vvoff[i] = (r * Tpv + c * 8) * 2;
+        }
+        const i32x4a_t rsk = rsrc_words_a(Kb), rsv = rsrc_words_a(Vb);
+        const int ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);
+        const int limbase = nvalid - 4 * h;
+        const int kvl0 = __builtin_amdgcn_readfirstlane(64 * (nt - 1)), kvl1 = __builtin_amdgcn_readfirstlane(64 * (nt - 1) + 32);
+        f32x16_t o0, o1;
+        int koff, voff, resc, snext, dslot, tdma, tleft;
+        if constexpr (FMT == FMT_F16) {
+#define MF "v_mfma_f32_32x32x16_f16"
+#include "attn_asm_f16.inc"
+#undef MF
+        } else {
+#define MF "v_mfma_f32_32x32x16_bf16"
+#include "attn_asm_bf16.inc"
+#undef MF
+        }
+        (void)koff; (void)voff; (void)resc; (void)snext; (void)dslot; (void)tdma; (void)tleft;
+        oacc[0] = o0; oacc[1] = o1;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    }
+    attn_finalize<F8, FMT>(oacc, lsum, ctx, ctx_scale, scale_rows, b, head, q0, ql, h, T, Tp);
+}
+
 int launch_attention_f8(const uint8_t* q8, const uint8_t* qs, const uint8_t* k8, const uint8_t* ks, const uint8_t* v8, const uint8_t* vs,
                         const int* valid, void* ctx, uint8_t* ctx_scale, long scale_rows, int B, int T, int Tp, int Tpv, hipStream_t s) {
     if (Tpv % 64 != 0 || Tpv < T || Tp % 32 != 0) { syl_set_error("launch_attention_f8", "Tp % 32 == 0, Tpv % 64 == 0, Tpv >= T"); return 1; }
@@ -526,6 +615,16 @@ static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* 
     int qw = 1;
     if (force_qw == 1 || force_qw == 2) qw = force_qw;
     if (fmt == FMT_SPLIT) qw = 1;
+    if (force_qw == 0 && fmt != FMT_SPLIT) {
+        // default since round 5: the hand-scheduled key loop (attention_asm_kernel); 32 / 64 queries per wave select the
+        // compiler-scheduled kernels, kept as its reference
+        const dim3 grid_a(((T + 127) / 128) * SYL_HEADS * B);
+        if (ctx_scale) hipLaunchKernelGGL((attention_asm_kernel<true, FMT_BF16>), grid_a, dim3(256), 0, s, q, k, vt, valid, c, T, Tp, Tpv, ctx_scale, scale_rows);
+        else if (fmt == FMT_F16) hipLaunchKernelGGL((attention_asm_kernel<false, FMT_F16>), grid_a, dim3(256), 0, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
+        else hipLaunchKernelGGL((attention_asm_kernel<false, FMT_BF16>), grid_a, dim3(256), 0, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((qw == 2 ? (T + 255) / 256 : (T + 127) / 128) * SYL_HEADS * B);
     if (fmt == FMT_SPLIT) {
         static PerDeviceOnce attr_once;

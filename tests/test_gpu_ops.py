@@ -58,9 +58,9 @@ def test_layernorm(lib, D):
     assert (y.cpu() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("qw", [1, 2])
+@pytest.mark.parametrize("qw", [0, 1, 2])       # 0: the default (hand-scheduled key loop), 1 / 2: the compiler-scheduled kernels (32 / 64 queries per wave)
 @pytest.mark.parametrize("B,T,valid", [(2, 64, None), (3, 143, [143, 100, 1]), (2, 499, [499, 300]), (1, 700, None),
-                                       (6, 499, None)])
+                                       (6, 499, None), (2, 1, None), (2, 33, [33, 32]), (3, 130, [130, 65, 64]), (1, 2999, None)])
 def test_attention(lib, B, T, valid, qw):
     from sylber_amd import _lib
     g = torch.Generator().manual_seed(B * 1000 + T)
@@ -68,7 +68,7 @@ def test_attention(lib, B, T, valid, qw):
     k = torch.randn(B, T, 768, generator=g)
     v = torch.randn(B, T, 768, generator=g)
     # a query/key spike so that the running max really jumps between tiles (online-softmax rescale path)
-    k[0, T // 2, :64] = 4.0 * q[0, 3, :64] / 8
+    k[0, T // 2, :64] = 4.0 * q[0, 3 % T, :64] / 8
     vd = torch.tensor(valid, dtype=torch.int32).cuda() if valid else None
     o = torch.full((B, T, 768), float("nan"), device="cuda")
     qd, kd, vdev = q.cuda(), k.cuda(), v.cuda()
@@ -152,7 +152,7 @@ def test_attention_full_batch_no_race(lib):
     kh = _bf(k).view(B, T, 12, 64).transpose(1, 2)
     vh = _bf(v).view(B, T, 12, 64).transpose(1, 2)
     ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).transpose(1, 2).reshape(B, T, 768)
-    for qw in (1, 2):
+    for qw in (0, 1, 2):
         outs = []
         for _ in range(3):
             o = torch.full((B, T, 768), float("nan"), device="cuda")

@@ -50,9 +50,9 @@ R = {
     "F": 120,                           # fragment ring: 4 x 4 registers
     "rk": 136, "rv": 140,               # LDS read addresses (4 each): slot of the K tile being read / of the V^T tile being read
     "m": 144, "nmb": 145, "thr": 146, "l": 147, "mx": 148, "ps": 149,   # ps: 149..152
-    "alpha": 153, "ta": 154, "tb": 155,
+    "alpha": 153, "ta": 154, "tb": 155, "ninf": 156,
 }
-FIXED_LO, FIXED_HI = 40, 155
+FIXED_LO, FIXED_HI = 40, 156
 
 LOG2E = 1.44269504088896341
 def f32bits(x):
@@ -151,7 +151,8 @@ class Gen:
         self.p = Prog()
         self.fmt = fmt
         self.cvt = "v_cvt_pk_bf16_f32" if fmt == "bf16" else "v_cvt_pk_f16_f32"
-        self.lds_order = []          # frag-ring entries in LDS issue order since the last lgkmcnt(0): for exact lgkmcnt values
+        self.lds_order = []          # frag-ring slots with a read in flight, in LDS issue order: for exact lgkmcnt values
+        self.landed = set()          # ring slots whose fragment has landed and not been consumed yet
         self.uid = 0
 
     def new_label(self, stem):
@@ -163,17 +164,28 @@ class Gen:
         return vr(R["F"] + 4 * slot, 4)
 
     def read(self, slot, addr_reg, off):
-        assert slot not in self.lds_order, ("ring slot %d still holds an unconsumed fragment" % slot)
+        assert slot not in self.lds_order and slot not in self.landed, ("ring slot %d still holds an unconsumed fragment" % slot)
         self.p.ds_read(self.F(slot), v(addr_reg), off)
         self.lds_order.append(slot)
 
     def wait_frag(self, slot):
-        """wait until the OLDEST outstanding read into ring slot `slot` has landed (LDS operations return in order)"""
+        """wait until the outstanding read into ring slot `slot` has landed (LDS operations return in order)"""
+        if slot in self.landed:                                  # drained by an earlier, wider wait
+            self.landed.discard(slot)
+            return
         assert slot in self.lds_order, ("fragment never requested", slot)
         k = self.lds_order.index(slot)
         younger = len(self.lds_order) - 1 - k
         self.p.waitcnt(lgkm=younger)
+        self.landed |= set(self.lds_order[:k])
         self.lds_order = self.lds_order[k + 1:]
+
+    def drain(self):
+        self.landed |= set(self.lds_order)
+        self.lds_order = []
+
+    def frag_state(self):
+        return (tuple(self.lds_order), tuple(sorted(self.landed)))
 
     # ---- softmax of one half-tile as a list of closures (each emits ONE instruction) -------------------------------------------------
     def softmax_ops(self, S, P, masked, init, kv_half, resume_label, slow_label):
@@ -189,7 +201,7 @@ class Gen:
             for r in range(16):
                 c = (r & 3) + 8 * (r >> 2)
                 E(lambda c=c: p.vcmp("v_cmp_lt_i32", imm(c), ta))                        # c < lim: the key is valid
-                E(lambda r=r: p.valu("v_cndmask_b32", s[r], lit(LIT_NINF), s[r]))          # vcc ? s : -inf
+                E(lambda r=r: p.valu("v_cndmask_b32", s[r], v(R["ninf"]), s[r]))           # vcc ? s : -inf (a literal AND vcc: two constant-bus reads)
         # row maximum of the lane's 16 scores: a tree of v_max3 (the tree keeps the dependent chains short)
         E(lambda: p.valu("v_max3_f32", ps[0], s[0], s[1], s[2]))
         E(lambda: p.valu("v_max3_f32", ps[1], s[3], s[4], s[5]))
@@ -308,7 +320,7 @@ class Gen:
         if barrier_dma:
             # the K fragments of MFMA 0 and 2 could not be requested before the barrier (they are read from tile t+1)
             p.waitcnt(vm=0, lgkm=0)
-            self.lds_order = []
+            self.drain()
             p.barrier()
             self.dma_block()
             self.read(0, R["rk"] + 0, s_half * 4096)
@@ -415,6 +427,7 @@ class Gen:
         p.salu("s_mov_b32", op("resc"), imm(0))
         p.salu("s_add_u32", "m0", op("ldsw"), imm(0))
         p.valu("v_mov_b32", v(R["l"]), imm(0))
+        p.valu("v_mov_b32", v(R["ninf"]), lit(LIT_NINF))
         p.dma(op("kvoff0"), opr("rsk", 4), op("koff"))
         p.salu("s_add_u32", "m0", "m0", imm(1024))
         for k in range(4):
@@ -454,18 +467,18 @@ class Gen:
         p.branch("s_cbranch_scc1", L_single)
 
         # ---------------- first tile (of several): no P.V in its even iteration, unmasked
-        lo0 = list(self.lds_order)
+        lo0 = self.frag_state()
         self.iteration("tile 0, even: S(1), softmax(0) [init]", 0, 1, None, init=True, nxt=(0, 0, True), addr_update="full")
         self.iteration("tile 0, odd: S(2) from tile 1, P.V(0), softmax(1)", 1, 0, 0, pv_first=True, nxt=(1, 1, False), barrier_dma=True)
         p.salu("s_sub_u32", op("tleft"), op("tleft"), imm(1))
         p.scmp("s_cmp_eq_u32", op("tleft"), imm(0))
         p.branch("s_cbranch_scc1", L_last)
         # ---------------- steady state: one trip = one 64-key tile that has a successor
-        lo_loop = list(self.lds_order)
+        lo_loop = self.frag_state()
         p.label(L_loop)
         self.iteration("tile t, even: S(2t+1), P.V(2t-1), softmax(2t)", 0, 1, 1, nxt=(0, 0, True), addr_update="full")
         self.iteration("tile t, odd: S(2t+2) from tile t+1, P.V(2t), softmax(2t+1)", 1, 0, 0, nxt=(1, 1, False), barrier_dma=True)
-        assert self.lds_order == lo_loop, (self.lds_order, lo_loop)
+        assert self.frag_state() == lo_loop, (self.frag_state(), lo_loop)
         p.salu("s_sub_u32", op("tleft"), op("tleft"), imm(1))
         p.scmp("s_cmp_lg_u32", op("tleft"), imm(0))
         p.branch("s_cbranch_scc1", L_loop)
@@ -478,7 +491,7 @@ class Gen:
         p.branch("s_branch", L_end)
         # ---------------- the only tile
         p.label(L_single)
-        self.lds_order = lo0
+        self.lds_order, self.landed = list(lo0[0]), set(lo0[1])
         self.iteration("only tile, even: S(1), softmax(0) [init, masked]", 0, 1, None, masked=True, init=True, kv_half="kvl0", nxt=(None, 0, False),
                        addr_update="rv")
         self.iteration("only tile, odd: P.V(0), softmax(1) [masked]", 1, None, 0, masked=True, pv_first=True, kv_half="kvl1", nxt=(None, 1, False))
@@ -505,7 +518,7 @@ class Gen:
         p.mfma(vr(R["O0"], 16), self.F(1), vr(Prd + 4, 4), vr(R["O0"], 16))
         self.wait_frag(3)
         p.mfma(vr(R["O1"], 16), self.F(3), vr(Prd + 4, 4), vr(R["O1"], 16))
-        assert not self.lds_order
+        assert not self.lds_order and not self.landed
 
 
 # ====================================================================================================================================
@@ -600,36 +613,52 @@ def check_hazards(ins):
             return regs_of(d["addr"]), regs_of(d["dst"])
         return set(), set()
 
+    labels = {d["name"]: j for j, d in enumerate(real) if d["kind"] == "label"}
+
+    def follow(j, ws, limit, visit, seen=None):
+        """every instruction reachable from position j within `limit` wait states, along BOTH arms of conditional branches"""
+        seen = set() if seen is None else seen
+        while j < n and ws < limit:
+            if (j, ws) in seen:
+                return
+            seen.add((j, ws))
+            e = real[j]
+            visit(e, ws)
+            if e["kind"] == "branch":
+                tgt = labels[e["target"]]
+                if e["op"] == "s_branch":
+                    j, ws = tgt, ws + 1
+                    continue
+                follow(tgt, ws + 1, limit, visit, seen)
+            ws += states(e)
+            j += 1
+
     for i, d in enumerate(real):
         if d["kind"] == "mfma":
             dst = regs_of(d["dst"])
-            # (a) MFMA result -> VALU / LDS read or write of it: 12 wait states (gfx950, 8-pass XDL).  Linear scan: the only branches
-            # that can follow inside the window are checked conservatively by following the fall-through path
-            ws, j = 0, i + 1
-            while j < n and ws < 12:
-                e = real[j]
+            # (a) MFMA result -> VALU / LDS read or write of it: 12 wait states (gfx950, 8-pass XDL)
+
+            def chk_a(e, ws, d=d, dst=dst):
                 if e["kind"] in ("valu", "vcmp", "ds_read"):
                     rd, wr = reads_writes(e)
                     assert not ((rd | wr) & dst), ("MFMA result touched after %d wait states" % ws, d, e)
-                ws += states(e)
-                j += 1
+            follow(i + 1, 0, 12, chk_a)
         if d["kind"] == "valu":
             rd, wr = reads_writes(d)
             # (b) VALU write -> MFMA reads it as A / B / C: 2 wait states
-            ws, j = 0, i + 1
-            while j < n and ws < 2:
-                e = real[j]
+
+            def chk_b(e, ws, d=d, wr=wr):
                 if e["kind"] == "mfma":
                     used = regs_of(e["a"]) | regs_of(e["b"]) | regs_of(e["c"]) | regs_of(e["dst"])
                     assert not (used & wr), ("VALU result read by an MFMA too early", d, e)
-                ws += states(e)
-                j += 1
+            follow(i + 1, 0, 2, chk_b)
             # (c) transcendental result -> the next VALU must not read it
-            if d.get("trans") and i + 1 < n:
-                e = real[i + 1]
-                if e["kind"] in ("valu", "vcmp"):
-                    rd2, _ = reads_writes(e)
-                    assert not (rd2 & wr) or e.get("trans"), ("trans result read by the next VALU", d, e)
+            if d.get("trans"):
+                def chk_c(e, ws, d=d, wr=wr):
+                    if e["kind"] in ("valu", "vcmp") and not e.get("trans"):
+                        rd2, _ = reads_writes(e)
+                        assert not (rd2 & wr), ("trans result read by the next VALU", d, e)
+                follow(i + 1, 0, 1, chk_c)
         if d["kind"] == "salu" and d["dst"] == "m0" and i + 1 < n:
             assert real[i + 1]["kind"] != "dma", ("LDS-DMA right behind its M0 write", d)
         if d["kind"] == "barrier":
@@ -677,10 +706,18 @@ def emit_product():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "product"
-    if what in ("product", "hashes"):
-        if what == "product":
-            emit_product()
+    if what == "product":
+        emit_product()
     elif what == "experiments":
-        pass
+        pass                                                     # (no timing-only variants of this loop are kept)
+    elif what == "hashes":
+        import hashlib, json, tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            OUTDIR = tmp
+            emit_product()
+            h = {f: hashlib.sha256(open(os.path.join(tmp, f), "rb").read()).hexdigest() for f in sorted(os.listdir(tmp))}
+        dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "attn_asm_hashes.json")
+        json.dump(h, open(dst, "w"), indent=1, sort_keys=True)
+        print("wrote", dst, len(h), "entries")
     else:
-        raise SystemExit("usage: gen_attn_asm.py [product]   (GEN_GEMM_ASM_OUT overrides the directory)")
+        raise SystemExit("usage: gen_attn_asm.py [product|hashes]   (GEN_GEMM_ASM_OUT overrides the directory)")
