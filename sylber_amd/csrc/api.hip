@@ -923,7 +923,7 @@ extern "C" int sylber_op_layernorm(const float* x_dev, const float* res_dev, con
     return launch_layernorm(a, (hipStream_t)stream);
 }
 
-// q,k,v [B,T,768] f32 -> bf16 head-major q (x0.125), k and key-permuted V^T
+// q,k,v [B,T,768] f32 -> bf16 head-major q (x SYL_Q_SCALE = log2(e) / 8), k and key-permuted V^T
 __global__ void pack_qkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                 bf16_t* __restrict__ qo, bf16_t* __restrict__ ko, bf16_t* __restrict__ vto, int T, int Tp, int Tpv) {
     const int b = blockIdx.y, t = blockIdx.x;
@@ -931,7 +931,7 @@ __global__ void pack_qkv_kernel(const float* __restrict__ q, const float* __rest
         const int head = c >> 6, d = c & 63;
         const size_t src = ((size_t)b * T + t) * 768 + c;
         const size_t hm = (((size_t)b * 12 + head) * Tp + t) * 64 + d;
-        qo[hm] = f2bf(q[src] * 0.125f);
+        qo[hm] = f2bf(q[src] * SYL_Q_SCALE);
         ko[hm] = f2bf(k[src]);
         const int pos = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
         vto[(((size_t)b * 12 + head) * 64 + d) * Tpv + pos] = f2bf(v[src]);
@@ -1057,6 +1057,9 @@ extern "C" int sylber_debug_attention_bench(int32_t B, int32_t T, int32_t precis
     TmpBuf qin;
     if (qin.alloc((size_t)B * T * 768 * 4 * 3)) { syl_set_error("sylber_debug_attention_bench", "alloc"); return 1; }
     float* q = (float*)qin.p; float* k = q + (size_t)B * T * 768; float* v = k + (size_t)B * T * 768;
+    const bool zero_data = iters < 0;         // iters < 0: all-zero operands (DVFS probe: the same instruction stream at lower switching power)
+    if (zero_data) { iters = -iters; HIP_TRY(hipMemset(qin.p, 0, (size_t)B * T * 768 * 4 * 3)); }
+    else
     {   // pseudo-random fp32 q, k, v in [-1, 1) via the bf16 filler (values irrelevant for timing beyond being finite)
         TmpBuf tmp;
         if (tmp.alloc((size_t)B * T * 768 * 3 * 2)) { syl_set_error("sylber_debug_attention_bench", "alloc"); return 1; }
@@ -1085,7 +1088,7 @@ extern "C" int sylber_debug_attention_bench(int32_t B, int32_t T, int32_t precis
         HIP_TRY(hipMemset(qb.p, 0, n * 2)); HIP_TRY(hipMemset(kb.p, 0, n * 2 + 64 * 64 * 2)); HIP_TRY(hipMemset(vb.p, 0, (size_t)B * 768 * Tpv * 2));
         hipLaunchKernelGGL(pack_qkv_kernel, dim3(T, B), dim3(256), 0, 0, q, k, v, (bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, T, Tp, Tpv);
         // precision SYLBER_BF16: the default kernel (hand-scheduled key loop); 132 / 164: the compiler-scheduled kernels, 32 / 64 queries per wave
-        const int qw = precision == 132 ? 1 : (precision == 164 ? 2 : 0);
+        const int qw = precision == 132 ? 1 : (precision == 164 ? 2 : (precision > 200 && precision < 220 ? precision - 100 : 0));   // 201..209: knock-out variants (experiments build)
         auto run = [&]() { return launch_attention((bf16_t*)qb.p, (bf16_t*)kb.p, (bf16_t*)vb.p, nullptr, (bf16_t*)cb.p, B, T, Tp, Tpv, qw, 0); };
         for (int i = 0; i < 3 && !rc; ++i) rc = run();
         hipEventRecord(e0, 0);

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, FMT == FMT_SPLIT ? 2 : (QW == 2 ? 3 : 4)) void
     float m_run[QW], l_run[QW];
 #pragma unroll
     for (int qs = 0; qs < QW; ++qs) { m_run[qs] = -INFINITY; l_run[qs] = 0.f; }
-    const float LOG2E = 1.44269504088896341f;
+    // (q arrives pre-scaled by log2(e) / 8: the scores are in log2 units)
 
     const int nt = (nvalid + AT_KV - 1) / AT_KV;
     {
@@ -249,10 +249,10 @@ __global__ __launch_bounds__(256, FMT == FMT_SPLIT ? 2 : (QW == 2 ? 3 : 4)) void
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 // first half-tile: m_run = -inf, mx finite (key 0 is always valid) -> need; a fully masked half has
                 // mx = -inf -> no need, p = exp2(-inf) = 0
-                const bool need = (mx - m_run[qs]) * LOG2E > 8.0f;
+                const bool need = (mx - m_run[qs]) > 8.0f;
                 if (__builtin_amdgcn_ballot_w64(need)) {
                     const float m_new = need ? mx : m_run[qs];
-                    const float alpha = need ? __builtin_amdgcn_exp2f((m_run[qs] - m_new) * LOG2E) : 1.0f;
+                    const float alpha = need ? __builtin_amdgcn_exp2f(m_run[qs] - m_new) : 1.0f;
                     m_run[qs] = m_new;
                     l_run[qs] *= alpha;
 #pragma unroll
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, FMT == FMT_SPLIT ? 2 : (QW == 2 ? 3 : 4)) void
 #pragma unroll
                         for (int r = 0; r < 16; ++r) oacc[qs][i][r] *= alpha;
                 }
-                const float mb = m_run[qs] * LOG2E;
+                const float mb = m_run[qs];
                 float psum = 0.f;
                 // P is converted in PAIRS (one v_cvt_pk per two scores) and, in the fp16 format, without the saturating
                 // clamp every other conversion carries: 0 <= p <= 2^8 by construction of the lazy maximum
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256, FMT == FMT_SPLIT ? 2 : (QW == 2 ? 3 : 4)) void
                     uint32_t pw[4], pwl[4];
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
-                        const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[qs][8 * j + e], LOG2E, -mb));
-                        const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[qs][8 * j + e + 1], LOG2E, -mb));
+                        const float p0 = __builtin_amdgcn_exp2f(sacc[qs][8 * j + e] - mb);
+                        const float p1 = __builtin_amdgcn_exp2f(sacc[qs][8 * j + e + 1] - mb);
                         psum += p0;
                         psum += p1;
                         pw[e >> 1] = H16<FMT>::pack2_bounded(p0, p1);
@@ -527,7 +527,7 @@ __device__ __forceinline__ i32x4a_t rsrc_words_a(const void* base) {
 }
 
 #define ATA_SLOT 16384
-template <bool F8, int FMT>
+template <bool F8, int FMT, int VAR = 0>
 __global__ __launch_bounds__(256, 3) void attention_asm_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                const bf16_t* __restrict__ Vt, const int* __restrict__ valid,
                                                                bf16_t* __restrict__ ctx, int T, int Tp, int Tpv,
@@ -572,6 +572,7 @@ __global__ __launch_bounds__(256, 3) void attention_asm_kernel(const bf16_t* __r
         const i32x4a_t rsk = rsrc_words_a(Kb), rsv = rsrc_words_a(Vb);
         const int ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);
         const int limbase = nvalid - 4 * h;
+        const int hmask = h ? 0 : -1;
         const int kvl0 = __builtin_amdgcn_readfirstlane(64 * (nt - 1)), kvl1 = __builtin_amdgcn_readfirstlane(64 * (nt - 1) + 32);
         f32x16_t o0, o1;
         int koff, voff, resc, snext, dslot, tdma, tleft;
@@ -581,7 +582,36 @@ __global__ __launch_bounds__(256, 3) void attention_asm_kernel(const bf16_t* __r
 #undef MF
         } else {
 #define MF "v_mfma_f32_32x32x16_bf16"
+#ifdef SYLBER_GEMM_ASM_EXPERIMENTS
+            if constexpr (VAR == 1) {
+#include "attn_asm_bf16_v1.inc"
+            } else if constexpr (VAR == 2) {
+#include "attn_asm_bf16_v2.inc"
+            } else if constexpr (VAR == 3) {
+#include "attn_asm_bf16_v3.inc"
+            } else if constexpr (VAR == 4) {
+#include "attn_asm_bf16_v4.inc"
+            } else if constexpr (VAR == 5) {
+#include "attn_asm_bf16_v5.inc"
+            } else if constexpr (VAR == 6) {
+#include "attn_asm_bf16_v6.inc"
+            } else if constexpr (VAR == 7) {
+#include "attn_asm_bf16_v7.inc"
+            } else if constexpr (VAR == 8) {
+#include "attn_asm_bf16_v8.inc"
+            } else if constexpr (VAR == 9) {
+#include "attn_asm_bf16_v9.inc"
+            } else if constexpr (VAR == 10) {
+#include "attn_asm_bf16_v10.inc"
+            } else if constexpr (VAR == 11) {
+#include "attn_asm_bf16_v11.inc"
+            } else if constexpr (VAR == 12) {
+#include "attn_asm_bf16_v12.inc"
+            } else
+#endif
+            {
 #include "attn_asm_bf16.inc"
+            }
 #undef MF
         }
         (void)koff; (void)voff; (void)resc; (void)snext; (void)dslot; (void)tdma; (void)tleft;
@@ -615,6 +645,16 @@ static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* 
     int qw = 1;
     if (force_qw == 1 || force_qw == 2) qw = force_qw;
     if (fmt == FMT_SPLIT) qw = 1;
+#ifdef SYLBER_GEMM_ASM_EXPERIMENTS
+    if (force_qw >= 101 && force_qw <= 112) {       // knock-out variants of the key loop (timing only, results wrong): tools/attn_bench.py
+        const dim3 grid_a(((T + 127) / 128) * SYL_HEADS * B);
+#define ATA_VAR(N) case 100 + N: hipLaunchKernelGGL((attention_asm_kernel<false, FMT_BF16, N>), grid_a, dim3(256), 0, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L); break;
+        switch (force_qw) { ATA_VAR(1) ATA_VAR(2) ATA_VAR(3) ATA_VAR(4) ATA_VAR(5) ATA_VAR(6) ATA_VAR(7) ATA_VAR(8) ATA_VAR(9) ATA_VAR(10) ATA_VAR(11) ATA_VAR(12) }
+#undef ATA_VAR
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+#endif
     if (force_qw == 0 && fmt != FMT_SPLIT) {
         // default since round 5: the hand-scheduled key loop (attention_asm_kernel); 32 / 64 queries per wave select the
         // compiler-scheduled kernels, kept as its reference

@@ -54,6 +54,10 @@ __device__ __forceinline__ bf16_t f2bf_dev(float f) { return __builtin_bit_cast(
 enum { FMT_BF16 = 0, FMT_F16 = 1, FMT_SPLIT = 2 };
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// q leaves its projection pre-scaled by 64^-0.5 * log2(e): the attention scores q . k are then in log2 units, so the softmax is
+// exp2(s - m) with no multiply per score (round 5; every 16-bit attention kernel and the q / k / v epilogues share this constant --
+// the MXFP8 attention core keeps its own 2^-3 in EPI_QK8)
+#define SYL_Q_SCALE 0.18033688011112042f
 template <int FMT> struct H16 {
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
     static __device__ __forceinline__ uint32_t pack2_bounded(float lo, float hi) { return pack_bf16x2(lo, hi); }   // |x| known < 65504

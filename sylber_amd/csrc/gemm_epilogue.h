@@ -207,7 +207,7 @@ __device__ __forceinline__ void epilogue_rows32(const GemmArgs& a, const f32x16_
         const int nv = a.valid[b] < a.T ? a.valid[b] : a.T;
         zero_row = t >= nv;                              // TP:428-431 zero padded frames (and rows beyond T)
     }
-    const float qs = (EPI == EPI_QK && ncol0 < SYL_HIDDEN && PLANE < 0) ? 0.125f : 1.0f;     // q third pre-scaled by 64^-0.5 (exact)
+    const float qs = (EPI == EPI_QK && ncol0 < SYL_HIDDEN && PLANE < 0) ? SYL_Q_SCALE : 1.0f;     // q third pre-scaled by 64^-0.5 log2(e)
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
@@ -271,7 +271,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& a, const f32x16_
         // then their hi halves and their lo halves go through the wave's staging region one after the other (LDS
         // operations of one wave execute in order, so pass 1 may overwrite what pass 0 has read)
         f32x16_t v[FM][FN];
-        const float qs = (EPI == EPI_QK && ncol0 < SYL_HIDDEN) ? 0.125f : 1.0f;
+        const float qs = (EPI == EPI_QK && ncol0 < SYL_HIDDEN) ? SYL_Q_SCALE : 1.0f;
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll

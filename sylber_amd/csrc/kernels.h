@@ -12,7 +12,7 @@ enum GemmEpi {
     EPI_BF16 = 0,       // out0 bf16 [M][ld0] = act(acc + bias)
     EPI_F32 = 1,        // out0 f32  [M][ld0] = act(acc + bias)
     EPI_F32_RES = 2,    // out0 f32  [M][ld0] = acc + bias + res[m][n]
-    EPI_QK = 3,         // fused q/k/v projection: columns [0,768) q (x0.125) -> out0, [768,1536) k -> out1, both
+    EPI_QK = 3,         // fused q/k/v projection: columns [0,768) q (x SYL_Q_SCALE = log2(e) / 8) -> out0, [768,1536) k -> out1, both
                         // [B,H,Tp,64] bf16; columns [1536,2304) (N = 2304 only; needs Tp % 32 == 0) v -> out2 = Vt
                         // [B,H,64,Tpv] bf16 with the key axis bit-swapped, transposed through LDS
     EPI_PROJ = 4,       // feature projection: zero padded frames; out0 f32 [M][768]; out1 bf16 xpad
@@ -130,7 +130,7 @@ struct LnArgs {
 int launch_layernorm(const LnArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
-// flash attention: softmax(q k^T + key mask) v, 12 heads x 64, q pre-scaled by 1/8
+// flash attention: softmax(q k^T + key mask) v, 12 heads x 64, q pre-scaled by log2(e) / 8 (scores in log2 units)
 //   q,k: [B,H,Tp,64] bf16; vt: [B,H,64,Tpv] bf16; ctx out: [B*Tp][768] bf16
 // ------------------------------------------------------------------------------------------------
 // qw: 0 = automatic, 1 / 2 = 32 / 64 queries per wave

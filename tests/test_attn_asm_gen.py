@@ -25,11 +25,29 @@ def prog():
     return p
 
 
+def test_f16_format_of_the_loop():
+    """the fp16 operand format (precision="fp16"): same schedule, f16 MFMA / pack / reference grid"""
+    import attn_asm_emu as E
+    import gen_attn_asm as G
+    p = G.Gen("f16").build()
+    assert G.check_hazards(p.ins)
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((150, 64)).astype(np.float32) * 0.54
+    k = rng.standard_normal((150, 64)).astype(np.float32)
+    v = rng.standard_normal((150, 64)).astype(np.float32)
+    k[70] = 16.0 * q[5]
+    ref = E.reference(q, k, v, 131, fmt="f16")
+    for qb in range(2):
+        ctx, _ = E.run_workgroup(q, k, v, 131, qblock=qb, fmt="f16", prog=p)
+        nq = min(128, 150 - qb * 128)
+        assert np.abs(ctx[:nq] - ref[qb * 128:qb * 128 + nq]).max() < 4e-3
+
+
 @pytest.mark.parametrize("T,nvalid", [(1, 1), (31, 31), (33, 32), (64, 33), (65, 65), (100, 70), (128, 97), (143, 1), (200, 200), (300, 193)])
 def test_emulated_key_loop_matches_softmax_attention(prog, T, nvalid):
     import attn_asm_emu as E
     rng = np.random.default_rng(T * 1000 + nvalid)
-    q = rng.standard_normal((T, 64)).astype(np.float32) * 0.375
+    q = rng.standard_normal((T, 64)).astype(np.float32) * 0.54           # (pre-scaled by log2(e) / 8: scores in log2 units)
     k = rng.standard_normal((T, 64)).astype(np.float32)
     v = rng.standard_normal((T, 64)).astype(np.float32)
     if T > 40:
@@ -52,7 +70,7 @@ def test_emulator_catches_a_missing_wait(prog):
     broken.ins = [d for d in prog.ins if not (d["kind"] == "waitcnt" and d["vm"] == 0 and d["lgkm"] == 0)]
     rng = np.random.default_rng(5)
     q, k, v = (rng.standard_normal((200, 64)).astype(np.float32) for _ in range(3))
-    ctx, _ = E.run_workgroup(q * 0.125, k, v, 200, mode="late", prog=broken)
+    ctx, _ = E.run_workgroup(q * 0.18, k, v, 200, mode="late", prog=broken)
     assert not np.isfinite(ctx).all()
 
 

@@ -58,6 +58,10 @@ def test_layernorm(lib, D):
     assert (y.cpu() - ref).abs().max().item() < 2e-5
 
 
+LOG2E = 1.4426950408889634
+Q_SCALE = 0.125 * LOG2E
+
+
 @pytest.mark.parametrize("qw", [0, 1, 2])       # 0: the default (hand-scheduled key loop), 1 / 2: the compiler-scheduled kernels (32 / 64 queries per wave)
 @pytest.mark.parametrize("B,T,valid", [(2, 64, None), (3, 143, [143, 100, 1]), (2, 499, [499, 300]), (1, 700, None),
                                        (6, 499, None), (2, 1, None), (2, 33, [33, 32]), (3, 130, [130, 65, 64]), (1, 2999, None)])
@@ -73,7 +77,8 @@ def test_attention(lib, B, T, valid, qw):
     o = torch.full((B, T, 768), float("nan"), device="cuda")
     qd, kd, vdev = q.cuda(), k.cuda(), v.cuda()
     _lib.check(lib.sylber_op_attention(_p(qd), _p(kd), _p(vdev), _p(vd), _p(o), B, T, 0, 32 * qw, None), "op_attention")
-    qh = _bf(q * 0.125).view(B, T, 12, 64).transpose(1, 2)
+    # q is rounded to bf16 AFTER its pre-scaling by log2(e) / 8 (csrc/common.h SYL_Q_SCALE): the scores are in log2 units
+    qh = (_bf(q * Q_SCALE) / LOG2E).view(B, T, 12, 64).transpose(1, 2)
     kh = _bf(k).view(B, T, 12, 64).transpose(1, 2)
     vh = _bf(v).view(B, T, 12, 64).transpose(1, 2)
     s = qh @ kh.transpose(-1, -2)
@@ -148,7 +153,7 @@ def test_attention_full_batch_no_race(lib):
     g = torch.Generator().manual_seed(11)
     q = torch.randn(B, T, 768, generator=g); k = torch.randn(B, T, 768, generator=g); v = torch.randn(B, T, 768, generator=g)
     qd, kd, vdev = q.cuda(), k.cuda(), v.cuda()
-    qh = _bf(q * 0.125).view(B, T, 12, 64).transpose(1, 2)
+    qh = (_bf(q * Q_SCALE) / LOG2E).view(B, T, 12, 64).transpose(1, 2)
     kh = _bf(k).view(B, T, 12, 64).transpose(1, 2)
     vh = _bf(v).view(B, T, 12, 64).transpose(1, 2)
     ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).transpose(1, 2).reshape(B, T, 768)

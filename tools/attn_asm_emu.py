@@ -139,7 +139,7 @@ class Emu:
 
     def valu(self, w, d):
         o, dst, src = d["op"], d["dst"], d["src"]
-        f = lambda i: self.rdf(w, src[i])
+        f = lambda i: np.broadcast_to(np.asarray(self.rdf(w, src[i]), np.float32), (NLANE,))
         u = lambda i: self.rd(w, src[i])
         with np.errstate(invalid="ignore", over="ignore", under="ignore", divide="ignore"):
             if o == "v_mov_b32":
@@ -147,6 +147,15 @@ class Emu:
             elif o == "v_add_u32":
                 res = (np.asarray(u(0), np.uint64) + np.asarray(u(1), np.uint64)).astype(np.uint64) & 0xFFFFFFFF
                 res = np.broadcast_to(res.astype(np.uint32), (NLANE,)).copy()
+            elif o in ("v_and_b32", "v_xor_b32"):
+                a0 = np.broadcast_to(np.asarray(u(0), np.uint32), (NLANE,))
+                a1 = np.broadcast_to(np.asarray(u(1), np.uint32), (NLANE,))
+                res = (a0 & a1) if o == "v_and_b32" else (a0 ^ a1)
+            elif o == "v_lshlrev_b32":                       # D = S1 << S0
+                res = (np.broadcast_to(np.asarray(u(1), np.uint32), (NLANE,)).astype(np.uint64) << int(u(0))).astype(np.uint64) & 0xFFFFFFFF
+                res = res.astype(np.uint32)
+            elif o == "v_cvt_f32_f16":
+                res = (np.asarray(u(0), np.uint32) & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32).view(np.uint32)
             elif o == "v_subrev_u32":
                 res = ((np.asarray(u(1), np.int64) - np.asarray(u(0), np.int64)) & 0xFFFFFFFF).astype(np.uint32)
                 res = np.broadcast_to(res, (NLANE,)).copy()
@@ -161,7 +170,7 @@ class Emu:
             elif o == "v_mul_f32":
                 res = np.broadcast_to((f(0) * f(1)).astype(np.float32), (NLANE,)).copy().view(np.uint32)
             elif o == "v_fmamk_f32":                         # D = S0 * K + S1, one rounding
-                res = (np.asarray(f(0), np.float64) * np.float64(f(1)) + np.asarray(f(2), np.float64)).astype(np.float32).view(np.uint32)
+                res = (np.asarray(f(0), np.float64) * np.asarray(f(1), np.float64) + np.asarray(f(2), np.float64)).astype(np.float32).view(np.uint32)
             elif o == "v_exp_f32":
                 res = np.exp2(f(0).astype(np.float64)).astype(np.float32).view(np.uint32)
             elif o == "v_cvt_pk_bf16_f32":
@@ -203,9 +212,10 @@ class Emu:
         elif k == "valu":
             self.valu(w, d)
         elif k == "vcmp":
-            if d["op"] == "v_cmp_gt_f32":
+            if d["op"] in ("v_cmp_gt_f32", "v_cmp_lt_f32"):
                 with np.errstate(invalid="ignore"):
-                    w.vcc = np.broadcast_to(self.rdf(w, d["a"]) > self.rdf(w, d["b"]), (NLANE,)).copy()
+                    a_, b_ = self.rdf(w, d["a"]), self.rdf(w, d["b"])
+                    w.vcc = np.broadcast_to((a_ > b_) if d["op"] == "v_cmp_gt_f32" else (a_ < b_), (NLANE,)).copy()
             elif d["op"] == "v_cmp_lt_i32":
                 a = np.asarray(self.rd(w, d["a"]), np.uint32).astype(np.int64)
                 b = np.asarray(self.rd(w, d["b"]), np.uint32).view(np.int32).astype(np.int64)
@@ -326,7 +336,7 @@ def from16(h, fmt):
 
 
 def run_workgroup(q, k, vmat, nvalid, qblock=0, fmt="bf16", mode="late", order=None, ring_base=0, prog=None):
-    """q, k, vmat: float32 [T][64] of one (utterance, head), q already scaled by 1/8.  Returns (ctx [128][64] float32 for queries
+    """q, k, vmat: float32 [T][64] of one (utterance, head), q already scaled by log2(e) / 8 (scores in log2 units).  Returns (ctx [128][64] float32 for queries
     qblock*128 ..., the generator's instruction count per wave)."""
     T = q.shape[0]
     Tp = (T + 31) & ~31
@@ -367,6 +377,7 @@ def run_workgroup(q, k, vmat, nvalid, qblock=0, fmt="bf16", mode="late", order=N
             ops["kvoff%d" % i] = ((r * 64 + c * 8) * 2).astype(np.uint32)
             ops["vvoff%d" % i] = ((r * Tpv + c * 8) * 2).astype(np.uint32)
         ops["limbase"] = ((nvalid - 4 * h) & 0xFFFFFFFF).astype(np.uint32)
+        ops["hmask"] = np.where(h == 0, 0xFFFFFFFF, 0).astype(np.uint32)
         ops["rsk"] = ("mem", kmem)
         ops["rsv"] = ("mem", vmem)
         ops["ldsw"] = ring_base + w * 2048
@@ -394,9 +405,9 @@ def run_workgroup(q, k, vmat, nvalid, qblock=0, fmt="bf16", mode="late", order=N
 def reference(q, k, vmat, nvalid, fmt="bf16"):
     """softmax(q k^T) v over the valid keys, on the 16-bit-rounded operands, float64"""
     qq, kk, vv = (from16(to16(x, fmt), fmt).astype(np.float64) for x in (q, k, vmat))
-    s = qq @ kk[:nvalid].T
+    s = qq @ kk[:nvalid].T                                   # log2 units (q carries log2(e) / 8)
     s -= s.max(1, keepdims=True)
-    p = np.exp(s)
+    p = np.exp2(s)
     return (p / p.sum(1, keepdims=True)) @ vv[:nvalid]
 
 

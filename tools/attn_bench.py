@@ -16,3 +16,17 @@ for (B, T) in [(32, 499), (8, 2999)]:
             _lib.check(lib.sylber_debug_attention_bench(B, T, prec, 20, ctypes.byref(ms)), "bench")
             best = min(best, ms.value)
         print("B=%d T=%d %-11s %.1f us  %.0f TF" % (B, T, name, best * 1e3, fl / (best * 1e-3) / 1e12), flush=True)
+    ms = ctypes.c_float()
+    _lib.check(lib.sylber_debug_attention_bench(B, T, 0, -20, ctypes.byref(ms)), "bench")
+    print("B=%d T=%d asm on ALL-ZERO operands (DVFS probe): %.1f us" % (B, T, ms.value * 1e3), flush=True)
+if os.environ.get("SYLBER_HIP_LIB", "").endswith("_exp.so"):
+    names = {1: "no exp", 2: "no softmax", 3: "no MFMA", 4: "no frag reads", 5: "no DMA/barrier", 6: "no max", 7: "MFMA + softmax only", 8: "MFMA only", 9: "data movement only",
+             10: "exps spread (correct)", 11: "S first behind the barrier (correct)", 12: "both (correct)"}
+    for (B, T) in [(32, 499), (8, 2999)]:
+        for var in sorted(names):
+            best = 1e9
+            for _ in range(3):
+                ms = ctypes.c_float()
+                _lib.check(lib.sylber_debug_attention_bench(B, T, 200 + var, 20, ctypes.byref(ms)), "bench")
+                best = min(best, ms.value)
+            print("B=%d T=%d knock-out %d (%s): %.1f us" % (B, T, var, names[var], best * 1e3), flush=True)

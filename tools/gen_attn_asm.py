@@ -49,18 +49,18 @@ R = {
     "PA": 104, "PB": 112,               # packed probabilities, 8 registers each
     "F": 120,                           # fragment ring: 4 x 4 registers
     "rk": 136, "rv": 140,               # LDS read addresses (4 each): slot of the K tile being read / of the V^T tile being read
-    "m": 144, "nmb": 145, "thr": 146, "l": 147, "mx": 148, "ps": 149,   # ps: 149..152
+    "m": 144, "l": 147, "mx": 148, "ps": 149,   # ps: 149..152   (145, 146 free)
     "alpha": 153, "ta": 154, "tb": 155, "ninf": 156,
+    "kc": 158, "qm": 162,               # the "reference" MFMA: A = a constant-one feature (4 registers), B = -m of the query (4 registers)
 }
-FIXED_LO, FIXED_HI = 40, 156
+FIXED_LO, FIXED_HI = 40, 165
 
 LOG2E = 1.44269504088896341
 def f32bits(x):
     return struct.unpack("<I", struct.pack("<f", x))[0]
-LIT_LOG2E = f32bits(LOG2E)                  # 0x3fb8aa3b
-LIT_NLOG2E = f32bits(-LOG2E)
-LIT_THR = f32bits(8.0 / LOG2E)              # lazy-maximum slack in natural-log units of the raw score
+LIT_THR = f32bits(8.0)                      # lazy-maximum slack: p <= 2^8 (scores arrive in log2 units: q is pre-scaled by log2(e) / 8)
 LIT_NINF = 0xff800000
+ONE16 = {"bf16": 0x3f80, "f16": 0x3c00}
 
 
 def v(n):
@@ -146,9 +146,29 @@ def regs_of(x):
 # ====================================================================================================================================
 # the schedule
 # ====================================================================================================================================
+# knock-out variants for timing experiments (results wrong by construction; experiments build only)
+VARIANTS = {
+    1: {"noexp"},                      # v_exp_f32 -> v_mov_b32
+    2: {"nosoftmax"},                  # no softmax instructions at all
+    3: {"nomfma"},                     # no MFMAs
+    4: {"nolds"},                      # no fragment reads
+    5: {"nodma"},                      # no LDS-DMA, no tile barrier
+    6: {"nomax"},                      # no row maximum / lazy-maximum test
+    7: {"nolds", "nodma"},             # MFMA + softmax only
+    8: {"nolds", "nodma", "nosoftmax"},   # MFMA only
+    9: {"nosoftmax", "nomfma"},        # data movement only
+    # schedule variants (results CORRECT): same-box A/Bs of the shipped schedule
+    10: {"spread"},                    # exps interleaved with the adds / packs instead of four in a row
+    11: {"nopvfirst"},                 # the iteration behind the tile barrier in S, PV order like the others
+    12: {"spread", "nopvfirst"},
+}
+TUNE_FLAGS = {"spread", "nopvfirst"}
+
+
 class Gen:
-    def __init__(self, fmt="bf16"):
+    def __init__(self, fmt="bf16", knock=()):
         self.p = Prog()
+        self.knock = set(knock)
         self.fmt = fmt
         self.cvt = "v_cvt_pk_bf16_f32" if fmt == "bf16" else "v_cvt_pk_f16_f32"
         self.lds_order = []          # frag-ring slots with a read in flight, in LDS issue order: for exact lgkmcnt values
@@ -187,13 +207,34 @@ class Gen:
     def frag_state(self):
         return (tuple(self.lds_order), tuple(sorted(self.landed)))
 
+    # ---- 16-bit helpers ------------------------------------------------------------------------------------------------------------
+    def round16(self, dst, src):
+        """dst = src rounded to the operand format's grid, as fp32 (two instructions)"""
+        p = self.p
+        p.valu(self.cvt, dst, src, imm(0))
+        if self.fmt == "bf16":
+            p.valu("v_lshlrev_b32", dst, imm(16), dst)
+        else:
+            p.valu("v_cvt_f32_f16", dst, dst)
+
+    def set_qm(self, tmp):
+        """qm[0] = the 16-bit image of -m in the k = 0 slot of the B operand (lanes h = 0 only; everything else stays zero)"""
+        p = self.p
+        p.valu(self.cvt, tmp, v(R["m"]), imm(0))                  # m is on the grid already: exact
+        p.valu("v_xor_b32", tmp, lit(0x8000), tmp)
+        p.valu("v_and_b32", v(R["qm"]), op("hmask"), tmp)
+
     # ---- softmax of one half-tile as a list of closures (each emits ONE instruction) -------------------------------------------------
     def softmax_ops(self, S, P, masked, init, kv_half, resume_label, slow_label):
+        """The scores arrive RELATIVE to the query's reference m and in log2 units: S' = (K . Q^T) - m comes out of the matrix pipe
+        (q is pre-scaled by log2(e) / 8 by its producer, and the S chain contains one extra MFMA whose A operand is a constant-one
+        feature and whose B operand holds -m), so the softmax is exp2 + row sum + pack and nothing else.  Only the very first
+        half-tile (init: no reference yet) subtracts explicitly."""
         p, ops = self.p, []
         s = [v(S + r) for r in range(16)]
         pr = [v(P + r) for r in range(8)]
         ps = [v(R["ps"] + k) for k in range(4)]
-        mx, m, nmb, thr, l, ta, tb = (v(R[k]) for k in ("mx", "m", "nmb", "thr", "l", "ta", "tb"))
+        mx, m, l, ta, tb = (v(R[k]) for k in ("mx", "m", "l", "ta", "tb"))
         E = lambda f: ops.append(f)
         if masked:
             # key of register r: kv + (r & 3) + 8 (r >> 2) + 4 h ; valid iff  c_r < nvalid - 4 h - kv =: lim
@@ -212,54 +253,76 @@ class Gen:
         E(lambda: p.valu("v_max3_f32", mx, mx, ps[3], s[15]))
         E(lambda: p.valu("v_max_f32", mx, mx, ps[0]))
         if init:
-            # first half-tile: m = the query's maximum over both lane halves (key 0 is always valid, so it is finite)
+            # first half-tile: raw scores.  m = the query's maximum over both lane halves (key 0 is always valid, so it is finite),
+            # rounded to the operand grid (it travels through the matrix pipe from now on)
             E(lambda: p.valu("v_mov_b32", ta, mx))
             E(lambda: p.valu("v_mov_b32", tb, mx))
             E(lambda: p.nop(1))
             E(lambda: p.valu("v_permlane32_swap_b32", ta, tb))
             E(lambda: p.nop(1))
-            E(lambda: p.valu("v_max_f32", m, ta, tb))
-            E(lambda: p.valu("v_mul_f32", nmb, lit(LIT_NLOG2E), m))
-            E(lambda: p.valu("v_add_f32", thr, lit(LIT_THR), m))
+            E(lambda: p.valu("v_max_f32", mx, ta, tb))
+            E(lambda: p.valu(self.cvt, m, mx, imm(0)))
+            E(lambda: (p.valu("v_lshlrev_b32", m, imm(16), m) if self.fmt == "bf16" else p.valu("v_cvt_f32_f16", m, m)))
+            E(lambda: p.valu(self.cvt, ta, m, imm(0)))
+            E(lambda: p.valu("v_xor_b32", ta, lit(0x8000), ta))
+            E(lambda: (p.valu("v_and_b32", v(R["qm"]), op("hmask"), ta), self.mark_ref_ready()))
+            for r in range(16):
+                E(lambda r=r: p.valu("v_sub_f32", s[r], s[r], m))
         else:
-            E(lambda: p.vcmp("v_cmp_gt_f32", mx, thr))
+            E(lambda: p.vcmp("v_cmp_lt_f32", lit(LIT_THR), mx))
             E(lambda: p.branch("s_cbranch_vccnz", slow_label))
-            E(lambda: p.label(resume_label))
-        # p = exp2(s log2e - m log2e), in place; row sum in four partial sums; packed pairs in register order
-        def grp(g):
-            for r in range(4 * g, 4 * g + 4):
-                E(lambda r=r: p.valu("v_fmamk_f32", s[r], s[r], lit(LIT_LOG2E), nmb))
-            for r in range(4 * g, 4 * g + 4):
-                E(lambda r=r: p.valu("v_exp_f32", s[r], s[r], trans=True))
-        grp(0)
-        grp(1)
-        for k in range(4):
-            E(lambda k=k: p.valu("v_add_f32", ps[k], s[k], s[4 + k]))
-        E(lambda: p.valu(self.cvt, pr[0], s[0], s[1]))
-        E(lambda: p.valu(self.cvt, pr[1], s[2], s[3]))
-        grp(2)
-        E(lambda: p.valu(self.cvt, pr[2], s[4], s[5]))
-        E(lambda: p.valu(self.cvt, pr[3], s[6], s[7]))
-        grp(3)
-        for k in range(4):
-            E(lambda k=k: p.valu("v_add_f32", ps[k], ps[k], s[8 + k]))
-        E(lambda: p.valu(self.cvt, pr[4], s[8], s[9]))
-        E(lambda: p.valu(self.cvt, pr[5], s[10], s[11]))
-        for k in range(4):
-            E(lambda k=k: p.valu("v_add_f32", ps[k], ps[k], s[12 + k]))
-        E(lambda: p.valu(self.cvt, pr[6], s[12], s[13]))
-        E(lambda: p.valu(self.cvt, pr[7], s[14], s[15]))
+            E(lambda: (p.label(resume_label), self.mark_ref_ready()))
+        # p = exp2(s'), in place; row sum in four partial sums; packed pairs in register order
+        ex = lambda r: E(lambda r=r: p.valu("v_exp_f32", s[r], s[r], trans=True))
+        add0 = lambda k: E(lambda k=k: p.valu("v_add_f32", ps[k], s[k], s[4 + k]))
+        addn = lambda k, b: E(lambda k=k, b=b: p.valu("v_add_f32", ps[k], ps[k], s[b + k]))
+        cv = lambda i: E(lambda i=i: p.valu(self.cvt, pr[i], s[2 * i], s[2 * i + 1]))
+        if "spread" in self.knock:
+            for r in range(8):
+                ex(r)
+            for k in range(4):
+                ex(8 + k); add0(k)
+            for k in range(4):
+                ex(12 + k); cv(k)
+            for k in range(4):
+                addn(k, 8)
+            cv(4); cv(5)
+            for k in range(4):
+                addn(k, 12)
+            cv(6); cv(7)
+        else:
+            for r in range(8):
+                ex(r)
+            for k in range(4):
+                add0(k)
+            cv(0); cv(1)
+            for r in range(8, 12):
+                ex(r)
+            cv(2); cv(3)
+            for r in range(12, 16):
+                ex(r)
+            for k in range(4):
+                addn(k, 8)
+            cv(4); cv(5)
+            for k in range(4):
+                addn(k, 12)
+            cv(6); cv(7)
         E(lambda: p.valu("v_add_f32", ps[0], ps[0], ps[1]))
         E(lambda: p.valu("v_add_f32", ps[2], ps[2], ps[3]))
         E(lambda: p.valu("v_add_f32", ps[0], ps[0], ps[2]))
         E(lambda: p.valu("v_add_f32", l, l, ps[0]))
         return ops
 
-    def slow_path(self, slow_label, resume_label):
-        """some lane's maximum left the lazy window: new reference per QUERY (both lane halves), alpha = exp2((m_old - m_new) log2e)
-        (= 1 exactly where the query keeps its reference); l is rescaled here, O at the end of the iteration"""
+    def mark_ref_ready(self):
+        self.ref_ready = True
+
+    def slow_path(self, slow_label, resume_label, S):
+        """some lane's relative maximum left the lazy window (> 8): new reference per QUERY (both lane halves decide alike),
+        m' = grid(m + max), the CURRENT scores are rebased by delta = m' - m (exact: both on the grid), alpha = exp2(-delta) (= 1
+        exactly where the query keeps its reference); l is rescaled here, O at the end of the iteration; the reference MFMA of the
+        half-tile in flight (issued later in this iteration) picks up the new -m"""
         p = self.p
-        mx, m, nmb, thr, l, ta, tb, al = (v(R[k]) for k in ("mx", "m", "nmb", "thr", "l", "ta", "tb", "alpha"))
+        mx, m, l, ta, tb, al = (v(R[k]) for k in ("mx", "m", "l", "ta", "tb", "alpha"))
         p.label(slow_label)
         p.valu("v_mov_b32", ta, mx)
         p.valu("v_mov_b32", tb, mx)
@@ -267,16 +330,18 @@ class Gen:
         p.valu("v_permlane32_swap_b32", ta, tb)
         p.nop(1)
         p.valu("v_max_f32", mx, ta, tb)
-        p.vcmp("v_cmp_gt_f32", mx, thr)
-        p.valu("v_cndmask_b32", ta, m, mx)                       # m_new = need ? mx : m
-        p.valu("v_sub_f32", tb, m, ta)
-        p.valu("v_mul_f32", tb, lit(LIT_LOG2E), tb)
-        p.valu("v_exp_f32", tb, tb, trans=True)
+        p.valu("v_add_f32", ta, mx, m)
+        self.round16(ta, ta)
+        p.vcmp("v_cmp_lt_f32", lit(LIT_THR), mx)
+        p.valu("v_cndmask_b32", ta, m, ta)                       # m' = need ? grid(m + max) : m
+        p.valu("v_sub_f32", tb, ta, m)                           # delta >= 0
         p.valu("v_mov_b32", m, ta)
-        p.valu("v_mul_f32", nmb, lit(LIT_NLOG2E), m)
-        p.valu("v_add_f32", thr, lit(LIT_THR), m)
-        # a second trip before the deferred rescale has run cannot happen (one softmax per iteration), so alpha is free
-        p.valu("v_mov_b32", al, tb)
+        self.set_qm(al)
+        for r in range(16):
+            p.valu("v_sub_f32", v(S + r), v(S + r), tb)
+        p.valu("v_sub_f32", al, imm(0), tb)
+        p.valu("v_exp_f32", al, al, trans=True)
+        p.nop(0)
         p.valu("v_mul_f32", l, l, al)
         p.salu("s_mov_b32", op("resc"), imm(1))
         p.branch("s_branch", resume_label)
@@ -331,9 +396,20 @@ class Gen:
         gaps = len(live)
         done_f = 0
         gi = 0
-        for n in range(8):
+        self.ref_ready = False
+        order = list(range(8))
+        if barrier_dma and "nopvfirst" not in self.knock:
+            # behind the tile barrier the P.V fragments are already in registers, the K fragments were requested a moment ago:
+            # P.V first (same-box A/B: -1.5 %)
+            assert not addr_update
+            order = [1, 0, 3, 2, 4, 5, 6, 7]
+        for n in order:
             m = mf[n]
             slot = n % 4
+            if n == 6 and s_half is not None:
+                # the reference MFMA of the S chain: S(i+1) -= m.  Behind the point where this iteration may have moved m
+                assert self.ref_ready, "the reference MFMA must follow the lazy-maximum decision of this iteration"
+                p.mfma(vr(Smm, 16), vr(R["kc"], 4), vr(R["qm"], 4), vr(Smm, 16))
             if m is not None:
                 self.wait_frag(slot)
                 if m[0] == "S":
@@ -387,7 +463,7 @@ class Gen:
             self.rescale_block()
         self.pending_slow = getattr(self, "pending_slow", [])
         if not init:
-            self.pending_slow.append((slow, resume))
+            self.pending_slow.append((slow, resume, Ssm))
 
     def dma_block(self):
         """request tile t+2 into the slot tile t-1 occupied (four 1-KiB pieces per wave: two of K, two of V^T), if there is one"""
@@ -412,8 +488,8 @@ class Gen:
         p.salu("s_add_u32", op("tdma"), op("tdma"), imm(1))
 
     def flush_slow(self):
-        for slow, resume in getattr(self, "pending_slow", []):
-            self.slow_path(slow, resume)
+        for slow, resume, S in getattr(self, "pending_slow", []):
+            self.slow_path(slow, resume, S)
         self.pending_slow = []
 
     # ---- the whole statement ------------------------------------------------------------------------------------------------------
@@ -428,6 +504,10 @@ class Gen:
         p.salu("s_add_u32", "m0", op("ldsw"), imm(0))
         p.valu("v_mov_b32", v(R["l"]), imm(0))
         p.valu("v_mov_b32", v(R["ninf"]), lit(LIT_NINF))
+        p.valu("v_and_b32", v(R["kc"]), lit(ONE16[self.fmt]), op("hmask"))     # A operand of the reference MFMA: feature k = 0 is 1.0, for every key
+        for k in range(1, 4):
+            p.valu("v_mov_b32", v(R["kc"] + k), imm(0))
+            p.valu("v_mov_b32", v(R["qm"] + k), imm(0))
         p.dma(op("kvoff0"), opr("rsk", 4), op("koff"))
         p.salu("s_add_u32", "m0", "m0", imm(1024))
         for k in range(4):
@@ -500,7 +580,31 @@ class Gen:
         self.flush_slow()
         p.label(L_end)
         p.nop(15)                                                # the caller reads O (VALU) right behind the statement
+        if self.knock - TUNE_FLAGS:
+            p.ins = self.apply_knock(p.ins)
         return p
+
+    def apply_knock(self, ins):
+        kn, out = self.knock, []
+        soft_ops = {"v_max3_f32", "v_max_f32", "v_fmamk_f32", "v_exp_f32", "v_add_f32", self.cvt, "v_cndmask_b32", "v_subrev_u32", "v_mul_f32",
+                    "v_sub_f32", "v_permlane32_swap_b32"}
+        for d in ins:
+            k = d["kind"]
+            if "noexp" in kn and k == "valu" and d["op"] == "v_exp_f32":
+                d = dict(d, op="v_mov_b32", trans=False)
+            if "nosoftmax" in kn and ((k == "valu" and d["op"] in soft_ops) or k == "vcmp" or (k == "branch" and d["op"] == "s_cbranch_vccnz")):
+                continue
+            if "nomax" in kn and ((k == "valu" and d["op"] in ("v_max3_f32", "v_max_f32")) or (k == "vcmp" and d["op"] == "v_cmp_gt_f32")
+                                  or (k == "branch" and d["op"] == "s_cbranch_vccnz")):
+                continue
+            if "nomfma" in kn and k == "mfma":
+                continue
+            if "nolds" in kn and (k == "ds_read" or (k == "waitcnt" and d["vm"] is None)):
+                continue
+            if "nodma" in kn and (k in ("dma", "barrier") or (k == "waitcnt" and d["vm"] is not None)):
+                continue
+            out.append(d)
+        return out
 
     def final_pv(self, parity):
         """P.V of the last half-tile (P in PB: the last iteration is odd); its first two fragments were prefetched into ring slots 1, 3"""
@@ -674,18 +778,19 @@ OPERANDS_OUT = ['[o0] "=&{v[40:55]}"(o0)', '[o1] "=&{v[56:71]}"(o1)', '[lsum] "=
 OPERANDS_IN = ['[q0] "v"(qf[0])', '[q1] "v"(qf[1])', '[q2] "v"(qf[2])', '[q3] "v"(qf[3])',
                '[off0] "v"(off[0])', '[off1] "v"(off[1])', '[off2] "v"(off[2])', '[off3] "v"(off[3])',
                '[kvoff0] "v"(kvoff[0])', '[kvoff1] "v"(kvoff[1])', '[vvoff0] "v"(vvoff[0])', '[vvoff1] "v"(vvoff[1])',
-               '[limbase] "v"(limbase)', '[rsk] "s"(rsk)', '[rsv] "s"(rsv)', '[ldsw] "s"(ldsw)', '[nt] "s"(nt)',
+               '[limbase] "v"(limbase)', '[hmask] "v"(hmask)', '[rsk] "s"(rsk)', '[rsv] "s"(rsv)', '[ldsw] "s"(ldsw)', '[nt] "s"(nt)',
                '[kvl0] "s"(kvl0)', '[kvl1] "s"(kvl1)']
 
 
-def emit(fmt):
-    g = Gen(fmt)
+def emit(fmt, var=0):
+    g = Gen(fmt, VARIANTS[var] if var else ())
     prog = g.build()
-    check_hazards(prog.ins)
+    if not (g.knock - TUNE_FLAGS):
+        check_hazards(prog.ins)
     lines = to_asm(prog.ins)
     clob = ", ".join('"v%d"' % r for r in range(FIXED_LO, FIXED_HI + 1) if not (40 <= r <= 71 or r == 147))
     os.makedirs(OUTDIR, exist_ok=True)
-    dst = os.path.join(OUTDIR, "attn_asm_%s.inc" % fmt)
+    dst = os.path.join(OUTDIR, "attn_asm_%s%s.inc" % (fmt, "_v%d" % var if var else ""))
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit; the schedule is documented there.\n")
         f.write("// Expects MF (MFMA mnemonic string literal) and the operands named below in scope.\n")
@@ -709,7 +814,9 @@ if __name__ == "__main__":
     if what == "product":
         emit_product()
     elif what == "experiments":
-        pass                                                     # (no timing-only variants of this loop are kept)
+        os.makedirs(OUTDIR, exist_ok=True)
+        for var in sorted(VARIANTS):
+            emit("bf16", var)
     elif what == "hashes":
         import hashlib, json, tempfile
         with tempfile.TemporaryDirectory() as tmp:
