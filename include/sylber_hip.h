@@ -166,7 +166,9 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      instantiation falls back to 128x192): 80 = 256x256 4-wave, 90 = 256x192, 95 = 256x256
  *                                      8-wave, 85 / 91 / 97 = the same with a three-slot X ring, 86 = that ring on a 256x128 tile / four waves (91 also requests the fp32 residual rows of out-proj / FFN2 from
  *                                      inside its K loop when the launch has whole tiles; 96 = 91 without that), 60 = the 64-byte-row first cut)
- *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   32 (automatic choice) or 64
+ *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   0 (default): the hand-scheduled key loop (csrc/attention.hip attention_asm_kernel, generated by
+ *                                      tools/gen_attn_asm.py; bf16 / fp16 modes); 32 or 64: the compiler-scheduled kernels with that many
+ *                                      queries per wave (its reference; split16 always runs the 32-query one)
  *   SYLBER_OPT_GEMM_PERSISTENT         0 (automatic): GEMM launches of more than one round run as persistent workgroups
  *                                      walking the tile list (4-wave kernels: two per CU; the 256x256 kernel: one per CU
  *                                      with cross-tile operand prefetch); k > 0: k workgroups per CU for the 4-wave
@@ -181,8 +183,8 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      best with two batches in flight; 3 is best with one, profiles/r04_resln_prefetch.md)
  *   SYLBER_OPT_FP8_ATTENTION           SYLBER_FP8 only: 1 (and 0 = the default) = the attention core on MXFP8 operands too -- the q / k / v projection
  *                                      quantises its outputs (e4m3, one power-of-two scale per 32 features of q / k and per 32 keys of v),
- *                                      P is e4m3: BASELINE configs[4] as worded; where the batch shape has no whole 256-row tiles the bf16
- *                                      core runs instead; -1 = always the bf16 core (q, k, v, P in bf16; round-3 behaviour) */
+ *                                      P is e4m3: BASELINE configs[4] as worded, whatever the batch shape (round 5: the q / k / v launch pads its rows
+ *                                      up to whole 256-row tiles and does not store the padding); -1 = always the bf16 core (q, k, v, P in bf16) */
 enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3, SYLBER_OPT_FUSE_OUTPROJ_LN = 4,
        SYLBER_OPT_CONV0_VALU = 5, SYLBER_OPT_RESLN_PREFETCH = 6, SYLBER_OPT_FP8_ATTENTION = 7 };
 int sylber_set_option(sylber_t h, int32_t key, int32_t value);

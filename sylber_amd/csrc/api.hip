@@ -284,7 +284,7 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
         case SYLBER_OPT_ATTN_QUERIES_PER_WAVE: c->opt_attn_qw = value == 32 ? 1 : (value == 64 ? 2 : 0); break;
         case SYLBER_OPT_GEMM_PERSISTENT: c->opt_gemm_persist = value; break;      // < 0: also keep the 256x256 kernel one tile per workgroup
         case SYLBER_OPT_FUSE_OUTPROJ_LN: c->opt_fuse_ln = value > 0 ? 1 : (value < 0 ? -1 : 0); break;
-        case SYLBER_OPT_CONV0_VALU: c->opt_conv0_valu = value > 0 ? 1 : 0; break;
+        case SYLBER_OPT_CONV0_VALU: c->opt_conv0_valu = value > 0 ? (value == 2 ? 2 : 1) : 0; break;     // (2: producer-only timing probe, experiments build)
         case SYLBER_OPT_RESLN_PREFETCH: c->opt_resln_pre = value < 0 ? -1 : (value <= 3 ? value : 0); break;
         case SYLBER_OPT_FP8_ATTENTION: c->opt_attn8 = value < 0 ? -1 : (value > 0 ? 1 : 0); break;
         default: syl_set_error("sylber_set_option", "unknown option key"); return 1;

@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
 #define C0M_WFR (16 * 64 * 32)                    // weight fragments: [16 blocks][64 lanes][hi 16 B | lo 16 B] = 32 KiB
 #define C0M_STG (32 * (256 + 16))                 // per-wave staging: 32 rows x 128 channels (+ 16 B pad): 8704 B
 #define C0M_LDS (C0M_WFR + 512 * 4 + (C0_ROWS * 5 + 16) * 4 + 4 * C0M_STG)
-template <int FMT>
+// NOSTORE (experiments build, SYLBER_OPT_CONV0_VALU = 2): the rows are produced into the LDS staging region and never leave it --
+// the cost of conv0 as a PRODUCER inside another kernel (profiles/r05_conv0_fusion.md); results wrong by construction
+template <int FMT, bool NOSTORE = false>
 __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restrict__ wav, int Lmax, int L0, int R0,
                                                             const float* __restrict__ w0, const float* __restrict__ scale_shift,
                                                             bf16_t* __restrict__ out) {
@@ -277,7 +279,8 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(const float* __restr
                 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
                 const u32x4_t v = *(const u32x4_t*)(stg + r * (256 + 16) + ch * 16);
                 const int l = l0 + r;
-                if (l < R0) __builtin_nontemporal_store(v, (u32x4_t*)(out + ((size_t)b * R0 + l) * SYL_CONV + q4 * 128 + ch * 8));
+                if constexpr (NOSTORE) { if (v.x == 0x7fc1dead && l < 0) out[0] = (bf16_t)v.y; }      // (keeps the staging reads alive)
+                else if (l < R0) __builtin_nontemporal_store(v, (u32x4_t*)(out + ((size_t)b * R0 + l) * SYL_CONV + q4 * 128 + ch * 8));
             }
         }
     }
@@ -303,7 +306,7 @@ int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, cons
         hipLaunchKernelGGL((conv0_gn_gelu_kernel<true, true, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
     else if (fmt == FMT_SPLIT)      // erf GELU in the reference's order (conv, then scale and shift), two half planes out
         hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, true, FMT_SPLIT>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, out_lo);
-    else if ((fmt == FMT_F16 || fmt == FMT_BF16) && valu16) {
+    else if ((fmt == FMT_F16 || fmt == FMT_BF16) && valu16 == 1) {
         if (fmt == FMT_F16) hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_F16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
         else hipLaunchKernelGGL((conv0_gn_gelu_kernel<false, false, FMT_BF16>), grid, dim3(256), 0, s, wav, Lmax, L0, R0, w0, scale_shift, out, 0L);
     } else if (fmt == FMT_F16 || fmt == FMT_BF16) {
@@ -318,6 +321,13 @@ int launch_conv0_gn_gelu(const float* wav, int B, int Lmax, int L0, int R0, cons
         int gx = (1024 + B - 1) / B;                  // ~1024 workgroups however long the batch: gx row-block walkers per utterance
         gx = gx < 1 ? 1 : (gx > (int)grid.x ? (int)grid.x : gx);
         const dim3 pgrid(gx, B);
+#ifdef SYLBER_GEMM_ASM_EXPERIMENTS
+        if (valu16 == 2) {
+            static PerDeviceOnce once2;
+            if (once2.need()) HIP_TRY(hipFuncSetAttribute((const void*)conv0_mfma_kernel<FMT_BF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C0M_LDS));
+            hipLaunchKernelGGL((conv0_mfma_kernel<FMT_BF16, true>), pgrid, dim3(256), C0M_LDS, s, wav, Lmax, L0, R0, w0, scale_shift, (bf16_t*)out);
+        } else
+#endif
         if (fmt == FMT_F16) hipLaunchKernelGGL((conv0_mfma_kernel<FMT_F16>), pgrid, dim3(256), C0M_LDS, s, wav, Lmax, L0, R0, w0, scale_shift, (bf16_t*)out);
         else hipLaunchKernelGGL((conv0_mfma_kernel<FMT_BF16>), pgrid, dim3(256), C0M_LDS, s, wav, Lmax, L0, R0, w0, scale_shift, (bf16_t*)out);
     }

@@ -342,3 +342,33 @@ def test_stream_abandoned_early_then_reused(sd):
     for out, exp in zip(got, ref):
         for g, e in zip(out, exp):
             assert np.array_equal(g["hidden_states"], e["hidden_states"]) and np.array_equal(g["segments"], e["segments"])
+
+
+# measured on MI355X with tools/agreement_table.py (round 5, 64 / 256 synthetic 10 s clips, truth = this library's fp32 mode, which is
+# bit-identical to the reference on every golden): tables identical 12 / 64 (38 / 256) bf16, 47 / 64 (183 / 256) fp16, 0 fp8, all split16;
+# boundary recall 0.9943 / 0.9984 / 0.9247 / 1.0; hidden rel-RMS 5.4e-3 / 7.3e-4 / 3.7e-2 / 3.1e-6.  Floors = measured minus a margin
+# of a few flipped decisions, so that a regression of a fast mode's DECISIONS is caught, not only of its hidden-state error
+AGREEMENT_FLOORS = {
+    "bf16": dict(recall=0.990, precision=0.989, tables=6, rel=7e-3),
+    "fp16": dict(recall=0.9965, precision=0.9975, tables=38, rel=1e-3),
+    "fp8": dict(recall=0.90, precision=0.95, tables=0, rel=4.5e-2),
+    "split16": dict(recall=1.0, precision=1.0, tables=64, rel=1e-5),
+}
+
+
+def test_agreement_table_floors(sd):
+    """the segment-agreement table of every fast mode (boundaries found / tables identical against the fp32 parity
+    mode on 64 synthetic 10 s clips = 15 186 boundaries) with floors at the measured values; split16 must reproduce EVERY table
+    (north_star's "boundaries bit-identical" is met by precision="split16" and "fp32": INTEGRATION.md)"""
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.agreement import segment_agreement
+    truth = HubertEncoderHIP(sd, precision="fp32")
+    for prec, fl in AGREEMENT_FLOORS.items():
+        e = HubertEncoderHIP(sd, precision=prec)
+        r = segment_agreement(sd, e, 64, truth=truth)
+        assert r["clips"] == 64 and r["boundaries_fp32"] > 10000
+        assert r["boundary_recall"] >= fl["recall"], (prec, r)
+        assert r["boundary_precision"] >= fl["precision"], (prec, r)
+        assert r["tables_identical"] >= fl["tables"], (prec, r)
+        assert r["hidden_rel_rms_vs_fp32"] <= fl["rel"], (prec, r)
+        del e
