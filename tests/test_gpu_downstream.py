@@ -121,3 +121,33 @@ def test_resynth_front_with_quantizer_hook(normalize):
     got, exp = inp.cpu().numpy(), exp_inp.numpy()
     assert np.array_equal(got == 0.0, exp == 0.0)
     assert np.abs(got - exp).max() <= 2e-4 * np.abs(exp).max()
+
+
+def test_resynth_front_against_the_references_own_resynthesize(golden_dir):
+    """row N3 end to end against REFERENCE OUTPUT (tests/golden/resynth_front.npz: the reference's own
+    SegmentSynthesis.resynthesize on seeded hidden states, tools/gen_golden_resynth.py): segment tables bit-exact, the conditioning
+    input with the reference's silence mask, the quantiser hook's broadcast, and the ``features=`` branch"""
+    from test_oracle_downstream import resynth_golden_inputs         # (the seeded inputs of the golden: tests/ is on sys.path under pytest)
+    from sylber_amd import HubertEncoderHIP
+    from sylber_amd.downstream import KMQuantizer, SegmentConditioner
+    g = np.load(os.path.join(golden_dir, "resynth_front.npz"))
+    msd = synthetic_mlp_state_dict(1)
+    h, cent, f = resynth_golden_inputs()
+    enc = HubertEncoderHIP(synthetic_state_dict(0, num_layers=1), num_layers=1)
+    cond = SegmentConditioner(msd)
+    hd = h.cuda()
+    seg, nseg, feats = enc.segment(hd, 2.6, 0.8)
+    assert np.array_equal(nseg.cpu().numpy(), g["nseg"])
+    tables = np.concatenate([seg[b, :int(nseg[b])].cpu().numpy().reshape(-1, 2) for b in range(4)], 0)
+    assert np.array_equal(tables, g["segments"])
+    inp, _ = cond(hd, seg, nseg, feats, normthreshold=2.6)
+    got = inp.cpu().numpy()
+    assert np.array_equal(got == 0.0, g["cond"] == 0.0)
+    assert np.abs(got - g["cond"]).max() <= 2e-4 * np.abs(g["cond"]).max()
+    inq, _ = cond(hd, seg, nseg, feats, normthreshold=2.6, quantizer=KMQuantizer(cent))
+    gq = inq.cpu().numpy()
+    assert np.array_equal(gq == 0.0, g["cond_quantized"] == 0.0)
+    assert np.abs(gq - g["cond_quantized"]).max() <= 2e-4 * np.abs(g["cond_quantized"]).max()
+    gf = cond.from_features(f.cuda()).cpu().numpy()
+    assert np.array_equal(gf == 0.0, g["cond_features"] == 0.0)
+    assert np.abs(gf - g["cond_features"]).max() <= 2e-4 * np.abs(g["cond_features"]).max()

@@ -17,6 +17,8 @@ python bench.py --batch 8 --clip-seconds 60 --no-cpu-baseline --no-api > $OUT/be
 python bench.py --no-overlap --no-cpu-baseline --no-api > $OUT/bench_sequential.json 2> $OUT/bench_sequential.err
 python bench.py --ragged --no-cpu-baseline --no-api > $OUT/bench_ragged.json 2> $OUT/bench_ragged.err
 python bench.py --exchange-selftest --no-cpu-baseline --no-api 2> $OUT/bench_selftest.err | tail -1 > $OUT/bench_exchange_selftest.json
+python tools/attn_bench.py > $OUT/attn_bench.txt 2>&1
+python tools/gemm_bench.py -1,4,91,97 > $OUT/gemm_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api > $OUT/trace_pipelined.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sequential -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-overlap > $OUT/trace_sequential.log 2>&1
