@@ -16,7 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 # SYLBER_EXPERIMENTS=1: the timing-only kernels (knock-out loops, phase stamps; some store nothing) are compiled in and the
 # result goes to ITS OWN file, so an experiments build can never be mistaken for / left behind as the product library.
 EXPERIMENTS = bool(os.environ.get("SYLBER_EXPERIMENTS"))
-LIB = os.path.join(HERE, "libsylber_hip_exp.so" if EXPERIMENTS else "libsylber_hip.so")
+# SYLBER_BUILD_VARIANT=name + SYLBER_EXTRA_CFLAGS="-D...": an A/B build with extra compiler flags into ITS OWN library
+# (libsylber_hip_<name>.so, objects under build/<name>/): load it with SYLBER_HIP_LIB for a same-box comparison
+VARIANT = os.environ.get("SYLBER_BUILD_VARIANT", "")
+EXTRA_CFLAGS = os.environ.get("SYLBER_EXTRA_CFLAGS", "").split() if VARIANT else []
+LIB = os.path.join(HERE, "libsylber_hip_%s.so" % VARIANT if VARIANT else ("libsylber_hip_exp.so" if EXPERIMENTS else "libsylber_hip.so"))
 GEN_DIR = os.path.join(HERE, "build", "gen")           # generated inline-asm loops (never committed: tools/gen_gemm_asm.py writes them here)
 GENERATORS = [os.path.join(os.path.dirname(HERE), "tools", g) for g in ("gen_gemm_asm.py", "gen_attn_asm.py")]
 SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip", "gemm_rowln.hip", "gemm_asm.hip", "gemm_asm_f8.hip"]
@@ -64,7 +68,7 @@ def generate(what=("product",), outdir: str = GEN_DIR) -> None:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
         return LIB
-    objdir = os.path.join(HERE, "build", "exp" if EXPERIMENTS else "obj")
+    objdir = os.path.join(HERE, "build", VARIANT if VARIANT else ("exp" if EXPERIMENTS else "obj"))
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     # the inline-asm K loops are generated at build time (33 k lines that used to be committed beside their generator)
@@ -81,7 +85,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(newest_shared, os.path.getmtime(os.path.join(CSRC, src))):
             return obj
-        extra = EXTRA.get(src, []) + exp_flags
+        extra = EXTRA.get(src, []) + exp_flags + EXTRA_CFLAGS
         cmd = [hipcc] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

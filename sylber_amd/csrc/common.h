@@ -184,6 +184,30 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * fmaf(xc, q, 0.5f);
 }
 
+// A/B (round 5): sigmoid forms of the same function, gelu(x) = x / (1 + exp2(-x P(x^2))), two transcendentals (exp2, rcp) instead of the
+// degree-8 polynomial.  SYL_GELU_VARIANT 1: P = p0 + p1 u, 7 instructions, max |error| 2.7e-4; 2: P = p0 + p1 u + p2 u^2 with u clamped at
+// 36 (p2 < 0: unclamped, the argument changes sign beyond |x| = 11), 9 instructions, 2.5e-5 (fits: minimax over [-12, 12], fp32 evaluation)
+#ifndef SYL_GELU_VARIANT
+#define SYL_GELU_VARIANT 0
+#endif
+__device__ __forceinline__ float gelu_sig2(float x) {
+    const float u = x * x;
+    const float t = fmaf(0.1001257f, u, 2.30876518f) * x;
+    const float e = __builtin_amdgcn_exp2f(-t);
+    return x * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ float gelu_sig3(float x) {
+    const float u = fminf(x * x, 36.0f);
+    const float t = fmaf(fmaf(-1.01424778e-03f, u, 1.06775700e-01f), u, 2.30112128f) * x;
+    const float e = __builtin_amdgcn_exp2f(-t);
+    return x * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+#if SYL_GELU_VARIANT == 1
+#define gelu_fast gelu_sig2
+#elif SYL_GELU_VARIANT == 2
+#define gelu_fast gelu_sig3
+#endif
+
 // two values of one run.  (This used to go through the packed-fp32 VALU -- v_pk_fma_f32 carries two lanes' worth of
 // work per issue -- and was measured neutral; packed fp32 is now banned from the library, see build.py.)
 __device__ __forceinline__ void gelu_fast2(float& a, float& b) { a = gelu_fast(a); b = gelu_fast(b); }
