@@ -10,21 +10,21 @@ OUT=$ROOT/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 python bench.py --agreement-clips 256 > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
 python bench.py --precision fp16 --no-cpu-baseline --agreement-clips 256 > $OUT/bench_fp16.json 2> $OUT/bench_fp16.err
-python bench.py --precision fp8 --no-cpu-baseline --no-api > $OUT/bench_fp8.json 2> $OUT/bench_fp8.err
+python bench.py --precision fp8 --no-cpu-baseline --no-api --no-other-configs > $OUT/bench_fp8.json 2> $OUT/bench_fp8.err
 python bench.py --precision fp32 --no-cpu-baseline --no-api --steps 5 --warmup 1 --inflight 1 > $OUT/bench_fp32.json 2> $OUT/bench_fp32.err
 python bench.py --precision split16 --no-cpu-baseline --no-api --steps 10 --warmup 2 --agreement-clips 256 > $OUT/bench_split16.json 2> $OUT/bench_split16.err
-python bench.py --batch 8 --clip-seconds 60 --no-cpu-baseline --no-api > $OUT/bench_longform.json 2> $OUT/bench_longform.err
-python bench.py --no-overlap --no-cpu-baseline --no-api > $OUT/bench_sequential.json 2> $OUT/bench_sequential.err
-python bench.py --ragged --no-cpu-baseline --no-api > $OUT/bench_ragged.json 2> $OUT/bench_ragged.err
+python bench.py --batch 8 --clip-seconds 60 --no-cpu-baseline --no-api --no-other-configs > $OUT/bench_longform.json 2> $OUT/bench_longform.err
+python bench.py --no-overlap --no-cpu-baseline --no-api --no-other-configs > $OUT/bench_sequential.json 2> $OUT/bench_sequential.err
+python bench.py --ragged --no-cpu-baseline --no-api --no-other-configs > $OUT/bench_ragged.json 2> $OUT/bench_ragged.err
 python bench.py --exchange-selftest --no-cpu-baseline --no-api 2> $OUT/bench_selftest.err | tail -1 > $OUT/bench_exchange_selftest.json
 python tools/attn_bench.py > $OUT/attn_bench.txt 2>&1
 python tools/gemm_bench.py -1,4,91,97 > $OUT/gemm_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api > $OUT/trace_pipelined.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sequential -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-overlap > $OUT/trace_sequential.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-overlap > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-overlap > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/pmc_mfma -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-overlap > $OUT/pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-other-configs > $OUT/trace_pipelined.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sequential -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-other-configs --no-overlap > $OUT/trace_sequential.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-other-configs --no-overlap > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-other-configs --no-overlap > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/pmc_mfma -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-other-configs --no-overlap > $OUT/pmc_mfma.log 2>&1
 cd $ROOT
 cp $(find $OUT/pmc_mfma -name '*counter_collection.csv' | head -1) $OUT/mfma_counters.csv
 rm -rf $OUT/pmc_mfma
