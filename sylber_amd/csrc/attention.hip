@@ -572,7 +572,6 @@ __global__ __launch_bounds__(256, 3) void attention_asm_kernel(const bf16_t* __r
         const i32x4a_t rsk = rsrc_words_a(Kb), rsv = rsrc_words_a(Vb);
         const int ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);
         const int limbase = nvalid - 4 * h;
-        const int hmask = h ? 0 : -1;
         const int kvl0 = __builtin_amdgcn_readfirstlane(64 * (nt - 1)), kvl1 = __builtin_amdgcn_readfirstlane(64 * (nt - 1) + 32);
         f32x16_t o0, o1;
         int koff, voff, resc, snext, dslot, tdma, tleft;
@@ -601,12 +600,6 @@ __global__ __launch_bounds__(256, 3) void attention_asm_kernel(const bf16_t* __r
 #include "attn_asm_bf16_v8.inc"
             } else if constexpr (VAR == 9) {
 #include "attn_asm_bf16_v9.inc"
-            } else if constexpr (VAR == 10) {
-#include "attn_asm_bf16_v10.inc"
-            } else if constexpr (VAR == 11) {
-#include "attn_asm_bf16_v11.inc"
-            } else if constexpr (VAR == 12) {
-#include "attn_asm_bf16_v12.inc"
             } else
 #endif
             {
@@ -646,10 +639,10 @@ static int launch_attention_any(const bf16_t* q, const bf16_t* k, const bf16_t* 
     if (force_qw == 1 || force_qw == 2) qw = force_qw;
     if (fmt == FMT_SPLIT) qw = 1;
 #ifdef SYLBER_GEMM_ASM_EXPERIMENTS
-    if (force_qw >= 101 && force_qw <= 112) {       // knock-out variants of the key loop (timing only, results wrong): tools/attn_bench.py
+    if (force_qw >= 101 && force_qw <= 109) {       // knock-out variants of the key loop (timing only, results wrong): tools/attn_bench.py
         const dim3 grid_a(((T + 127) / 128) * SYL_HEADS * B);
 #define ATA_VAR(N) case 100 + N: hipLaunchKernelGGL((attention_asm_kernel<false, FMT_BF16, N>), grid_a, dim3(256), 0, s, q, k, vt, valid, c, T, Tp, Tpv, nullptr, 0L); break;
-        switch (force_qw) { ATA_VAR(1) ATA_VAR(2) ATA_VAR(3) ATA_VAR(4) ATA_VAR(5) ATA_VAR(6) ATA_VAR(7) ATA_VAR(8) ATA_VAR(9) ATA_VAR(10) ATA_VAR(11) ATA_VAR(12) }
+        switch (force_qw) { ATA_VAR(1) ATA_VAR(2) ATA_VAR(3) ATA_VAR(4) ATA_VAR(5) ATA_VAR(6) ATA_VAR(7) ATA_VAR(8) ATA_VAR(9) }
 #undef ATA_VAR
         HIP_TRY(hipGetLastError());
         return 0;

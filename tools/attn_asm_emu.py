@@ -377,7 +377,6 @@ def run_workgroup(q, k, vmat, nvalid, qblock=0, fmt="bf16", mode="late", order=N
             ops["kvoff%d" % i] = ((r * 64 + c * 8) * 2).astype(np.uint32)
             ops["vvoff%d" % i] = ((r * Tpv + c * 8) * 2).astype(np.uint32)
         ops["limbase"] = ((nvalid - 4 * h) & 0xFFFFFFFF).astype(np.uint32)
-        ops["hmask"] = np.where(h == 0, 0xFFFFFFFF, 0).astype(np.uint32)
         ops["rsk"] = ("mem", kmem)
         ops["rsv"] = ("mem", vmem)
         ops["ldsw"] = ring_base + w * 2048
@@ -390,8 +389,8 @@ def run_workgroup(q, k, vmat, nvalid, qblock=0, fmt="bf16", mode="late", order=N
     emu.run(waves, order)
     ctx = np.zeros((128, 64), np.float32)
     for w, wv in enumerate(waves):
-        o = wv.v[40:72].view(np.float32)                          # O0: 40..55, O1: 56..71
-        l = wv.v[147].view(np.float32)
+        o = wv.v[G.R["O0"]:G.R["O0"] + 32].view(np.float32)      # O0, O1
+        l = wv.v[G.R["l"]].view(np.float32)
         ltot = l + l[lane ^ 32]
         for ln in range(NLANE):
             qq, hh = ln & 31, ln >> 5

@@ -1,36 +1,44 @@
 #!/usr/bin/env python3
-"""Generate the hand-scheduled key loop of attention_asm_kernel (csrc/attention_asm.hip) -> attn_asm_{bf16,f16}.inc.
+"""Generate the hand-scheduled key loop of attention_asm_kernel (csrc/attention.hip) -> attn_asm_{bf16,f16}.inc.
 
 The whole key loop of one wave (32 queries x all keys of one (utterance, head)) is ONE inline-asm statement, software-pipelined
 over 32-key HALF-TILES so that the matrix pipe never waits for the softmax of the same wave (semantics:
 transformers eager_attention_forward / sdpa TP:234-259 reached from sylber/model/sylber.py:122 -- softmax(q k^T / 8 + key mask) v):
 
-    iteration i:   MFMA   S(i+1) = K(half i+1) . Q^T        4 x v_mfma_f32_32x32x16 (chain on one accumulator block)
+    iteration i:   MFMA   S(i+1) = K(half i+1) . Q^T - m     4 x v_mfma_f32_32x32x16, a chain on one accumulator block whose first link
+                                                             takes the SEED BLOCK (16 registers holding -m) as its C operand
                    MFMA   O^T   += V^T(half i-1) . P(i-1)^T  4 x v_mfma (two accumulator blocks x two 16-key groups)
-                   VALU   P(i)   = exp2((S(i) - m) log2 e), row sums, bf16 pack   (~65 instructions)
-    the eight MFMAs alternate S, PV, S, PV, ... and the VALU work is dealt evenly into the gaps between them.
+                   VALU   P(i)   = exp2(S(i)), row sums, 16-bit pack   (49 instructions: q is pre-scaled by log2(e) / 8 by its producer,
+                                                             so the scores leave the matrix pipe relative to m and in log2 units)
+    issue order P.V, P.V, S, P.V, S, P.V, S, S: the S chain starts behind this iteration's lazy-maximum decision (which may rewrite the
+    seed block), and behind a tile barrier the P.V fragments are the ones already in registers; the VALU work is dealt into the gaps.
 
-Everything stays "query = lane & 31" as in csrc/attention.hip (the compiler-scheduled kernel, kept as the reference): S^T[key][q]
+Everything stays "query = lane & 31" as in the compiler-scheduled attention_bf16_kernel (kept as the reference): S^T[key][q]
 leaves the matrix pipe with lane (q, h) holding keys 8 g + 4 h + e of the half-tile in register 4 g + e, which packed to 16 bits in
 register order IS the B operand of the two P.V MFMAs (V^T's key axis is stored with bits 2 and 3 swapped by the q/k/v GEMM epilogue).
+P has ONE register buffer: a pack is gated behind the issue of the P.V MFMAs that still read the registers it overwrites.
 
 Registers are FIXED physical VGPRs (an asm operand cannot be addressed by sub-register, and the softmax works on single registers
-of the MFMA accumulator blocks): see R below.  Inputs arrive in compiler-allocated operands.
+of the MFMA accumulator blocks): see R below (163 registers: three waves per SIMD).  Inputs arrive in compiler-allocated operands.
 
 LDS: a ring of three 16-KiB slots per workgroup (K tile of 64 keys x 128 B at +0, V^T tile of 64 features x 128 B at +8192); three
 tiles are live at any time (V of tile t-1, K and V of tile t, K of tile t+1).  One barrier per 64-key tile, at the head of every odd
 iteration: behind it every wave's LDS-DMA pieces of tile t+1 have landed (own pieces: s_waitcnt vmcnt(0) before the barrier) and
 every wave has finished reading tile t-1, whose slot the pieces of tile t+2 are then requested into.
 
-Online softmax: the running maximum is LAZY (as in attention.hip): scores are exponentiated against a stale maximum until a new
-score exceeds it by 8 / log2 e; the test is per lane against the lane's own 16 scores (no cross-lane exchange on the fast path --
-both halves of a query hold the same m, and the slow path, entered by the whole wave when ANY lane trips, exchanges the maxima with
-v_permlane32_swap and decides per query).  The rescale of the accumulator by alpha is deferred to the end of the iteration (the
-P.V MFMAs of half-tile i-1, issued during iteration i, still belong to the old scale).
+Online softmax: the running maximum is LAZY (as in attention_bf16_kernel): scores are exponentiated against a stale reference until
+a relative score exceeds 8 (p <= 2^8); the test is per lane against the lane's own 16 scores (no cross-lane exchange on the fast
+path -- both halves of a query hold the same m, and the slow path, entered by the whole wave when ANY lane trips, exchanges the maxima
+with v_permlane32_swap, decides per query, rebases the scores in flight and rewrites the seed block).  The rescale of the accumulator
+by alpha is deferred to the end of the iteration (the P.V MFMAs of half-tile i-1, issued during iteration i, belong to the old scale).
 
 The instruction list is built as a small IR that is (a) printed as the asm text, (b) checked statically for the hazards the
-compiler would otherwise handle (MFMA result -> VALU: 12 wait states on gfx950; transcendental result -> next VALU: 1; M0 write ->
-LDS-DMA: 1), and (c) EXECUTED by tools/attn_asm_emu.py against a numpy softmax (tests/test_attn_asm_gen.py, CPU tier).
+compiler would otherwise handle (MFMA result -> VALU: 12 wait states on gfx950; VALU result -> MFMA operand: 2; transcendental
+result -> next VALU: 1; M0 write -> LDS-DMA: 1; along both arms of every branch), and (c) EXECUTED by tools/attn_asm_emu.py against a
+numpy softmax (tests/test_attn_asm_gen.py, CPU tier).
+
+History (profiles/r05_attention.md): v1 multiplied and subtracted per score (65 VALU); v2 fed -m through the matrix pipe as a ninth
+MFMA (constant-one feature x -m) -- time-neutral under the chip's power cap; v3 (this one) seeds the chain's accumulator instead: -2 %.
 """
 import os
 import struct
@@ -46,21 +54,21 @@ NSLOT = 3
 R = {
     "O0": 40, "O1": 56,                 # O^T accumulators (features 0-31 / 32-63), 16 registers each
     "SA": 72, "SB": 88,                 # score blocks (double buffer by half-tile parity)
-    "PA": 104, "PB": 112,               # packed probabilities, 8 registers each
-    "F": 120,                           # fragment ring: 4 x 4 registers
-    "rk": 136, "rv": 140,               # LDS read addresses (4 each): slot of the K tile being read / of the V^T tile being read
-    "m": 144, "l": 147, "mx": 148, "ps": 149,   # ps: 149..152   (145, 146 free)
-    "alpha": 153, "ta": 154, "tb": 155, "ninf": 156,
-    "kc": 158, "qm": 162,               # the "reference" MFMA: A = a constant-one feature (4 registers), B = -m of the query (4 registers)
+    "P": 104,                           # packed probabilities, 8 registers (ONE buffer: a pack is held back until the P.V MFMAs that read
+                                        # its registers have issued)
+    "F": 112,                           # fragment ring: 4 x 4 registers
+    "SD": 128,                          # seed block: 16 registers holding -m, the C operand of the first MFMA of every S chain
+    "rk": 144, "rv": 148,               # LDS read addresses (4 each): slot of the K tile being read / of the V^T tile being read
+    "m": 152, "l": 153, "mx": 154, "ps": 155,   # ps: 155..158
+    "alpha": 159, "ta": 160, "tb": 161, "ninf": 162,
 }
-FIXED_LO, FIXED_HI = 40, 165
+FIXED_LO, FIXED_HI = 40, 162
 
 LOG2E = 1.44269504088896341
 def f32bits(x):
     return struct.unpack("<I", struct.pack("<f", x))[0]
 LIT_THR = f32bits(8.0)                      # lazy-maximum slack: p <= 2^8 (scores arrive in log2 units: q is pre-scaled by log2(e) / 8)
 LIT_NINF = 0xff800000
-ONE16 = {"bf16": 0x3f80, "f16": 0x3c00}
 
 
 def v(n):
@@ -157,12 +165,8 @@ VARIANTS = {
     7: {"nolds", "nodma"},             # MFMA + softmax only
     8: {"nolds", "nodma", "nosoftmax"},   # MFMA only
     9: {"nosoftmax", "nomfma"},        # data movement only
-    # schedule variants (results CORRECT): same-box A/Bs of the shipped schedule
-    10: {"spread"},                    # exps interleaved with the adds / packs instead of four in a row
-    11: {"nopvfirst"},                 # the iteration behind the tile barrier in S, PV order like the others
-    12: {"spread", "nopvfirst"},
 }
-TUNE_FLAGS = {"spread", "nopvfirst"}
+TUNE_FLAGS = set()
 
 
 class Gen:
@@ -207,35 +211,19 @@ class Gen:
     def frag_state(self):
         return (tuple(self.lds_order), tuple(sorted(self.landed)))
 
-    # ---- 16-bit helpers ------------------------------------------------------------------------------------------------------------
-    def round16(self, dst, src):
-        """dst = src rounded to the operand format's grid, as fp32 (two instructions)"""
-        p = self.p
-        p.valu(self.cvt, dst, src, imm(0))
-        if self.fmt == "bf16":
-            p.valu("v_lshlrev_b32", dst, imm(16), dst)
-        else:
-            p.valu("v_cvt_f32_f16", dst, dst)
-
-    def set_qm(self, tmp):
-        """qm[0] = the 16-bit image of -m in the k = 0 slot of the B operand (lanes h = 0 only; everything else stays zero)"""
-        p = self.p
-        p.valu(self.cvt, tmp, v(R["m"]), imm(0))                  # m is on the grid already: exact
-        p.valu("v_xor_b32", tmp, lit(0x8000), tmp)
-        p.valu("v_and_b32", v(R["qm"]), op("hmask"), tmp)
-
-    # ---- softmax of one half-tile as a list of closures (each emits ONE instruction) -------------------------------------------------
-    def softmax_ops(self, S, P, masked, init, kv_half, resume_label, slow_label):
-        """The scores arrive RELATIVE to the query's reference m and in log2 units: S' = (K . Q^T) - m comes out of the matrix pipe
-        (q is pre-scaled by log2(e) / 8 by its producer, and the S chain contains one extra MFMA whose A operand is a constant-one
-        feature and whose B operand holds -m), so the softmax is exp2 + row sum + pack and nothing else.  Only the very first
-        half-tile (init: no reference yet) subtracts explicitly."""
+    # ---- softmax of one half-tile as a list of (closure, gate) pairs (each closure emits ONE instruction) ---------------------------
+    def softmax_ops(self, S, masked, init, kv_half, resume_label, slow_label, has_pv):
+        """The scores arrive RELATIVE to the query's reference m and in log2 units: q is pre-scaled by log2(e) / 8 by its producer and the
+        first MFMA of every S chain takes the seed block (-m in all 16 registers) as its C operand, so the softmax is exp2 + row sum +
+        pack and nothing else.  Only the very first half-tile (init: no reference yet) subtracts explicitly.
+        gate: None, or the set of MFMA positions that must have ISSUED before the instruction may be emitted (the packs overwrite the
+        single P buffer the P.V MFMAs of this iteration still read)."""
         p, ops = self.p, []
         s = [v(S + r) for r in range(16)]
-        pr = [v(P + r) for r in range(8)]
+        pr = [v(R["P"] + r) for r in range(8)]
         ps = [v(R["ps"] + k) for k in range(4)]
         mx, m, l, ta, tb = (v(R[k]) for k in ("mx", "m", "l", "ta", "tb"))
-        E = lambda f: ops.append(f)
+        E = lambda f, gate=None: ops.append((f, gate))
         if masked:
             # key of register r: kv + (r & 3) + 8 (r >> 2) + 4 h ; valid iff  c_r < nvalid - 4 h - kv =: lim
             E(lambda: p.valu("v_subrev_u32", ta, op(kv_half), op("limbase")))          # lim = limbase - kv
@@ -253,64 +241,48 @@ class Gen:
         E(lambda: p.valu("v_max3_f32", mx, mx, ps[3], s[15]))
         E(lambda: p.valu("v_max_f32", mx, mx, ps[0]))
         if init:
-            # first half-tile: raw scores.  m = the query's maximum over both lane halves (key 0 is always valid, so it is finite),
-            # rounded to the operand grid (it travels through the matrix pipe from now on)
+            # first half-tile: raw scores.  m = the query's maximum over both lane halves (key 0 is always valid, so it is finite)
             E(lambda: p.valu("v_mov_b32", ta, mx))
             E(lambda: p.valu("v_mov_b32", tb, mx))
             E(lambda: p.nop(1))
             E(lambda: p.valu("v_permlane32_swap_b32", ta, tb))
             E(lambda: p.nop(1))
-            E(lambda: p.valu("v_max_f32", mx, ta, tb))
-            E(lambda: p.valu(self.cvt, m, mx, imm(0)))
-            E(lambda: (p.valu("v_lshlrev_b32", m, imm(16), m) if self.fmt == "bf16" else p.valu("v_cvt_f32_f16", m, m)))
-            E(lambda: p.valu(self.cvt, ta, m, imm(0)))
-            E(lambda: p.valu("v_xor_b32", ta, lit(0x8000), ta))
-            E(lambda: (p.valu("v_and_b32", v(R["qm"]), op("hmask"), ta), self.mark_ref_ready()))
+            E(lambda: p.valu("v_max_f32", m, ta, tb))
+            for r in range(16):
+                E(lambda r=r: p.valu("v_sub_f32", v(R["SD"] + r), imm(0), m))
             for r in range(16):
                 E(lambda r=r: p.valu("v_sub_f32", s[r], s[r], m))
+            E(lambda: self.mark_ref_ready())                     # (behind the rebase: a VALU result needs two wait states before an MFMA reads it)
         else:
             E(lambda: p.vcmp("v_cmp_lt_f32", lit(LIT_THR), mx))
             E(lambda: p.branch("s_cbranch_vccnz", slow_label))
             E(lambda: (p.label(resume_label), self.mark_ref_ready()))
         # p = exp2(s'), in place; row sum in four partial sums; packed pairs in register order
+        g0 = {1, 3} if has_pv else None          # P[0..3] is the B operand of the P.V MFMAs at positions 1 and 3, P[4..7] of 5 and 7
+        g1 = {5, 7} if has_pv else None
         ex = lambda r: E(lambda r=r: p.valu("v_exp_f32", s[r], s[r], trans=True))
         add0 = lambda k: E(lambda k=k: p.valu("v_add_f32", ps[k], s[k], s[4 + k]))
         addn = lambda k, b: E(lambda k=k, b=b: p.valu("v_add_f32", ps[k], ps[k], s[b + k]))
-        cv = lambda i: E(lambda i=i: p.valu(self.cvt, pr[i], s[2 * i], s[2 * i + 1]))
-        if "spread" in self.knock:
-            for r in range(8):
-                ex(r)
-            for k in range(4):
-                ex(8 + k); add0(k)
-            for k in range(4):
-                ex(12 + k); cv(k)
-            for k in range(4):
-                addn(k, 8)
-            cv(4); cv(5)
-            for k in range(4):
-                addn(k, 12)
-            cv(6); cv(7)
-        else:
-            for r in range(8):
-                ex(r)
-            for k in range(4):
-                add0(k)
-            cv(0); cv(1)
-            for r in range(8, 12):
-                ex(r)
-            cv(2); cv(3)
-            for r in range(12, 16):
-                ex(r)
-            for k in range(4):
-                addn(k, 8)
-            cv(4); cv(5)
-            for k in range(4):
-                addn(k, 12)
-            cv(6); cv(7)
+        cv = lambda i: E(lambda i=i: p.valu(self.cvt, pr[i], s[2 * i], s[2 * i + 1]), g0 if i < 4 else g1)
+        for r in range(8):
+            ex(r)
+        for k in range(4):
+            add0(k)
+        for r in range(8, 12):
+            ex(r)
+        cv(0); cv(1)
+        for r in range(12, 16):
+            ex(r)
+        cv(2); cv(3)
+        for k in range(4):
+            addn(k, 8)
+        for k in range(4):
+            addn(k, 12)
         E(lambda: p.valu("v_add_f32", ps[0], ps[0], ps[1]))
         E(lambda: p.valu("v_add_f32", ps[2], ps[2], ps[3]))
         E(lambda: p.valu("v_add_f32", ps[0], ps[0], ps[2]))
         E(lambda: p.valu("v_add_f32", l, l, ps[0]))
+        cv(4); cv(5); cv(6); cv(7)
         return ops
 
     def mark_ref_ready(self):
@@ -318,9 +290,9 @@ class Gen:
 
     def slow_path(self, slow_label, resume_label, S):
         """some lane's relative maximum left the lazy window (> 8): new reference per QUERY (both lane halves decide alike),
-        m' = grid(m + max), the CURRENT scores are rebased by delta = m' - m (exact: both on the grid), alpha = exp2(-delta) (= 1
-        exactly where the query keeps its reference); l is rescaled here, O at the end of the iteration; the reference MFMA of the
-        half-tile in flight (issued later in this iteration) picks up the new -m"""
+        m' = m + max, the CURRENT scores are rebased by delta = m' - m, alpha = exp2(-delta) (= 1 exactly where the query keeps its
+        reference); l is rescaled here, O at the end of the iteration; the seed block is rewritten, so the S chain in flight (whose
+        first MFMA is issued only behind this point of the iteration) is relative to the new reference"""
         p = self.p
         mx, m, l, ta, tb, al = (v(R[k]) for k in ("mx", "m", "l", "ta", "tb", "alpha"))
         p.label(slow_label)
@@ -331,12 +303,12 @@ class Gen:
         p.nop(1)
         p.valu("v_max_f32", mx, ta, tb)
         p.valu("v_add_f32", ta, mx, m)
-        self.round16(ta, ta)
         p.vcmp("v_cmp_lt_f32", lit(LIT_THR), mx)
-        p.valu("v_cndmask_b32", ta, m, ta)                       # m' = need ? grid(m + max) : m
-        p.valu("v_sub_f32", tb, ta, m)                           # delta >= 0
+        p.valu("v_cndmask_b32", ta, m, ta)                       # m' = need ? m + max : m
+        p.valu("v_sub_f32", tb, ta, m)                           # delta >= 0 (exactly 0 where the reference stays)
         p.valu("v_mov_b32", m, ta)
-        self.set_qm(al)
+        for r in range(16):
+            p.valu("v_sub_f32", v(R["SD"] + r), imm(0), m)
         for r in range(16):
             p.valu("v_sub_f32", v(S + r), v(S + r), tb)
         p.valu("v_sub_f32", al, imm(0), tb)
@@ -362,82 +334,97 @@ class Gen:
     # ---- one iteration ------------------------------------------------------------------------------------------------------------
     def iteration(self, name, parity, s_half, pv_half, masked=False, init=False, pv_first=False, nxt=None, kv_half=None,
                   barrier_dma=False, addr_update=None):
-        """parity: 0 = even half-tile (softmax SA -> PA, S MFMAs -> SB, P.V reads PB), 1 = odd.
+        """parity: 0 = even half-tile (softmax on SA, S MFMAs -> SB), 1 = odd.  P has ONE buffer.
         s_half: None or the K half (0 / 1) of S(i+1) read through rk; pv_half: None or the V half of P.V(i-1) read through rv.
         nxt: (s_half, pv_half, k_after_barrier) of the NEXT iteration, for the prefetch of its first four fragments (None: no S / PV).
         barrier_dma: this iteration opens a new tile: wait for the own pieces of tile t+1, barrier, request tile t+2, THEN read K.
-        addr_update: "full" (rv <- rk, rk <- slot of the next tile) / "rv" (rv <- rk only) / None, placed behind MFMA 3."""
+        addr_update: "full" (rv <- rk, rk <- slot of the next tile) / "rv" (rv <- rk only) / None.
+        MFMA positions: even n = S chain link n / 2 (K fragment ks = n / 2), odd n = P.V (j = n / 4, ds = (n / 2) % 2); position n uses ring
+        slot n % 4.  ISSUE order: P.V, P.V, S, P.V, S, P.V, S, S -- the S chain starts behind this iteration's lazy-maximum decision (its
+        first link reads the seed block), and behind a tile barrier the P.V fragments are the ones already in registers."""
         p = self.p
         p.comment("==== %s" % name)
-        Ssm, Pw = (R["SA"], R["PA"]) if parity == 0 else (R["SB"], R["PB"])
-        Smm, Prd = (R["SB"], R["PB"]) if parity == 0 else (R["SA"], R["PA"])
+        Ssm = R["SA"] if parity == 0 else R["SB"]
+        Smm = R["SB"] if parity == 0 else R["SA"]
         resume, slow = self.new_label("resume"), self.new_label("slow")
-        fill = self.softmax_ops(Ssm, Pw, masked, init, kv_half, resume, slow)
-        # MFMA list: position n uses ring slot n % 4
+        has_s, has_pv = s_half is not None, pv_half is not None
+        fill = self.softmax_ops(Ssm, masked, init, kv_half, resume, slow, has_pv)
         mf = []
         for n in range(8):
             if n % 2 == 0:
-                ks = n // 2
-                mf.append(("S", ks) if s_half is not None else None)
+                mf.append(("S", n // 2) if has_s else None)
             else:
-                j, ds = (n // 2) // 2, (n // 2) % 2
-                mf.append(("PV", j, ds) if pv_half is not None else None)
+                mf.append(("PV", (n // 2) // 2, (n // 2) % 2) if has_pv else None)
         if barrier_dma:
-            # the K fragments of MFMA 0 and 2 could not be requested before the barrier (they are read from tile t+1)
+            # the K fragments of positions 0 and 2 could not be requested before the barrier (they are read from tile t+1)
             p.waitcnt(vm=0, lgkm=0)
             self.drain()
             p.barrier()
             self.dma_block()
             self.read(0, R["rk"] + 0, s_half * 4096)
             self.read(2, R["rk"] + 1, s_half * 4096)
-            # in-order return: the V fragments (slots 1, 3), requested earlier, were drained by the lgkmcnt(0) above
-        nf = len(fill)
-        live = [m for m in mf if m is not None]
-        gaps = len(live)
+        order = [n for n in (1, 3, 0, 5, 2, 7, 4, 6) if mf[n] is not None]
+        nf, gaps = len(fill), len(order)
         done_f = 0
-        gi = 0
+        issued = set()
         self.ref_ready = False
-        order = list(range(8))
-        if barrier_dma and "nopvfirst" not in self.knock:
-            # behind the tile barrier the P.V fragments are already in registers, the K fragments were requested a moment ago:
-            # P.V first (same-box A/B: -1.5 %)
-            assert not addr_update
-            order = [1, 0, 3, 2, 4, 5, 6, 7]
-        for n in order:
+        state = {"rv_moved": False, "rk_moved": False}
+
+        def emit_fillers(want, force_ref=False):
+            nonlocal done_f
+            while done_f < nf and (done_f < want or (force_ref and not self.ref_ready)):
+                f, gate = fill[done_f]
+                if gate is not None and not gate <= issued:
+                    assert not force_ref, "a gated pack in front of the lazy-maximum decision"
+                    break
+                f()
+                done_f += 1
+
+        def addr_steps():
+            # rv <- rk once every read of this iteration through rv (V of tile t-1: the refills behind positions 1 and 3) has been issued
+            # -- from then on "through rv" means V of tile t; rk <- slot of the next tile once rv has its copy and every read through
+            # rk (K of tile t: the refills behind positions 0 and 2) has been issued
+            if not addr_update:
+                return
+            if not state["rv_moved"] and {n for n in (1, 3) if mf[n] is not None} <= issued:
+                for k in range(4):
+                    p.valu("v_mov_b32", v(R["rv"] + k), v(R["rk"] + k))
+                state["rv_moved"] = True
+            if addr_update == "full" and state["rv_moved"] and not state["rk_moved"] and {n for n in (0, 2) if mf[n] is not None} <= issued:
+                for k in range(4):
+                    p.valu("v_add_u32", v(R["rk"] + k), op("snext"), op("off%d" % k))
+                p.salu("s_add_u32", op("snext"), op("snext"), imm(SLOT))
+                p.scmp("s_cmp_eq_u32", op("snext"), imm(NSLOT * SLOT))
+                p.salu("s_cselect_b32", op("snext"), imm(0), op("snext"))
+                state["rk_moved"] = True
+
+        for gi, n in enumerate(order):
             m = mf[n]
             slot = n % 4
-            if n == 6 and s_half is not None:
-                # the reference MFMA of the S chain: S(i+1) -= m.  Behind the point where this iteration may have moved m
-                assert self.ref_ready, "the reference MFMA must follow the lazy-maximum decision of this iteration"
-                p.mfma(vr(Smm, 16), vr(R["kc"], 4), vr(R["qm"], 4), vr(Smm, 16))
-            if m is not None:
-                self.wait_frag(slot)
-                if m[0] == "S":
-                    ks = m[1]
-                    p.mfma(vr(Smm, 16), self.F(slot), opr("q%d" % ks, 4), imm(0) if ks == 0 else vr(Smm, 16))
-                else:
-                    _, j, ds = m
-                    O = R["O0"] if ds == 0 else R["O1"]
-                    p.mfma(vr(O, 16), self.F(slot), vr(Prd + 4 * j, 4), imm(0) if (pv_first and j == 0) else vr(O, 16))
-            # the read that refills this ring slot for the second half of THIS iteration
+            if m[0] == "S" and not self.ref_ready:
+                emit_fillers(0, force_ref=True)                  # the S chain's first link reads the seed block: decision first
+            self.wait_frag(slot)
+            if m[0] == "S":
+                ks = m[1]
+                assert self.ref_ready
+                p.mfma(vr(Smm, 16), self.F(slot), opr("q%d" % ks, 4), vr(R["SD"], 16) if ks == 0 else vr(Smm, 16))
+            else:
+                _, j, ds = m
+                O = R["O0"] if ds == 0 else R["O1"]
+                p.mfma(vr(O, 16), self.F(slot), vr(R["P"] + 4 * j, 4), imm(0) if (pv_first and j == 0) else vr(O, 16))
+            issued.add(n)
+            # the read that refills this ring slot: positions 0-3 fetch the fragment of position n + 4 of THIS iteration, 4-7 the
+            # fragment of position n - 4 of the NEXT one
             if n < 4:
                 m4 = mf[n + 4]
                 if m4 is not None:
                     if m4[0] == "S":
+                        assert not state["rk_moved"]
                         self.read(slot, R["rk"] + m4[1], s_half * 4096)
                     else:
+                        assert not state["rv_moved"]
                         self.read(slot, R["rv"] + 2 * pv_half + m4[1], VT + m4[2] * 4096)
-            if n == 3 and addr_update:
-                # every read of this iteration through rv (V of tile t-1) and rk (K of tile t) has been issued
-                for k in range(4):
-                    p.valu("v_mov_b32", v(R["rv"] + k), v(R["rk"] + k))
-                if addr_update == "full":
-                    for k in range(4):
-                        p.valu("v_add_u32", v(R["rk"] + k), op("snext"), op("off%d" % k))
-                    p.salu("s_add_u32", op("snext"), op("snext"), imm(SLOT))
-                    p.scmp("s_cmp_eq_u32", op("snext"), imm(NSLOT * SLOT))
-                    p.salu("s_cselect_b32", op("snext"), imm(0), op("snext"))
-            # the first four fragments of the NEXT iteration
+            addr_steps()
             if n >= 4 and nxt is not None:
                 ns, npv, k_late = nxt
                 pos = n - 4
@@ -445,21 +432,27 @@ class Gen:
                     self.read(slot, R["rk"] + pos // 2, ns * 4096)
                 if pos % 2 == 1 and npv is not None:
                     j, ds = (pos // 2) // 2, (pos // 2) % 2
+                    assert state["rv_moved"] or not addr_update, "the next iteration's V fragments are read through the moved rv"
                     self.read(slot, R["rv"] + 2 * npv + j, VT + ds * 4096)
-            # this gap's share of the softmax
-            if m is not None:
-                gi += 1
-                want = (nf * gi + gaps - 1) // gaps if gi < gaps else nf
-                while done_f < want:
-                    fill[done_f]()
-                    done_f += 1
-        if gaps == 0:
-            for f in fill:
-                f()
-        elif done_f < nf:
-            for f in fill[done_f:]:
-                f()
-        if pv_half is not None and not init:
+            emit_fillers((nf * (gi + 1) + gaps - 1) // gaps if gi + 1 < gaps else nf)
+        # positions that do not exist in this iteration still have successors to prefetch (first tile: no P.V, last odd: no S)
+        for n in (5, 7, 4, 6):
+            if mf[n] is None and nxt is not None:
+                ns, npv, k_late = nxt
+                pos, slot = n - 4, n % 4
+                issued.add(n - 4); issued.add(n)
+                addr_steps()
+                if pos % 2 == 0 and ns is not None and not k_late:
+                    self.read(slot, R["rk"] + pos // 2, ns * 4096)
+                if pos % 2 == 1 and npv is not None:
+                    j, ds = (pos // 2) // 2, (pos // 2) % 2
+                    self.read(slot, R["rv"] + 2 * npv + j, VT + ds * 4096)
+        issued |= set(range(8))
+        addr_steps()
+        emit_fillers(nf)
+        assert done_f == nf
+        assert not addr_update or (state["rv_moved"] and (addr_update != "full" or state["rk_moved"]))
+        if has_pv and not init:
             self.rescale_block()
         self.pending_slow = getattr(self, "pending_slow", [])
         if not init:
@@ -504,10 +497,6 @@ class Gen:
         p.salu("s_add_u32", "m0", op("ldsw"), imm(0))
         p.valu("v_mov_b32", v(R["l"]), imm(0))
         p.valu("v_mov_b32", v(R["ninf"]), lit(LIT_NINF))
-        p.valu("v_and_b32", v(R["kc"]), lit(ONE16[self.fmt]), op("hmask"))     # A operand of the reference MFMA: feature k = 0 is 1.0, for every key
-        for k in range(1, 4):
-            p.valu("v_mov_b32", v(R["kc"] + k), imm(0))
-            p.valu("v_mov_b32", v(R["qm"] + k), imm(0))
         p.dma(op("kvoff0"), opr("rsk", 4), op("koff"))
         p.salu("s_add_u32", "m0", "m0", imm(1024))
         for k in range(4):
@@ -607,10 +596,10 @@ class Gen:
         return out
 
     def final_pv(self, parity):
-        """P.V of the last half-tile (P in PB: the last iteration is odd); its first two fragments were prefetched into ring slots 1, 3"""
+        """P.V of the last half-tile; its first two fragments were prefetched into ring slots 1, 3"""
         p = self.p
         p.comment("==== final P.V(n-1)")
-        Prd = R["PB"]
+        Prd = R["P"]
         # j = 1 fragments
         self.wait_frag(1)
         p.mfma(vr(R["O0"], 16), self.F(1), vr(Prd, 4), vr(R["O0"], 16))
@@ -772,13 +761,13 @@ def check_hazards(ins):
     return True
 
 
-OPERANDS_OUT = ['[o0] "=&{v[40:55]}"(o0)', '[o1] "=&{v[56:71]}"(o1)', '[lsum] "=&{v147}"(lsum)',
+OPERANDS_OUT = ['[o0] "=&{v[40:55]}"(o0)', '[o1] "=&{v[56:71]}"(o1)', '[lsum] "=&{v%d}"(lsum)' % R["l"],
                 '[koff] "=&s"(koff)', '[voff] "=&s"(voff)', '[resc] "=&s"(resc)', '[snext] "=&s"(snext)', '[dslot] "=&s"(dslot)',
                 '[tdma] "=&s"(tdma)', '[tleft] "=&s"(tleft)']
 OPERANDS_IN = ['[q0] "v"(qf[0])', '[q1] "v"(qf[1])', '[q2] "v"(qf[2])', '[q3] "v"(qf[3])',
                '[off0] "v"(off[0])', '[off1] "v"(off[1])', '[off2] "v"(off[2])', '[off3] "v"(off[3])',
                '[kvoff0] "v"(kvoff[0])', '[kvoff1] "v"(kvoff[1])', '[vvoff0] "v"(vvoff[0])', '[vvoff1] "v"(vvoff[1])',
-               '[limbase] "v"(limbase)', '[hmask] "v"(hmask)', '[rsk] "s"(rsk)', '[rsv] "s"(rsv)', '[ldsw] "s"(ldsw)', '[nt] "s"(nt)',
+               '[limbase] "v"(limbase)', '[rsk] "s"(rsk)', '[rsv] "s"(rsv)', '[ldsw] "s"(ldsw)', '[nt] "s"(nt)',
                '[kvl0] "s"(kvl0)', '[kvl1] "s"(kvl1)']
 
 
@@ -788,7 +777,7 @@ def emit(fmt, var=0):
     if not (g.knock - TUNE_FLAGS):
         check_hazards(prog.ins)
     lines = to_asm(prog.ins)
-    clob = ", ".join('"v%d"' % r for r in range(FIXED_LO, FIXED_HI + 1) if not (40 <= r <= 71 or r == 147))
+    clob = ", ".join('"v%d"' % r for r in range(FIXED_LO, FIXED_HI + 1) if not (40 <= r <= 71 or r == R["l"]))
     os.makedirs(OUTDIR, exist_ok=True)
     dst = os.path.join(OUTDIR, "attn_asm_%s%s.inc" % (fmt, "_v%d" % var if var else ""))
     with open(dst, "w") as f:
