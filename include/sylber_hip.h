@@ -172,7 +172,8 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *   SYLBER_OPT_GEMM_PERSISTENT         0 (automatic): GEMM launches of more than one round run as persistent workgroups
  *                                      walking the tile list (4-wave kernels: two per CU; the 256x256 kernel: one per CU
  *                                      with cross-tile operand prefetch); k > 0: k workgroups per CU for the 4-wave
- *                                      kernels; k < 0: one workgroup per tile everywhere (A/B switch)
+ *                                      kernels; k < 0: one workgroup per tile everywhere (A/B switch); 100: the asm tiles walk 8-row x 4-column
+ *                                      panels per XCD instead of row-major (A/B, measured slower: DESIGN.md §6)
  *   SYLBER_OPT_FUSE_OUTPROJ_LN         1: the attention out-projection and the LayerNorm behind it run as ONE launch on
  *                                      full-row tiles (csrc/gemm_rowln.hip; bit-identical outputs) where the shape allows;
  *                                      0 / -1 (default): GEMM launch + LayerNorm launch (faster with two batches in flight)
