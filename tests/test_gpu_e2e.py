@@ -71,7 +71,8 @@ def test_sample_wav_golden(S, golden_dir, tmp_path):
     assert _boundary_recall(out["segments"], g["sample_segments"]) >= BOUNDARY_FLOOR["bf16"]
 
 
-BOUNDARY_FLOOR = {"bf16": 0.90, "fp16": 0.95, "split": 1.0}
+# measured (profiles/r05_sample_wav_agreement.md): bf16 78 / 81, fp16 81 / 81; floors = measured minus one flipped boundary PAIR
+BOUNDARY_FLOOR = {"bf16": 0.93, "fp16": 0.975, "split": 1.0}
 
 
 def _boundary_recall(got, ref):
