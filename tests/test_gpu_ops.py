@@ -64,7 +64,7 @@ Q_SCALE = 0.125 * LOG2E
 
 @pytest.mark.parametrize("qw", [0, 1, 2])       # 0: the default (hand-scheduled key loop), 1 / 2: the compiler-scheduled kernels (32 / 64 queries per wave)
 @pytest.mark.parametrize("B,T,valid", [(2, 64, None), (3, 143, [143, 100, 1]), (2, 499, [499, 300]), (1, 700, None),
-                                       (6, 499, None), (2, 1, None), (2, 33, [33, 32]), (3, 130, [130, 65, 64]), (1, 2999, None)])
+                                       (6, 499, None), (2, 1, None), (2, 33, [33, 32]), (3, 130, [130, 65, 64]), (1, 2999, None), (1, 6000, [4097]), (2, 193, [193, 129])])
 def test_attention(lib, B, T, valid, qw):
     from sylber_amd import _lib
     g = torch.Generator().manual_seed(B * 1000 + T)
