@@ -199,6 +199,19 @@ def cpu_baseline(sd, seconds_budget=25.0):
                       % (iters, B, cores, os.cpu_count() or 1)}
 
 
+def attention_roofline(kernels: dict, B: int, T: int, precision: str, layers: int = 9):
+    """the attention core's own line: algorithmic FLOPs 4 B 12 T^2 64 per layer (0.765 GFLOP per 10 s clip and layer) over the
+    summed duration of its launches; MXFP8 operands (precision="fp8") answer to the fp8 peak"""
+    ms = kernels.get("attention", 0.0)
+    if ms <= 0:
+        return None
+    fl = layers * 4.0 * B * 12 * T * T * 64
+    peak = MFMA_FP8_PEAK_TFLOPS if precision == "fp8" else MFMA_BF16_PEAK_TFLOPS
+    tf = fl / (ms * 1e-3) / 1e12
+    return {"bound": "mfma (issue / power limited: profiles/r05_attention.md)", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(tf / peak, 4), "ms_per_forward": round(ms, 4), "launches_per_forward": layers}
+
+
 def roofline_by_peak(kernels: dict, B: int, clip_samples: int, precision: str) -> dict:
     """Per-dtype MFMA roofline of one forward: every GEMM launch is scored against the dense peak of the operand type it
     ACTUALLY runs on -- precision="fp8" runs q,k,v / out-proj / FFN1 / FFN2 on v_mfma_scale_f32_32x32x64_f8f6f4 (5 PF) and the
@@ -276,7 +289,7 @@ def measure_other_config(torch, dev, sd, streams4, precision: str, B: int, clip_
     enc.set_profiling(False)
     out = {"value": round(B * clip_seconds * steps / dt, 1), "unit": "audio-sec/s", "ms_per_step": round(1e3 * dt / steps, 3),
            "steps": steps, "warmup": warmup, "precision": precision, "batch": B, "clip_seconds": clip_seconds, "frames_per_clip": T_frames,
-           "roofline": roofline_by_peak(kernels, B, clip_samples, precision),
+           "roofline": dict(roofline_by_peak(kernels, B, clip_samples, precision), attention=attention_roofline(kernels, B, T_frames, precision)),
            "kernel_ms_per_forward": {k: kernels[k] for k in ("attention", "conv0_gn_gelu", "posconv", "layernorm", "segment") if k in kernels},
            "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2)}
     del encs, enc, bufs, batch
@@ -736,6 +749,7 @@ def main():
                     "avg_launch_ms": round(gemm_ms / max(n_launch, 1), 4), "flops_per_forward": gemm_fl,
                     "per_launch_tflops": {k: round(fl[k] / (ms_of[k] * 1e-3) / 1e12, 1) for k in fl if ms_of[k] > 0}}
         roofline["by_operand_type"] = roofline_by_peak(kernels, B, clip_samples, args.precision)
+        roofline["attention"] = attention_roofline(kernels, B, T_frames, args.precision)
         if args.precision == "fp8":
             roofline["peak_note"] = ("`frac` of this block divides the whole GEMM family by the 16-bit peak (2.5 PF); the MXFP8 launches are "
                                      "scored against the fp8 peak (5 PF) in by_operand_type.encoder_gemms")

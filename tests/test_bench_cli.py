@@ -61,3 +61,12 @@ def test_roofline_by_peak_scores_fp8_launches_against_the_fp8_peak():
     assert r16["encoder_gemms"]["peak"] == 2500.0 and abs(r16["encoder_gemms"]["frac"] - 0.4) < 1e-3
     rs = bench.roofline_by_peak(kernels, 32, bench.CLIP_SAMPLES, "split16")
     assert abs(rs["encoder_gemms"]["issued_frac"] - 1.2) < 1e-3        # three MFMA passes per algorithmic contraction
+
+
+def test_attention_roofline_accounting():
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.attention_roofline({"attention": 0.333}, 32, 499, "bf16")
+    assert abs(r["achieved"] - 9 * 4.0 * 32 * 12 * 499 * 499 * 64 / 0.333e-3 / 1e12) < 0.1 and r["peak"] == 2500.0
+    assert bench.attention_roofline({"attention": 0.38}, 32, 499, "fp8")["peak"] == 5000.0
+    assert bench.attention_roofline({}, 32, 499, "bf16") is None
