@@ -97,8 +97,12 @@ int sylber_forward(sylber_t h, const float* wav_dev, const int32_t* lengths_host
  * pageable copy, no host synchronisation).  A handle is single-stream: it owns ONE workspace, so two forwards of the
  * same handle must be ordered on the same stream; use one handle per in-flight batch to overlap batches. */
 
-/* (2)+(3) boundary detection + segment mean-pool, one workgroup per utterance, bit-exact w.r.t. the
- * reference's numpy float32 evaluation order.
+/* (2)+(3) boundary detection + segment mean-pool, bit-exact w.r.t. the reference's numpy float32 evaluation order.
+ * Round 6: frame norms, one workgroup per unbroken run of speech frames (independent instances of get_segment's two phases: a
+ * non-speech frame resets the scan, segment_utils.py:84-90), compaction and pooling as four launches that use the whole chip
+ * (SYLBER_OPT_SEGMENT = -1: the one-workgroup-per-utterance kernel of rounds 1-5).  Touches no encoder workspace, so it may run on a
+ * side stream under the same handle's next sylber_forward; it does use a per-handle scratch slab (frame norms, slot table): the
+ * sylber_segment calls of ONE handle must be ordered on one stream.
  *   hidden_dev [B, T, D] fp32 (D = 768 on the product path)
  *   seg_dev    [B, T, 2] int64  (start, end-exclusive) frame indices, first nseg_dev[b] rows valid
  *   nseg_dev   [B] int32
@@ -164,7 +168,7 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      0 = 256x128, 3 = 128x128, 4 = 128x192, 10 = 256x256 8-wave, 11 = 256x192 8-wave;
  *                                      hand-scheduled K loops (csrc/gemm_asm.hip; a launch whose epilogue / K has no such
  *                                      instantiation falls back to 128x192): 80 = 256x256 4-wave, 90 = 256x192, 95 = 256x256
- *                                      8-wave, 85 / 91 / 97 = the same with a three-slot X ring, 86 = that ring on a 256x128 tile / four waves (91 also requests the fp32 residual rows of out-proj / FFN2 from
+ *                                      8-wave, 85 / 91 / 97 = the same with a three-slot X ring, 51 / 57 = 91 / 97 on 192-row tiles, 86 = that ring on a 256x128 tile / four waves (91 also requests the fp32 residual rows of out-proj / FFN2 from
  *                                      inside its K loop when the launch has whole tiles; 96 = 91 without that), 60 = the 64-byte-row first cut)
  *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   0 (default): the hand-scheduled key loop (csrc/attention.hip attention_asm_kernel, generated by
  *                                      tools/gen_attn_asm.py; bf16 / fp16 modes); 32 or 64: the compiler-scheduled kernels with that many
@@ -172,8 +176,7 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *   SYLBER_OPT_GEMM_PERSISTENT         0 (automatic): GEMM launches of more than one round run as persistent workgroups
  *                                      walking the tile list (4-wave kernels: two per CU; the 256x256 kernel: one per CU
  *                                      with cross-tile operand prefetch); k > 0: k workgroups per CU for the 4-wave
- *                                      kernels; k < 0: one workgroup per tile everywhere (A/B switch); 100: the asm tiles walk 8-row x 4-column
- *                                      panels per XCD instead of row-major (A/B, measured slower: DESIGN.md §6)
+ *                                      kernels; k < 0: one workgroup per tile everywhere (A/B switch)
  *   SYLBER_OPT_FUSE_OUTPROJ_LN         1: the attention out-projection and the LayerNorm behind it run as ONE launch on
  *                                      full-row tiles (csrc/gemm_rowln.hip; bit-identical outputs) where the shape allows;
  *                                      0 / -1 (default): GEMM launch + LayerNorm launch (faster with two batches in flight)
@@ -185,10 +188,29 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *   SYLBER_OPT_FP8_ATTENTION           SYLBER_FP8 only: 1 (and 0 = the default) = the attention core on MXFP8 operands too -- the q / k / v projection
  *                                      quantises its outputs (e4m3, one power-of-two scale per 32 features of q / k and per 32 keys of v),
  *                                      P is e4m3: BASELINE configs[4] as worded, whatever the batch shape (round 5: the q / k / v launch pads its rows
- *                                      up to whole 256-row tiles and does not store the padding); -1 = always the bf16 core (q, k, v, P in bf16) */
+ *                                      up to whole 256-row tiles and does not store the padding); -1 = always the bf16 core (q, k, v, P in bf16)
+ *   SYLBER_OPT_GEMM_TAIL               k > 0: a GEMM launch whose tile count is not a whole number of rounds of 256 persistent workgroups is split BY ROWS --
+ *                                      the rows of the full rounds on the chosen tile, the remaining rows as a second launch on tile id k (bit-identical
+ *                                      outputs: every element is one fp32 chain over K whatever tile computes it).  0 / -1 (default): one launch.  Measured
+ *                                      not to pay (a small tile alone on a CU is no faster than a big one; csrc/gemm_bf16.hip launch_f): the partial
+ *                                      rounds are handled by the 192-row tiles below; this stays as a test vehicle
+ *   SYLBER_OPT_GEMM_H192               0 (default): the cost model may pick the 192-row siblings of the hand-scheduled tiles (ids 51 = 192x192, 57 = 192x256:
+ *                                      a second tile HEIGHT, for launches whose 256-row tile count leaves a partial last round); -1: 256-row tiles only (A/B)
+ *   SYLBER_OPT_SEGMENT                 0 (default): sylber_segment as wide kernels -- frame norms, one workgroup per unbroken run of speech frames
+ *                                      (independent instances of get_segment's two phases), compaction, pooling one wave per segment, all on all
+ *                                      CUs; -1: one workgroup per utterance (rounds 1-5; bit-identical, A/B switch and reference)
+ *   SYLBER_OPT_FP16_AUDIT              1: (re)start the fp16 headroom audit -- from now on every forward of a SYLBER_FP16 / SYLBER_MIXED16 handle scans each
+ *                                      16-bit activation buffer right behind its producer and accumulates, per stage, the number of values AT the
+ *                                      format's saturation value (+-65504: the fp16 modes clamp on conversion, they never produce infinities) and the
+ *                                      largest magnitude seen; read with sylber_get_fp16_audit.  0 (default): off, nothing is launched. */
 enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3, SYLBER_OPT_FUSE_OUTPROJ_LN = 4,
-       SYLBER_OPT_CONV0_VALU = 5, SYLBER_OPT_RESLN_PREFETCH = 6, SYLBER_OPT_FP8_ATTENTION = 7 };
+       SYLBER_OPT_CONV0_VALU = 5, SYLBER_OPT_RESLN_PREFETCH = 6, SYLBER_OPT_FP8_ATTENTION = 7, SYLBER_OPT_GEMM_TAIL = 8, SYLBER_OPT_SEGMENT = 9, SYLBER_OPT_FP16_AUDIT = 10, SYLBER_OPT_GEMM_H192 = 11 };
 int sylber_set_option(sylber_t h, int32_t key, int32_t value);
+/* the audit's counters since SYLBER_OPT_FP16_AUDIT was last set (synchronises the device): names[i] (static strings: conv0 .. conv6, ln512,
+ * proj_xpad, layernorm, q, k, v, context, ffn1), saturated[i] values clamped at +-65504, max_abs[i] largest magnitude; returns the number of
+ * stages written (<= cap), 0 when the audit never ran, -1 on error.  A non-zero `saturated` means this checkpoint / input does not fit
+ * IEEE half at that stage: use SYLBER_BF16 (8 exponent bits) or SYLBER_SPLIT16. */
+int sylber_get_fp16_audit(sylber_t h, const char** names, uint32_t* saturated, float* max_abs, int32_t cap);
 
 /* the `features is not None` branch of resynthesize (segment_synthesis.py:135-140): features_dev [rows, input_dim] frame
  * features supplied by the caller (e.g. decoded unit embeddings) -> cond_dev [rows, output_dim] = MLP(features), rows with

@@ -7,9 +7,10 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SYLBER_HIP_LIB: development override (same-box A/B of two builds of the library, tools/ab_lib.sh); the product loads the in-tree build
-# SYLBER_EXPERIMENTS=1 (tools/ only): the timing-kernel build, which build.py writes to its own file
-LIB_PATH = os.environ.get("SYLBER_HIP_LIB") or os.path.join(_HERE, "libsylber_hip_exp.so" if os.environ.get("SYLBER_EXPERIMENTS") else "libsylber_hip.so")
+# The product loads the in-tree build and nothing else: no environment variable swaps the library (round 6; development A/Bs of
+# two builds go through tools/with_lib.py, which calls use_library() before anything is loaded)
+LIB_PATH = os.path.join(_HERE, "libsylber_hip.so")
+_DEV_LIB = False        # set by use_library(): an older A/B build may lack the newest entry points
 MAX_LAYERS = 12
 
 c_float_p = POINTER(c_float)
@@ -53,6 +54,7 @@ EXPORTS = {
     "sylber_set_graph_mode": (c_int, [c_void_p, c_int32]),
     "sylber_get_profile": (c_int, [c_void_p, POINTER(c_char_p), POINTER(c_float), c_int32]),
     "sylber_workspace_bytes": (c_int64, [c_void_p]),
+    "sylber_get_fp16_audit": (c_int, [c_void_p, POINTER(c_char_p), POINTER(ctypes.c_uint32), POINTER(c_float), c_int32]),
     "sylber_op_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  c_int32, c_void_p]),
     "sylber_op_linear16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -102,13 +104,22 @@ def load() -> ctypes.CDLL:
                 "or `python sylber_amd/build.py`; there is no CPU fallback on the product path." % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in list(EXPORTS.items()) + list(DEV_EXPORTS.items()):
-            if os.environ.get("SYLBER_HIP_LIB") and not hasattr(lib, name):
-                continue                 # an OLDER build loaded for a same-box A/B (tools/ab_*.sh) may lack the newest entry points
+            if _DEV_LIB and not hasattr(lib, name):
+                continue                 # an OLDER build loaded for a same-box A/B (tools/with_lib.py) may lack the newest entry points
             fn = getattr(lib, name)      # AttributeError if the ABI drifted from include/sylber_hip.h
             fn.restype = res
             fn.argtypes = args
         _LIB = lib
     return _LIB
+
+
+def use_library(path: str) -> None:
+    """development only (tools/with_lib.py): load another build of the library (a reference build for a same-box A/B, or the
+    experiments build with its timing kernels).  Must be called before the first load()."""
+    global LIB_PATH, _DEV_LIB
+    if _LIB is not None:
+        raise SylberHipError("use_library() after the library was loaded")
+    LIB_PATH, _DEV_LIB = os.path.abspath(path), True
 
 
 def check(status: int, what: str) -> None:

@@ -22,6 +22,8 @@ VARIANT = os.environ.get("SYLBER_BUILD_VARIANT", "")
 EXTRA_CFLAGS = os.environ.get("SYLBER_EXTRA_CFLAGS", "").split() if VARIANT else []
 LIB = os.path.join(HERE, "libsylber_hip_%s.so" % VARIANT if VARIANT else ("libsylber_hip_exp.so" if EXPERIMENTS else "libsylber_hip.so"))
 GEN_DIR = os.path.join(HERE, "build", "gen")           # generated inline-asm loops (never committed: tools/gen_gemm_asm.py writes them here)
+GEN_EXP_DIR = os.path.join(HERE, "build", "gen_exp")   # the knock-out / timing variants of the experiments build: their own directory, so that
+                                                       # they neither ship with the product snapshot nor age the product's objects
 GENERATORS = [os.path.join(os.path.dirname(HERE), "tools", g) for g in ("gen_gemm_asm.py", "gen_attn_asm.py")]
 SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip", "gemm_rowln.hip", "gemm_asm.hip", "gemm_asm_f8.hip"]
 EXTRA = {"segment.hip": ["-ffp-contract=off"]}
@@ -45,6 +47,8 @@ def _newest_source() -> float:
         for f in os.listdir(root):
             t = max(t, os.path.getmtime(os.path.join(root, f)))
     for g in GENERATORS:
+        if not os.path.exists(g):
+            raise FileNotFoundError("%s is missing: the inline-asm K loops are generated at build time (tools/ must ship with the package)" % g)
         t = max(t, os.path.getmtime(g))
     return max(t, os.path.getmtime(os.path.abspath(__file__)))
 
@@ -56,7 +60,9 @@ def generate(what=("product",), outdir: str = GEN_DIR) -> None:
     with tempfile.TemporaryDirectory() as tmp:
         for g in GENERATORS:
             for w in what:
-                subprocess.run([sys.executable, g, w], check=True, capture_output=True, env=dict(os.environ, GEN_GEMM_ASM_OUT=tmp))
+                r = subprocess.run([sys.executable, g, w], capture_output=True, text=True, env=dict(os.environ, GEN_GEMM_ASM_OUT=tmp))
+                if r.returncode != 0:            # e.g. a hazard-check assert of the generator: say which one and why
+                    raise RuntimeError("%s %s failed (exit %d):\n%s" % (os.path.basename(g), w, r.returncode, (r.stderr or r.stdout)[-3000:]))
         for f in sorted(os.listdir(tmp)):
             new = open(os.path.join(tmp, f), "rb").read()
             dst = os.path.join(outdir, f)
@@ -72,12 +78,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     # the inline-asm K loops are generated at build time (33 k lines that used to be committed beside their generator)
-    generate(("product", "experiments") if EXPERIMENTS else ("product",))
-    exp_flags = ["-I", GEN_DIR] + (["-DSYLBER_GEMM_ASM_EXPERIMENTS"] if EXPERIMENTS else [])
+    generate(("product",))
+    exp_flags = ["-I", GEN_DIR]
+    gen_dirs = [GEN_DIR]
+    if EXPERIMENTS:
+        generate(("experiments",), GEN_EXP_DIR)
+        exp_flags += ["-I", GEN_EXP_DIR, "-DSYLBER_GEMM_ASM_EXPERIMENTS"]
+        gen_dirs.append(GEN_EXP_DIR)
 
     # a source is recompiled when it, any header / generated loop beside it, the public headers or this file is newer
     shared = [os.path.getmtime(os.path.abspath(__file__))]
-    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include"), GEN_DIR):
+    for root in [CSRC, os.path.join(os.path.dirname(HERE), "include")] + gen_dirs:
         shared += [os.path.getmtime(os.path.join(root, f)) for f in os.listdir(root) if not f.endswith(".hip")]
     newest_shared = max(shared)
 

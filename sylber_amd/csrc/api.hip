@@ -87,6 +87,12 @@ struct sylber_ctx {
     int opt_gemm_cfg = 0, opt_attn_qw = 0, opt_gemm_persist = 0;   // sylber_set_option (0 = automatic)
     int opt_fuse_ln = 0;                                           // out-projection + LayerNorm in one launch: 0 auto, 1 always, -1 never
     int opt_conv0_valu = 0;                                        // 1: conv0 of the 16-bit modes on the VALU kernel (A/B switch)
+    // fp16 headroom audit (SYLBER_OPT_FP16_AUDIT): per stage, how many 16-bit activations sit AT the saturation value and the largest magnitude
+    int opt_audit16 = 0;
+    unsigned* audit_dev = nullptr;                                 // [AUDIT_STAGES][2]: saturated count, max |x| as half bits
+    int opt_segment = 0;                                           // boundary detection: 0 wide (all CUs), -1 one workgroup per utterance
+    int opt_gemm_h192 = 0;                                         // -1: no 192-row tiles in the cost model (A/B switch)
+    int opt_gemm_tail = 0;                                         // row split of multi-round GEMM launches: 0 auto, -1 never, k + 1 = tail tile id k
     int opt_attn8 = 0;                                             // SYLBER_FP8: attention core on MXFP8 operands (0 / 1 on, -1 off)
     int opt_resln_pre = 0;                                         // residual prefetch of the out-proj / FFN2 K loops: 0 default, -1 off, 1..3 columns
     bool graph_mode = false;
@@ -271,11 +277,14 @@ extern "C" void sylber_destroy(sylber_t c) {
     if (c->f8base) hipFree(c->f8base);
     if (c->ws) hipFree(c->ws);
     if (c->seg_scratch) hipFree(c->seg_scratch);
+    if (c->audit_dev) hipFree(c->audit_dev);
     for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     delete c;
 }
 
+// stages of the fp16 headroom audit (audit16 below)
+enum { AUD_CONV0 = 0, AUD_CONV6 = 6, AUD_LN512 = 7, AUD_XPAD = 8, AUD_LN = 9, AUD_Q = 10, AUD_K = 11, AUD_V = 12, AUD_CTX = 13, AUD_FFN1 = 14, AUDIT_STAGES = 15 };
 extern "C" int sylber_set_stop_stage(sylber_t c, int32_t stage) { if (!c) return 1; c->stop_stage = stage; return 0; }
 extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
     if (!c) { syl_set_error("sylber_set_option", "null handle"); return 1; }
@@ -287,6 +296,19 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
         case SYLBER_OPT_CONV0_VALU: c->opt_conv0_valu = value > 0 ? (value == 2 ? 2 : 1) : 0; break;     // (2: producer-only timing probe, experiments build)
         case SYLBER_OPT_RESLN_PREFETCH: c->opt_resln_pre = value < 0 ? -1 : (value <= 3 ? value : 0); break;
         case SYLBER_OPT_FP8_ATTENTION: c->opt_attn8 = value < 0 ? -1 : (value > 0 ? 1 : 0); break;
+        case SYLBER_OPT_FP16_AUDIT: {
+            GUARD_DEVICE(c->device);
+            c->opt_audit16 = value > 0 ? 1 : 0;
+            if (c->opt_audit16) {                                 // (re)start the audit from zero
+                if (!c->audit_dev) HIP_TRY(hipMalloc((void**)&c->audit_dev, AUDIT_STAGES * 2 * sizeof(unsigned)));
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipMemset(c->audit_dev, 0, AUDIT_STAGES * 2 * sizeof(unsigned)));
+            }
+            break;
+        }
+        case SYLBER_OPT_SEGMENT: c->opt_segment = value < 0 ? -1 : 0; break;
+        case SYLBER_OPT_GEMM_H192: c->opt_gemm_h192 = value < 0 ? -1 : 0; break;
+        case SYLBER_OPT_GEMM_TAIL: c->opt_gemm_tail = value < 0 ? -1 : (value > 0 ? value + 1 : 0); break;   // k > 0: tail tile id k (stored id + 1)
         default: syl_set_error("sylber_set_option", "unknown option key"); return 1;
     }
     if (c->graph_mode) { for (auto& g : c->graphs) if (g.exec) hipGraphExecDestroy(g.exec); c->graphs.clear(); }   // captured launches are stale
@@ -413,6 +435,46 @@ static int upload_valid(int* valid_dev, const int32_t* lengths_host, int B, int 
     return 0;
 }
 
+// ---- fp16 headroom audit --------------------------------------------------------------------------------------------
+// IEEE half tops out at 65504; the fp16 modes SATURATE on conversion (H16<FMT_F16>::sat) instead of producing infinities, so a
+// checkpoint whose activations outgrow the format is clamped silently.  With SYLBER_OPT_FP16_AUDIT on, every producer of a 16-bit
+// activation buffer is followed by a scan of what it wrote: values AT +-65504 (0x7bff) are counted as saturated, the largest magnitude is
+// kept as the stage's headroom figure.  Off (default): nothing is launched.  Synthetic weights have never come near the limit; real ones
+// have never been seen by this library (the checkpoint is not obtainable offline) -- this is how a user finds out.
+static const char* const AUDIT_NAMES[AUDIT_STAGES] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "ln512", "proj_xpad", "layernorm",
+                                                      "q", "k", "v", "context", "ffn1"};
+__global__ __launch_bounds__(256) void audit16_kernel(const unsigned short* __restrict__ buf, long rows, long cols, long pitch, unsigned* __restrict__ slot) {
+    unsigned sat = 0, mx = 0;
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const unsigned a = buf[(i / cols) * pitch + i % cols] & 0x7fffu;
+        if (a <= 0x7c00u) mx = a > mx ? a : mx;             // (NaN patterns are not magnitudes)
+        sat += a == 0x7bffu;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { sat += __shfl_xor(sat, d, 64); const unsigned o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0) { if (sat) atomicAdd(slot, sat); atomicMax(slot + 1, mx); }
+}
+static int audit16(sylber_ctx* c, int stage, const void* buf, long rows, long cols, long pitch, hipStream_t s) {
+    if (!c->opt_audit16 || !c->audit_dev) return 0;
+    long blocks = (rows * cols + 256L * 16 - 1) / (256L * 16);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(audit16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)buf, rows, cols, pitch, c->audit_dev + 2 * stage);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int sylber_get_fp16_audit(sylber_t c, const char** names, uint32_t* saturated, float* max_abs, int32_t cap) {
+    if (!c) { syl_set_error("sylber_get_fp16_audit", "null handle"); return -1; }
+    if (!c->audit_dev) return 0;
+    GUARD_DEVICE(c->device);
+    unsigned host[AUDIT_STAGES * 2];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, c->audit_dev, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) {
+        syl_set_error("sylber_get_fp16_audit", "device read failed"); return -1;
+    }
+    const int n = cap < AUDIT_STAGES ? cap : AUDIT_STAGES;
+    for (int i = 0; i < n; ++i) { names[i] = AUDIT_NAMES[i]; saturated[i] = host[2 * i]; max_abs[i] = h2f_host((bf16_t)host[2 * i + 1]); }
+    return n;
+}
+
 struct ProfScope {
     sylber_ctx* c; hipStream_t s; bool on;
     ProfScope(sylber_ctx* c_, hipStream_t s_, const char* name) : c(c_), s(s_), on(c_->profiling != 0) {
@@ -476,6 +538,8 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
     RUN("conv0_finalize", launch_conv0_finalize(part, p.nchunk, c->conv0_w, c->gn_w, c->gn_b, B, p.L[0], ss, s));
     const bool split = c->precision == SYLBER_SPLIT16;      // hi / lo half planes, erf GELU (fp32-grade decisions)
     RUN("conv0_gn_gelu", launch_conv0_gn_gelu(wav_dev, B, Lmax, p.L[0], p.R[0], c->conv0_w, ss, bufA, 0, s, c->fmt_conv, p.lo_bufA, c->opt_conv0_valu));
+    const bool aud_c = c->opt_audit16 && c->fmt_conv == FMT_F16, aud_e = c->opt_audit16 && c->fmt == FMT_F16;   // (the audit launches are never captured: graph mode is refused with it)
+    if (aud_c && audit16(c, AUD_CONV0, bufA, (long)B * p.R[0], 512, 512, s)) return 1;
     // ---- conv layers 1..6 as implicit GEMM (ping-pong)
     bf16_t* src = bufA; bf16_t* dst = bufB;
     long src_lo = p.lo_bufA, dst_lo = p.lo_bufB;
@@ -483,11 +547,12 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         GemmArgs a = {};
         a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w[i];
         a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = split ? ACT_GELU_ERF7 : ACT_GELU_FAST;
-        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.fmt = c->fmt_conv;
+        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.tune_tail = c->opt_gemm_tail; a.tune_h192 = c->opt_gemm_h192;  a.fmt = c->fmt_conv;
         a.x_lo = src_lo; a.w_lo = (long)512 * CK[i] * 512; a.out_lo = dst_lo;
         a.kpat = (CK[i] == 3 && c->fmt_conv != FMT_SPLIT) ? 1 : 0;      // chunk-major K order (weights packed to match at create)
         static const char* nm[7] = {"", "gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_conv6"};
         RUN(nm[i], launch_gemm_bf16(EPI_BF16, a, s));
+        if (aud_c && audit16(c, AUD_CONV0 + i, dst, (long)B * p.R[i], 512, 512, s)) return 1;
         bf16_t* t = src; src = dst; dst = t;
         const long tl = src_lo; src_lo = dst_lo; dst_lo = tl;
     }
@@ -509,6 +574,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         g.out0 = xf32; g.ld0 = 768; g.out1 = xpad; g.Tp = p.Tp; g.T = p.T; g.valid = valid; g.xpad_rows = p.Tp + 128; g.fmt = c->fmt;
         g.x_lo = p.lo_ln512; g.w_lo = (long)768 * 512; g.out_lo = p.lo_xpad;
         RUN("gemm_proj", launch_gemm_bf16(EPI_PROJ, g, s));
+        if (aud_e && (audit16(c, AUD_LN512, ln512, M, 512, 512, s) || audit16(c, AUD_XPAD, xpad, (long)B * (p.Tp + 128), 768, 768, s))) return 1;
     }
     // ---- positional conv + residual, encoder LayerNorm
     RUN("posconv", launch_posconv(xpad, c->pos_w, c->pos_b, xf32, pre, B, p.Tp, split ? 2 : 1, s, c->fmt, p.lo_xpad, (long)16 * 128 * 64 * 56));
@@ -525,7 +591,9 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         if (last) { a.out_f32 = hidden_dev; a.ld_f32 = 768; a.Tp = p.Tp; a.T = p.T; }
         else if (to_fp8) { a.out_fp8 = h8; a.ld_fp8 = 768; a.out_scale = h8s; a.scale_rows = Mp; a.out_stats = stats; }
         else { a.out_bf16 = hbf; a.ld_bf16 = 768; a.out_stats = stats; a.out_lo = p.lo_hbf; }   // no fp32 copy: see EPI_F32_RESLN
-        return launch_layernorm(a, s);
+        if (launch_layernorm(a, s)) return 1;
+        if (aud_e && !last && !to_fp8) return audit16(c, AUD_LN, hbf, M, 768, 768, s);
+        return 0;
     };
     RUN("layernorm", run_ln(c->enc_ln_w, c->enc_ln_b, c->stop_stage == 2, f8));
     if (c->stop_stage == 2) return 0;
@@ -563,9 +631,11 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             GemmArgs g = {};
             g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 2304; g.K = 768; g.bias = d.bqkv;
             g.out0 = q; g.out1 = k; g.out2 = vt; g.Tp = p.Tp; g.Tpv = p.Tpv; g.T = p.T;
-            g.tune_cfg = c->opt_gemm_cfg; g.tune_persist = c->opt_gemm_persist; g.fmt = c->fmt;
+            g.tune_cfg = c->opt_gemm_cfg; g.tune_persist = c->opt_gemm_persist; g.tune_tail = c->opt_gemm_tail; g.tune_h192 = c->opt_gemm_h192;  g.fmt = c->fmt;
             g.x_lo = p.lo_hbf; g.w_lo = (long)2304 * 768; g.out_lo = p.lo_qk; g.out2_lo = p.lo_vt;
             RUN("gemm_qkv", launch_gemm_bf16(EPI_QK, g, s));
+            if (aud_e && (audit16(c, AUD_Q, q, M, 768, 768, s) || audit16(c, AUD_K, k, M, 768, 768, s) ||
+                          audit16(c, AUD_V, vt, (long)B * 768, p.Tp, p.Tpv, s))) return 1;
         }
         if (f8) {
             if (attn8) RUN("attention", launch_attention_f8(q8, q8s, k8, k8s, v8, v8s, valid, ctx8, ctx8s, Mp, B, p.T, p.Tp, p.Tpv, s));
@@ -578,10 +648,11 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             RUN("gemm_out", launch_gemm_mxfp8(EPI_F32_RESLN, o, s));
         } else {
         RUN("attention", launch_attention(q, k, vt, valid, ctx, B, p.T, p.Tp, p.Tpv, c->opt_attn_qw, s, c->fmt, p.lo_qk, p.lo_vt, p.lo_ctx));
+        if (aud_e && audit16(c, AUD_CTX, ctx, M, 768, 768, s)) return 1;
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
         o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
-        o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist; o.fmt = c->fmt; o.tune_pre = c->opt_resln_pre;
+        o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist; o.tune_tail = c->opt_gemm_tail; o.tune_h192 = c->opt_gemm_h192;  o.fmt = c->fmt; o.tune_pre = c->opt_resln_pre;
         o.x_lo = p.lo_ctx; o.w_lo = (long)768 * 768;
         // out-projection + LayerNorm 1 as ONE launch on full-row tiles (gemm_rowln.hip) where the batch fills the chip
         o.out1 = hbf; o.ln_stats_out = stats; o.ln_gamma_out = d.ln1w; o.ln_beta_out = d.ln1b;
@@ -603,13 +674,14 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         } else {
         GemmArgs f1 = {};
         f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = split ? ACT_GELU_ERF7 : ACT_GELU_FAST;
-        f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist; f1.fmt = c->fmt;
+        f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist; f1.tune_tail = c->opt_gemm_tail; f1.tune_h192 = c->opt_gemm_h192;  f1.fmt = c->fmt;
         f1.x_lo = p.lo_hbf; f1.w_lo = (long)3072 * 768; f1.out_lo = p.lo_ffn;
         RUN("gemm_ffn1", launch_gemm_bf16(EPI_BF16, f1, s));
+        if (aud_e && audit16(c, AUD_FFN1, ffn, M, 3072, 3072, s)) return 1;
         GemmArgs f2 = {};
         f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
         f2.out0 = pre; f2.ld0 = 768; f2.res = pre; f2.ldres = 768; f2.ln_stats = stats; f2.ln_gamma = d.ln1w; f2.ln_beta = d.ln1b;
-        f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist; f2.fmt = c->fmt; f2.tune_pre = c->opt_resln_pre;
+        f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist; f2.tune_tail = c->opt_gemm_tail; f2.tune_h192 = c->opt_gemm_h192;  f2.fmt = c->fmt; f2.tune_pre = c->opt_resln_pre;
         f2.x_lo = p.lo_ffn; f2.w_lo = (long)768 * 3072;
         RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RESLN, f2, s));
         }
@@ -651,7 +723,7 @@ extern "C" int sylber_forward(sylber_t c, const float* wav_dev, const int32_t* l
     int* valid = (int*)(c->ws + p.o_valid);
     // valid frames per utterance (TP:664-689): conv-length formula of the number of valid samples
     if (upload_valid(valid, lengths_host, B, Lmax, s)) return 1;
-    if (!c->graph_mode || c->profiling || s == nullptr) return forward_launch(c, p, wav_dev, hidden_dev, s);
+    if (!c->graph_mode || c->profiling || c->opt_audit16 || s == nullptr) return forward_launch(c, p, wav_dev, hidden_dev, s);
     GraphEntry* e = nullptr;
     for (auto& g : c->graphs)
         if (g.B == B && g.Lmax == Lmax && g.stop_stage == c->stop_stage && g.in == wav_dev && g.out == hidden_dev) e = &g;
@@ -776,7 +848,7 @@ extern "C" int sylber_segment(sylber_t c, const float* hidden_dev, int32_t B, in
     if (!c || !hidden_dev || !seg_dev || !nseg_dev) { syl_set_error("sylber_segment", "null argument"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     GUARD_DEVICE(c->device);
-    // utterances beyond 3940 frames (78.8 s) keep their bookkeeping in a global slab instead of LDS (grow-only)
+    // per-utterance slab of the wide path (frame norms, slot table, bookkeeping of long runs; grow-only)
     const size_t need = segment_scratch_floats(B, T, D);
     if (need > c->seg_scratch_floats) {
         HIP_TRY(hipStreamSynchronize(s));
@@ -786,7 +858,7 @@ extern "C" int sylber_segment(sylber_t c, const float* hidden_dev, int32_t B, in
         c->seg_scratch_floats = need;
     }
     ProfScope ps(c, s, "segment");
-    return launch_segment(hidden_dev, B, T, D, norm_thr, merge_thr, seg_dev, nseg_dev, feat_dev, c->seg_scratch, s);
+    return launch_segment(hidden_dev, B, T, D, norm_thr, merge_thr, seg_dev, nseg_dev, feat_dev, c->seg_scratch, s, c->opt_segment);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -796,6 +868,16 @@ struct TmpBuf {
     ~TmpBuf() { if (p) hipFree(p); }
     int alloc(size_t bytes) { return hipMalloc(&p, bytes) == hipSuccess ? 0 : 1; }
 };
+
+// `tile` argument of the op-level entry points: -1 = automatic, else tile id + 1000 x (workgroups per CU; 9 = one workgroup per tile)
+// + 100000 x t (tail policy of the launch, GemmArgs::tune_tail: t = 1 never split by rows, t >= 2 force a split with tail tile id t - 2)
+static void decode_tile(int tile, GemmArgs& g) {
+    const int t = tile >= 100000 ? tile / 100000 : 0;
+    if (tile >= 100000) tile %= 100000;
+    g.tune_tail = t == 0 ? 0 : (t == 1 ? -1 : t - 1);
+    g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1;
+    g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+}
 
 extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const float* bias_dev, float* c_dev, int32_t M,
                                 int32_t N, int32_t K, int32_t act, int32_t precision, int32_t tile, void* stream) {
@@ -830,7 +912,7 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
         GemmArgs g = {};
         g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev; g.act = act;
         g.out0 = c_dev; g.ld0 = N; g.fmt = FMT_SPLIT; g.x_lo = xp; g.w_lo = wp;
-        g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+        decode_tile(tile, g);
         if (launch_gemm_bf16(EPI_F32, g, s)) return 1;
         HIP_TRY(hipStreamSynchronize(s));
         return 0;
@@ -842,7 +924,7 @@ extern "C" int sylber_op_linear(const float* a_dev, const float* w_dev, const fl
     if (launch_f32_to_bf16(w_dev, (bf16_t*)wb.p, (size_t)N * K, s)) return 1;
     GemmArgs g = {};
     g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev; g.act = act;
-    g.out0 = c_dev; g.ld0 = N; g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+    g.out0 = c_dev; g.ld0 = N; decode_tile(tile, g);
     if (launch_gemm_bf16(EPI_F32, g, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -861,7 +943,7 @@ extern "C" int sylber_op_linear_resln(const float* a_dev, const float* w_dev, co
     GemmArgs g = {};
     g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev;
     g.out0 = pre_dev; g.ld0 = N; g.res = pre_dev; g.ldres = N; g.ln_stats = stats_dev; g.ln_gamma = gamma_dev; g.ln_beta = beta_dev;
-    g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+    decode_tile(tile, g);
     if (launch_gemm_bf16(EPI_F32_RESLN, g, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -886,7 +968,7 @@ extern "C" int sylber_op_conv3(const float* x_dev, const float* w_host, uint16_t
     HIP_TRY(hipMemcpyAsync(wb.p, wp.data(), wp.size() * 2, hipMemcpyHostToDevice, s));
     GemmArgs g = {};
     g.X = (bf16_t*)xb.p; g.ldx = 1024; g.W = (bf16_t*)wb.p; g.M = M; g.N = 512; g.K = 1536; g.act = ACT_GELU_FAST; g.kpat = 1;
-    g.out0 = y16_dev; g.ld0 = 512; g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+    g.out0 = y16_dev; g.ld0 = 512; decode_tile(tile, g);
     if (launch_gemm_bf16(EPI_BF16, g, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -904,7 +986,7 @@ extern "C" int sylber_op_linear16(const float* a_dev, const float* w_dev, const 
     if (launch_f32_to_bf16(w_dev, (bf16_t*)wb.p, (size_t)N * K, s)) return 1;
     GemmArgs g = {};
     g.X = (bf16_t*)ab.p; g.ldx = K; g.W = (bf16_t*)wb.p; g.M = M; g.N = N; g.K = K; g.bias = bias_dev; g.act = act;
-    g.out0 = c16_dev; g.ld0 = N; g.tune_cfg = tile < 0 ? 0 : tile % 1000 + 1; g.tune_persist = tile >= 9000 ? -1 : (tile >= 1000 ? tile / 1000 : 0);
+    g.out0 = c16_dev; g.ld0 = N; decode_tile(tile, g);
     if (launch_gemm_bf16(EPI_BF16, g, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
@@ -1162,6 +1244,10 @@ static int gemm_bench_f8(int M, int N, int K, int epi, int act, int cfg, int ite
 static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg, int32_t iters,
                            float* ms_out, unsigned long long* g_gemm_trace_out) {
     if (cfg >= 100 && cfg < 200) return gemm_bench_f8(M, N, K, epi, act, cfg - 100, iters, ms_out);
+    const bool no_h192 = act >= 10000;                    // act + 10000: the cost model without the 192-row tiles (A/B)
+    act %= 10000;
+    const int tail_code = act / 100;                      // act + 100 t: tail policy of the launch (GemmArgs::tune_tail)
+    act %= 100;
     const bool kpat = cfg >= 350000;                      // cfg + 400000: the 3-tap conv layers' chunk-major K order (K = 1536, ldx = 1024)
     if (kpat) cfg -= 400000;
     const bool cold = cfg >= 150000;                      // cfg + 200000: operands flushed out of the caches before every launch
@@ -1191,6 +1277,8 @@ static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t
     }
     g.tune_cfg = cfg < 0 ? 0 : (cfg % 1000) + 1;
     g.tune_persist = cfg >= 9000 ? -1 : (cfg >= 1000 ? cfg / 1000 : 0);    // cfg = persist * 1000 + tile (9000 + tile: persist = -1)
+    g.tune_h192 = no_h192 ? -1 : 0;
+    g.tune_tail = tail_code == 0 ? 0 : (tail_code == 1 ? -1 : tail_code - 1);   // act + 100 t: t = 1 never split, t >= 2 force tail tile id t - 2
     TmpBuf trb;
     if (g_gemm_trace_out) {
         if (trb.alloc(20 * 8)) { syl_set_error("sylber_debug_gemm_bench", "alloc"); return 1; }

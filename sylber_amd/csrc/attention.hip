@@ -38,7 +38,9 @@ template <bool F8, int FMT>
 __device__ __forceinline__ void attn_finalize(const f32x16_t (&oacc)[2], float l_run, bf16_t* __restrict__ ctx, uint8_t* __restrict__ ctx_scale,
                                               long scale_rows, int b, int head, int q_first, int ql, int h, int T, int Tp, long lo_ctx = 0) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / l_tot;
+        // an utterance without a single valid key (valid[b] == 0: sylber_forward rejects such lengths, the op-level entry point does not)
+        // leaves l = 0 and O = 0: its context rows are written as zeros, not as 0 x inf = NaN (which would reach every later layer through V^T)
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
         const int q = q_first + ql;
         if constexpr (F8) {
             // SYLBER_FP8: the context leaves as MXFP8 for the out-projection GEMM.  A 32-wide d block of a head is one

@@ -66,9 +66,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = (a.N + BN - 1) / BN;
-    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tiles_m = (a.M - a.m_begin + BM - 1) / BM;
     const int wg = xcd_remap(tile_id, tiles_m * tiles_n);
-    const int m0 = (wg / tiles_n) * BM;
+    const int m0 = a.m_begin + (wg / tiles_n) * BM;
     const int n0 = (wg % tiles_n) * BN;
 
     // ---- staging: wave w owns pieces w, w+4, ...; piece p < BM/8 is X rows 8p.., else W rows
@@ -259,7 +259,7 @@ template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int 
 __global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int BM = 64 * FM, BN = 64 * FN;
-    const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int ntiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gemm_bf16_tile<FM, FN, BK, NSTAGE, PRIO, EPI, ACT, FMT>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) __builtin_amdgcn_s_barrier();   // LDS (operand ring / epilogue staging) is reused
@@ -271,7 +271,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * FM, BN = 64 * FN;
     constexpr int LDS = NSTAGE * (BM + BN) * BK * 2;
     if (a.K % BK != 0) { syl_set_error("launch_gemm_bf16", "K must be a multiple of the K step"); return 1; }
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int tiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static PerDeviceOnce attr_once;
     auto kern = gemm_bf16_kernel<FM, FN, BK, NSTAGE, MINB, PRIO, EPI, ACT, FMT>;
     if (attr_once.need()) {
@@ -319,9 +319,9 @@ __device__ __forceinline__ void gemm8_bf16_tile(const GemmArgs& a, const int til
     const bool hi = wave < (NP % 8 == 0 ? 8 : NP % 8);   // this wave issues NPW_HI pieces per step
 
     const int tiles_n = (a.N + BN - 1) / BN;
-    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tiles_m = (a.M - a.m_begin + BM - 1) / BM;
     const int wg = xcd_remap(tile_id, tiles_m * tiles_n);
-    const int m0 = (wg / tiles_n) * BM;
+    const int m0 = a.m_begin + (wg / tiles_n) * BM;
     const int n0 = (wg % tiles_n) * BN;
 
     const int srow = lane >> 2, spos = lane & 3;
@@ -502,9 +502,9 @@ __device__ __forceinline__ void gemm8u_bf16_tile(const GemmArgs& a, const int ti
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+    const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M - a.m_begin + BM - 1) / BM;
     const int wg = xcd_remap(tile_id, tiles_m * tiles_n);
-    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const int m0 = a.m_begin + (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
     const int srow = lane >> 2, spos = lane & 3;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + (size_t)m0 * a.ldx), rw = make_rsrc(a.W + (size_t)n0 * a.K);
     int voff[NPW];
@@ -625,7 +625,7 @@ __device__ __forceinline__ void gemm8u_bf16_tile(const GemmArgs& a, const int ti
 template <int EPI, int ACT, int FMT, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void gemm8u_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
-    const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const int ntiles = ((a.M - a.m_begin + 255) / 256) * ((a.N + 255) / 256);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gemm8u_bf16_tile<EPI, ACT, FMT, TRACE>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) {
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void gemm8u_bf16_kernel(const GemmArgs a) {
 template <int EPI, int ACT, int FMT, bool TRACE = false>
 static int launch_cfg8u(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = 4 * (256 + 256) * 64;
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const int tiles = ((a.M - a.m_begin + 255) / 256) * ((a.N + 255) / 256);
     static PerDeviceOnce attr_once;
     auto kern = gemm8u_bf16_kernel<EPI, ACT, FMT, TRACE>;
     if (attr_once.need()) {
@@ -659,7 +659,7 @@ template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT, int VAR = 0
 __global__ __launch_bounds__(512, 2) void gemm8_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
-    const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int ntiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         gemm8_bf16_tile<FM, FN, WM, WN, EPI, ACT, FMT, VAR>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) {
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int group = wave >> 2;
     const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = a.N / BN, tiles_m = a.M / BM;
+    const int tiles_n = a.N / BN, tiles_m = (a.M - a.m_begin) / BM;
     const int ntiles = tiles_m * tiles_n;
     const int srow = lane >> 2, spos = lane & 3;
     const int frow = lane & 31;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_bf16_kernel(const GemmArgs a) {
     struct TileSrc { __amdgpu_buffer_rsrc_t rx, rw; };
     auto setup = [&](int tile_id, TileSrc& g, int& m0, int& n0) {
         const int wg = xcd_remap(tile_id, ntiles);
-        m0 = (wg / tiles_n) * BM;
+        m0 = a.m_begin + (wg / tiles_n) * BM;
         n0 = (wg % tiles_n) * BN;
         g.rx = make_rsrc(a.X + (size_t)m0 * a.ldx);
         g.rw = make_rsrc(a.W + (size_t)n0 * a.K);
@@ -842,7 +842,7 @@ template <int FM, int FN, int WM, int WN, int EPI, int ACT, int FMT, int VAR = 0
 static int launch_cfg8(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDS = 4 * (BM + BN) * 64;
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int tiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static PerDeviceOnce attr_once;
     auto kern = gemm8_bf16_kernel<FM, FN, WM, WN, EPI, ACT, FMT, VAR>;
     if (attr_once.need()) {
@@ -868,12 +868,74 @@ static int launch_cfg8p(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+// tail policy constants (measured: profiles/r06_tail_policy.md)
+#ifndef GEMM_SOLO_EFF
+#define GEMM_SOLO_EFF 0.60          // a 2-per-CU tile alone on its CU, relative to its rated efficiency (measured: a lone 128x192x3072 tile 66 us, two co-resident 80 us)
+#endif
+#ifndef GEMM_SPLIT_US
+#define GEMM_SPLIT_US 4.0           // what the second launch of a split costs (dispatch gap + a second prologue)
+#endif
+#ifndef GEMM_H192_EFF
+#define GEMM_H192_EFF 0.95          // the 192-row tiles' efficiency relative to their 256-row siblings
+#endif
+#define GEMM_CU_MACS_PER_US 1.8e6   // one CU's rate on these loops (256 x 256 x 768 MACs in ~28 us)
+
+// launch one tile configuration (by id) over rows [a.m_begin, a.M)
+template <int EPI, int ACT, int FMT>
+static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
+    if constexpr (FMT == FMT_SPLIT) {
+        // the split-operand mode instantiates the three tile shapes the cost model picks (and nothing else)
+        if (cfg == 3) return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);
+        if (cfg == 10) {
+            if constexpr (EPI == EPI_BF16) {
+                if (a.tune_persist >= 0 && (a.M - a.m_begin) % 256 == 0 && a.N % 256 == 0 && a.K >= 96 && (long)((a.M - a.m_begin) / 256) * (a.N / 256) > 256)
+                    return launch_cfg8p<ACT, FMT>(a, s);
+            }
+            return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);
+        }
+        return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);
+    } else
+    switch (cfg) {
+        case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT, FMT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
+        case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);   // 128x128, 2 WG/CU
+        case 10:
+            if constexpr (EPI == EPI_BF16) {
+                // whole tiles, more than one round, at least 3 K steps: the persistent kernel with cross-tile prefetch
+                if (a.tune_persist >= 0 && (a.M - a.m_begin) % 256 == 0 && a.N % 256 == 0 && a.K >= 96 && (long)((a.M - a.m_begin) / 256) * (a.N / 256) > 256)
+                    return launch_cfg8p<ACT, FMT>(a, s);
+            }
+            return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
+        case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
+        case 51: case 57: case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 86: case 87: case 88: case 89: case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 98:
+            // hand-scheduled K loop; a forced tile without an instantiation for this epilogue falls back to 128x192 (sylber_hip.h)
+            if (gemm_asm_has_tile(EPI, a, cfg) || (cfg != 51 && cfg != 57 && cfg != 60 && cfg != 80 && cfg != 85 && cfg != 86 && cfg != 90 && cfg != 91 && cfg != 95 && cfg != 96 && cfg != 97 && gemm_asm_applicable(EPI, a))) {
+                GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm(EPI, b, s);
+            }
+            break;
+        case 40: if constexpr (FMT == FMT_BF16) return launch_cfg8u<EPI, ACT, FMT>(a, s); break;                     // unstaggered 8-wave 256x256
+        case 41: if constexpr (FMT == FMT_BF16 && EPI == EPI_BF16 && ACT == 0) return launch_cfg8u<EPI, ACT, FMT, true>(a, s); break;   // its trace
+        case 30: if constexpr (FMT == FMT_BF16 && (EPI == EPI_BF16 || EPI == EPI_F32_RESLN)) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 10>(a, s); break;   // trace
+        default: break;
+    }
+    return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);              // 128x192, 2 WG/CU
+}
+
 // Tile-shape choice, measured on MI355X with tools/gemm_bench.py (random operands):
 //   cfg 3  128x128, 4 waves, 2 workgroups/CU   best when the tile count just fills one round (conv6)
 //   cfg 4  128x192, 4 waves, 2 workgroups/CU   best for N = 768 / 1536 (500 / 1000 tiles = 1 / 2 rounds)
 //   cfg 10 256x256, 8 waves staggered, 1 WG/CU best for the big GEMMs (conv1-5, FFN1): +20-25 %
 // Two co-resident workgroups (cfg 3/4) cover each other's epilogue / barrier / DMA-issue time; the big
 // tile (cfg 10) instead halves the per-FLOP L1/TA traffic.  Cost = rounds x (tile area per CU) / eff.
+//
+// PARTIAL ROUNDS (round 6).  The persistent big tiles walk the tile list 256 at a time, so a launch of r + f rounds (0 < f < 1) costs
+// r + 1: the 32 x 10 s headline is exactly 3 rounds (FFN1 / q,k,v) and 1 round (out-proj / FFN2), every other batch shape pays up to a
+// whole round per launch (8 x 60 s: 4.4 -> 5 and 1.47 -> 2; profiles/r06_shape_sweep.md).  Two mechanisms, both bit-identical (every
+// output element is one fp32 chain over K in the same order whatever tile computes it; tests/test_gpu_ops.py):
+//   * a second tile HEIGHT: tiles 51 / 57 = the loops of 91 / 97 on 192-row tiles (gemm_asm.hip); the cost model below picks the height
+//     whose tile count wastes less of its last round (8 x 60 s, N = 768: 376 tiles = 2 rounds at 256 rows, 504 tiles = 2 rounds of
+//     3/4-size tiles at 192 rows)
+//   * a row split: rows of the full rounds on the chosen tile, rows [M1, M) as a second launch on another tile (GemmArgs::m_begin).
+//     Measured not to pay with the tiles that exist (see below): kept as a forced option and as the test vehicle of m_begin.
 template <int EPI, int ACT, int FMT>
 static int launch_f(const GemmArgs& a, hipStream_t s) {
     struct Cfg { int id, bm, bn, per_cu; double eff; };
@@ -887,57 +949,75 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     const bool x3 = FMT != FMT_SPLIT;
     // 86 = the X3 loop on a 256x128 tile / four waves: slower per FLOP than 97 (923 vs 974 TF on conv1), but a launch of 64 row tiles
     // x 512 columns (conv6) fills 256 CUs with it and half of them with 256x256 tiles: 22.0 vs 29.7 us
-    const Cfg cfgs[7] = {{3, 128, 128, 2, 0.93}, {4, 128, 192, 2, 1.00}, {10, 256, 256, 1, 1.20},
-                         {x3 ? 85 : 80, 256, 256, 1, long_k ? 1.28 : 1.10}, {91, 256, 192, 1, long_k ? 1.10 : 1.04},
-                         {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27}, {86, 256, 128, 1, 1.10}};
-    int best = 0;
-    double best_cost = 1e300;
-    for (int i = 0; i < 7; ++i) {
-        if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, cfgs[i].id))) continue;   // only tiles that exist for this epilogue / format
-        const long tm = (a.M + cfgs[i].bm - 1) / cfgs[i].bm, tn = (a.N + cfgs[i].bn - 1) / cfgs[i].bn;
-        if (cfgs[i].id == 86 && tm * tn < 192) continue;    // (measured for launches that fill the chip; small batches keep their tiles)
-        const long slots = 256L * cfgs[i].per_cu;
+    // 51 / 57 = tiles 91 / 97 at 192 rows (round 6): 6 % fewer FLOPs per staged byte, rated GEMM_H192_EFF of their siblings; they win where their
+    // tile count fills the last round of 256 workgroups and the 256-row count does not
+    constexpr int NCFG = 9;
+    const Cfg cfgs[NCFG] = {{3, 128, 128, 2, 0.93}, {4, 128, 192, 2, 1.00}, {10, 256, 256, 1, 1.20},
+                            {x3 ? 85 : 80, 256, 256, 1, long_k ? 1.28 : 1.10}, {91, 256, 192, 1, long_k ? 1.10 : 1.04},
+                            {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27}, {86, 256, 128, 1, 1.10},
+                            {51, 192, 192, 1, (long_k ? 1.10 : 1.04) * GEMM_H192_EFF}, {57, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF}};
+    // cost of configuration i over `rows` rows: rounds x (tile area per CU) / eff.  A two-per-CU configuration whose tiles leave every
+    // CU with at most ONE workgroup is charged one tile per CU, at the lower efficiency of a workgroup that runs alone (GEMM_SOLO_EFF:
+    // nobody covers its prologue / epilogue) -- the tail of a split launch is usually such a launch
+    auto cost_of = [&](int i, long rows) -> double {
+        const Cfg& c = cfgs[i];
+        if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, c.id))) return 1e300;   // only tiles that exist for this epilogue / format
+        if ((c.id == 51 || c.id == 57) && a.tune_h192 < 0) return 1e300;
+        const long tm = (rows + c.bm - 1) / c.bm, tn = (a.N + c.bn - 1) / c.bn;
+        if (c.id == 86 && tm * tn < 192) return 1e300;      // (measured for launches that fill the chip; small batches keep their tiles)
+        if (c.per_cu == 2 && tm * tn <= 256) return (double)c.bm * c.bn / (c.eff * GEMM_SOLO_EFF);
+        const long slots = 256L * c.per_cu;
         const long rounds = (tm * tn + slots - 1) / slots;
-        const double cost = (double)rounds * cfgs[i].per_cu * cfgs[i].bm * cfgs[i].bn / cfgs[i].eff;
-        if (cost < best_cost) { best_cost = cost; best = i; }
-    }
+        return (double)rounds * c.per_cu * c.bm * c.bn / c.eff;
+    };
+    auto pick = [&](long rows, double* cost) -> int {
+        int best = 0;
+        double best_cost = 1e300;
+        for (int i = 0; i < NCFG; ++i) {
+            const double ci = cost_of(i, rows);
+            if (ci < best_cost) { best_cost = ci; best = i; }
+        }
+        *cost = best_cost;
+        return best;
+    };
+    const long rows = a.M - a.m_begin;
+    double whole_cost;
+    const int best = pick(rows, &whole_cost);
     int cfg = cfgs[best].id;
     if (a.tune_cfg > 0) cfg = a.tune_cfg - 1;            // per-call override (sylber_set_option / parity tests)
-    if constexpr (FMT == FMT_SPLIT) {
-        // the split-operand mode instantiates the three tile shapes the cost model picks (and nothing else)
-        if (cfg == 3) return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);
-        if (cfg == 10) {
-            if constexpr (EPI == EPI_BF16) {
-                if (a.tune_persist >= 0 && a.M % 256 == 0 && a.N % 256 == 0 && a.K >= 96 && (long)(a.M / 256) * (a.N / 256) > 256)
-                    return launch_cfg8p<ACT, FMT>(a, s);
+    // ---- row split: rows of the full rounds on the chosen tile, the rest re-tiled.  FORCED ONLY (tune_tail > 0): measured (profiles/r06_tail_policy.md),
+    // a smaller tile alone on its CU runs its K loop at the same wall time per step as a big one (a lone 128x192x3072 tile: 66 us; two
+    // co-resident: 80 us), so re-tiling the tail buys nothing and the second launch costs 3-5 us; with two batches in flight it is a loss
+    // (8 x 60 s: 8.76 -> 9.15 ms).  What does fill a partial round at full CU efficiency is a second tile HEIGHT: tiles 51 / 57 above.
+    if (a.tune_tail > 0 && a.m_begin == 0) {
+        int bi = -1;
+        for (int i = 0; i < NCFG; ++i) if (cfgs[i].id == cfg) bi = i;
+        if (bi >= 0 && cost_of(bi, rows) < 1e299) {
+            const Cfg& c = cfgs[bi];
+            const long tm = (rows + c.bm - 1) / c.bm, tn = (a.N + c.bn - 1) / c.bn, slots = 256L * c.per_cu;
+            const long full = (tm * tn) / slots, rem = tm * tn - full * slots;
+            const long main_tiles_m = full * slots / tn;        // whole row tiles inside the full rounds
+            const long M1 = main_tiles_m * c.bm;
+            if (full >= 1 && rem > 0 && M1 > 0 && M1 < a.M) {
+                double tail_cost = 1e300;
+                int ti = -1;
+                if (a.tune_tail > 0) { for (int i = 0; i < NCFG; ++i) if (cfgs[i].id == a.tune_tail - 1) ti = i; if (ti >= 0) tail_cost = cost_of(ti, a.M - M1); }
+                else ti = pick(a.M - M1, &tail_cost);
+                // a second launch costs ~GEMM_SPLIT_US of an idle chip: in the model's units (output elements per CU at K) that is
+                // GEMM_SPLIT_US x (MACs a CU retires per us) / K
+                const double split_cost = (double)full * c.per_cu * c.bm * c.bn / c.eff + tail_cost + GEMM_SPLIT_US * GEMM_CU_MACS_PER_US / a.K;
+                const double unsplit = a.tune_cfg > 0 ? cost_of(bi, rows) : whole_cost;
+                if (ti >= 0 && tail_cost < 1e299 && (a.tune_tail > 0 || split_cost < 0.95 * unsplit)) {
+                    GemmArgs head = a, tail = a;
+                    head.M = (int)M1; head.tune_tail = -1;
+                    tail.m_begin = (int)M1; tail.tune_tail = -1; tail.tune_cfg = 0;
+                    if (launch_tile<EPI, ACT, FMT>(cfg, head, s) != 0) return 1;
+                    return launch_tile<EPI, ACT, FMT>(cfgs[ti].id, tail, s);
+                }
             }
-            return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);
         }
-        return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);
-    } else
-    switch (cfg) {
-        case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT, FMT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
-        case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);   // 128x128, 2 WG/CU
-        case 10:
-            if constexpr (EPI == EPI_BF16) {
-                // whole tiles, more than one round, at least 3 K steps: the persistent kernel with cross-tile prefetch
-                if (a.tune_persist >= 0 && a.M % 256 == 0 && a.N % 256 == 0 && a.K >= 96 && (long)(a.M / 256) * (a.N / 256) > 256)
-                    return launch_cfg8p<ACT, FMT>(a, s);
-            }
-            return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
-        case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
-        case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 86: case 87: case 88: case 89: case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 98:
-            // hand-scheduled K loop; a forced tile without an instantiation for this epilogue falls back to 128x192 (sylber_hip.h)
-            if (gemm_asm_has_tile(EPI, a, cfg) || (cfg != 60 && cfg != 80 && cfg != 85 && cfg != 86 && cfg != 90 && cfg != 91 && cfg != 95 && cfg != 96 && cfg != 97 && gemm_asm_applicable(EPI, a))) {
-                GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm(EPI, b, s);
-            }
-            break;
-        case 40: if constexpr (FMT == FMT_BF16) return launch_cfg8u<EPI, ACT, FMT>(a, s); break;                     // unstaggered 8-wave 256x256
-        case 41: if constexpr (FMT == FMT_BF16 && EPI == EPI_BF16 && ACT == 0) return launch_cfg8u<EPI, ACT, FMT, true>(a, s); break;   // its trace
-        case 30: if constexpr (FMT == FMT_BF16 && (EPI == EPI_BF16 || EPI == EPI_F32_RESLN)) return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT, 10>(a, s); break;   // trace
-        default: break;
     }
-    return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);              // 128x192, 2 WG/CU
+    return launch_tile<EPI, ACT, FMT>(cfg, a, s);
 }
 
 // operand format (GemmArgs::fmt): the fp16 instantiations exist for the epilogues the fp16 forward uses

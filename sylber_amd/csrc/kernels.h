@@ -51,6 +51,10 @@ struct GemmArgs {
     int kpat;                     // 1: the 3-tap stride-2 conv layers' chunk-major K order (K = 1536, 512 channels): W is packed
                                   // [out][64-channel chunk][tap 0, 2, 1][64] and the X byte offset of K position o follows tap3_offset(o)
     int tune_pre;                 // residual GEMMs on tile 91: -1 no residual prefetch in the K loop, 1..3 fragment columns prefetched, 0 default
+    int m_begin;                  // the launch covers rows [m_begin, M) (0 = all): the tail launch of a row-split GEMM (launch_f, "tail policy");
+                                  // row indices stay absolute everywhere (operands, epilogues, the row -> (utterance, frame) maps)
+    int tune_h192;                // -1: the cost model leaves the 192-row tiles (51 / 57) out (A/B switch)
+    int tune_tail;                // tail policy of multi-round launches: 0 automatic, -1 never split, k > 0 = force a split with tail tile id k - 1
 };
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
@@ -159,10 +163,11 @@ int launch_posconv_f32(const float* xpad, const float* w, const float* bias, con
                        int Tp, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
-// segmentation (get_segment + mean-pool), one workgroup per utterance, numpy-f32 bit-exact
+// segmentation (get_segment + mean-pool), numpy-f32 bit-exact
 // ------------------------------------------------------------------------------------------------
+// mode 0: wide (frame norms, one workgroup per run of speech frames, compaction, pooling: all CUs); -1: one workgroup per utterance
 int launch_segment(const float* hidden, int B, int T, int D, float norm_thr, float merge_thr, int64_t* seg, int* nseg,
-                   float* feat, float* scratch, hipStream_t s);
+                   float* feat, float* scratch, hipStream_t s, int mode = 0);
 size_t segment_scratch_floats(int B, int T, int D);
 
 // misc elementwise

@@ -332,20 +332,360 @@ __global__ __launch_bounds__(256) void segment_kernel(const float* __restrict__ 
     }
 }
 
+// ================================================================================================================================
+// Round 6: the same algorithm WIDE.  The one-workgroup-per-utterance kernel above keeps 8 (8 x 60 s) or 32 (32 x 10 s) of the 256 CUs
+// busy for 1.2 / 0.23 ms; on the critical path of the synchronous Segmenter.__call__ that is 12 % of a long-form call.  What the
+// reference computes decomposes further than "one utterance":
+//   * frame norms: independent rows                                                     -> segment_norms_kernel, all CUs
+//   * greedy scan + refinement: the scan's state is RESET by every non-speech frame (segment_utils.py:84-90: s = -1, seg_cnt = 0; `curr`
+//     is overwritten by the next speech frame before it is read), and a mid-boundary only ever pairs two segments of the same unbroken
+//     run of speech frames (it is recorded where a run continues, :102-106).  So every maximal run of speech frames is an independent
+//     instance of phases 1 and 2: one workgroup per RUN (segment_runs_kernel), the arithmetic of a run statement for statement the
+//     code above (same wave layout, same order, same slow-path decisions); run-local segment tables land in a per-utterance slot table
+//     indexed by the run's first frame (a run of n frames has at most n segments, runs are disjoint: no two runs share a slot)
+//   * the table in frame order = the live slots in slot order                           -> segment_compact_kernel (prefix count)
+//   * mean-pool: independent segments                                                   -> segment_pool_kernel, one wave per segment, all CUs
+// Bit-identical to the kernel above and to the oracle on every golden (tests/test_gpu_segment.py runs both).
+// A run's bookkeeping lives in LDS up to SEG_LCAP frames (10 s of unbroken speech); longer runs are taken by the GS = true launch of
+// the same kernel, which keeps it in the utterance's global slab (launched only when T > SEG_LCAP can hold such a run at all).
+#define SEG_LCAP 512
+
+// per-utterance slab (floats): nsq [T], npw [T], slot table [(T+1) x 2] ints, live [T+1] ints, then (GS runs) simp / simn / sweep [T] each,
+// mid [(T+1) x 2], merged [T+1]
+__host__ __device__ inline size_t seg_wide_slab_floats(int T) { return (5 * (size_t)T + 6 * ((size_t)T + 1) + 63) & ~(size_t)63; }
+
+__global__ __launch_bounds__(256) void segment_norms_kernel(const float* __restrict__ hidden, int B, int T, float* __restrict__ scratch, size_t slab) {
+    __shared__ float ss_s[64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long rows = (long)B * T, r0 = (long)blockIdx.x * 64 + wave * 16;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        float x[4][12];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const long g = r0 + 4 * q + r; load_pw(hidden + (size_t)(g < rows ? g : rows - 1) * SEG_D, lane, x[r]); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ss = pw_dot(x[r], x[r]) + 1e-8f;
+            if (lane == 0) ss_s[wave * 16 + 4 * q + r] = ss;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {                                          // the square root and the ~600-cycle glibc powf: one ROW per thread
+        const long g = (long)blockIdx.x * 64 + tid;
+        if (g < rows) {
+            const int b = (int)(g / T), t = (int)(g % T);
+            float* sl = scratch + (size_t)b * slab;
+            const float ss = ss_s[tid];
+            sl[t] = sqrtf(ss);
+            sl[T + t] = powf_half_glibc(ss);
+            int* live = (int*)(sl + 2 * (size_t)T) + 2 * ((size_t)T + 1);
+            live[t] = 0;
+            if (t == T - 1) live[T] = 0;
+        }
+    }
+}
+
+template <bool GS>
+__global__ __launch_bounds__(256) void segment_runs_kernel(const float* __restrict__ hidden, int T, float norm_thr, float merge_thr,
+                                                           float* __restrict__ scratch, size_t slab, int list_cap) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    float* ca_s = lds_f;                       // [768]
+    float* cb_s = ca_s + SEG_D;                // [768]
+    int* sh_i = (int*)(cb_s + SEG_D);          // [16]
+    int* mystart = sh_i + 16;                  // [list_cap]
+    const int b = blockIdx.y, rx = blockIdx.x, G = gridDim.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* states = hidden + (size_t)b * T * SEG_D;
+    float* sl = scratch + (size_t)b * slab;
+    const float* g_nsq = sl;
+    const float* g_npw = sl + T;
+    int* g_slot = (int*)(sl + 2 * (size_t)T);  // [(T+1)][2]
+    int* g_live = g_slot + 2 * ((size_t)T + 1);
+
+    // ---- which runs are mine: run r (in frame order) belongs to workgroup r % G
+    if (tid < 16) sh_i[tid] = 0;
+    __syncthreads();
+    int running = 0;
+    for (int c0 = 0; c0 < T; c0 += 256) {
+        const int i = c0 + tid;
+        const bool sp = i < T && g_nsq[i] >= norm_thr;
+        const bool pv = i > 0 && i < T && g_nsq[i - 1] >= norm_thr;
+        const bool st = sp && !pv;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(st);
+        if (lane == 0) sh_i[4 + wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += sh_i[4 + w];
+        const int tot = sh_i[4] + sh_i[5] + sh_i[6] + sh_i[7];
+        if (st) {
+            const int ord = off + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            if (ord % G == rx) mystart[ord / G] = i;
+        }
+        running += tot;
+        __syncthreads();
+    }
+    const int mine = running > rx ? (running - rx + G - 1) / G : 0;
+
+    for (int jr = 0; jr < mine; ++jr) {
+        __syncthreads();                                     // the previous run's LDS is free
+        const int base = mystart[jr];
+        // ---- the run's end: the first non-speech frame behind its start, or T
+        if (tid == 0) sh_i[8] = T;
+        __syncthreads();
+        for (int c0 = base + 1; c0 < T; c0 += 256) {
+            const int i = c0 + tid;
+            const bool ns = i < T && !(g_nsq[i] >= norm_thr);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(ns);
+            if (bal != 0ull && lane == 0) atomicMin(&sh_i[8], c0 + wave * 64 + (int)__builtin_ctzll(bal));
+            __syncthreads();
+            const int e = sh_i[8];
+            __syncthreads();
+            if (e < T) break;
+        }
+        const int end = sh_i[8];
+        const int len = end - base;
+        if ((len > SEG_LCAP) != GS) continue;                // (uniform) the other launch's run
+
+        float *simp_s, *simn_s, *sweep_s;
+        const float *nsq, *npw;                              // run-relative: frame i at [i - base]
+        int *seg, *mid, *merged;
+        if constexpr (GS) {
+            float* g_simp = (float*)(g_live + ((size_t)T + 1));
+            simp_s = g_simp + base; simn_s = g_simp + T + base; sweep_s = g_simp + 2 * (size_t)T + base;
+            nsq = g_nsq + base; npw = g_npw + base;
+            seg = g_slot + 2 * (size_t)base;                 // the slot table itself
+            mid = (int*)(g_simp + 3 * (size_t)T) + 2 * (size_t)base;
+            merged = (int*)(g_simp + 3 * (size_t)T) + 2 * ((size_t)T + 1) + base;
+        } else {
+            float* tb = (float*)(mystart + list_cap);
+            simp_s = tb; simn_s = simp_s + SEG_LCAP; sweep_s = simn_s + SEG_LCAP;
+            float* nsq_w = sweep_s + SEG_LCAP; float* npw_w = nsq_w + SEG_LCAP;
+            seg = (int*)(npw_w + SEG_LCAP); mid = seg + 2 * (SEG_LCAP + 1); merged = mid + 2 * (SEG_LCAP + 1);
+            for (int i = tid; i < len; i += 256) { nsq_w[i] = g_nsq[base + i]; npw_w[i] = g_npw[base + i]; }
+            nsq = nsq_w; npw = npw_w;
+        }
+        for (int i = tid; i < len; i += 256) merged[i] = 0;
+        __syncthreads();
+
+        // ---- phase 1: greedy scan over the run's frames [base, end), all of them speech (segment_utils.py:78-108), wave 0
+        if (wave == 0) {
+            int s = -1, seg_cnt = 0, nseg = 0, nmid = 0;
+            float c[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) c[i] = 0.f;
+            float g0[4][12], g1[4][12];
+            auto ldg = [&](int i, float (&g)[4][12]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) load_pw(states + (size_t)(i + r < T ? i + r : T - 1) * SEG_D, lane, g[r]);
+            };
+            ldg(base, g0);
+            for (int i0 = base; i0 < end; i0 += 4) {
+                ldg(i0 + 4, g1);
+                auto step = [&](int i, const float (&x)[12]) {
+                    if (i >= end) return;
+                    if (seg_cnt == 0) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) c[k] = x[k];
+                        seg_cnt = 1; s = i;
+                    } else {
+                        // (estimate + guard band, exact chain inside the band; one division + two FMA corrections per element: see segment_kernel)
+                        const float dot = pw_dot(c, x);
+                        const float cc = pw_dot(c, c) + 1e-8f;
+                        const float est = dot * __builtin_amdgcn_rsqf(cc) * __builtin_amdgcn_rcpf(npw[i - base]);
+                        bool merge;
+                        if (est > merge_thr + 1e-4f) merge = true;
+                        else if (est < merge_thr - 1e-4f) merge = false;
+                        else merge = (dot / powf_half_glibc(cc) / npw[i - base]) >= merge_thr;   // also taken for NaN
+                        if (merge) {
+                            const float cf = (float)seg_cnt, c1 = (float)(seg_cnt + 1);
+                            const float r = 1.0f / c1;
+                            float a[12];
+                            float amin = INFINITY, amax = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) {
+                                a[k] = c[k] * cf + x[k];
+                                amin = fminf(amin, fabsf(a[k])); amax = fmaxf(amax, fabsf(a[k]));
+                            }
+                            if (__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f) || !(amax <= 0x1p126f))) {
+#pragma unroll
+                                for (int k = 0; k < 12; ++k) c[k] = a[k] / c1;
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 12; ++k) {
+                                    const float q0 = a[k] * r;
+                                    const float q1 = fmaf(fmaf(-q0, c1, a[k]), r, q0);
+                                    c[k] = fmaf(fmaf(-q1, c1, a[k]), r, q1);
+                                }
+                            }
+                            seg_cnt += 1;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) c[k] = x[k];
+                            seg_cnt += 1;                      // NOT reset (segment_utils.py:103)
+                            if (lane == 0) { seg[2 * nseg] = s; seg[2 * nseg + 1] = i; mid[2 * nmid] = i; mid[2 * nmid + 1] = nseg; }
+                            ++nseg; ++nmid;
+                            s = i;
+                        }
+                    }
+                };
+                step(i0, g0[0]); step(i0 + 1, g0[1]); step(i0 + 2, g0[2]); step(i0 + 3, g0[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) g0[r][k] = g1[r][k];
+            }
+            if (s > -1) { if (lane == 0) { seg[2 * nseg] = s; seg[2 * nseg + 1] = end; } ++nseg; }   // closed by the silence frame at `end`, or by T
+            if (lane == 0) { sh_i[0] = nseg; sh_i[1] = nmid; }
+        }
+        __syncthreads();
+        const int nseg = sh_i[0], nmid = sh_i[1];
+
+        // ---- phase 2: boundary refinement / re-merge (segment_utils.py:110-128), whole workgroup
+        for (int m = 0; m < nmid; ++m) {
+            const int bd = mid[2 * m], si = mid[2 * m + 1];
+            if (si >= nseg - 1) continue;
+            const int a0 = seg[2 * si], a1 = seg[2 * si + 1];
+            const int b0 = seg[2 * si + 2], b1 = seg[2 * si + 3];
+            const int la = (a1 - a0) / 2, lb = (b1 - b0) / 2;
+            int ws = bd - (la > 1 ? la : 1); ws = ws < a0 ? a0 : ws;
+            int we = bd + (lb > 1 ? lb : 1); we = we > b1 ? b1 : we;
+            const int w = we - ws;
+            float xw[12];
+            load_pw(states + (size_t)(wave < w ? ws + wave : a0) * SEG_D, lane, xw);
+            if (tid < 128) mean_rows<128>(states, a0, a1, tid, ca_s);
+            else mean_rows<128>(states, b0, b1, tid - 128, cb_s);
+            __syncthreads();
+            float ca[12], cb[12];
+            load_pw(ca_s, lane, ca);
+            load_pw(cb_s, lane, cb);
+            const float saa = pw_dot(ca, ca) + 1e-8f, sbb = pw_dot(cb, cb) + 1e-8f;
+            const float sim_ab = pw_dot(ca, cb) / powf_half_glibc(saa) / powf_half_glibc(sbb);   // every wave, identical
+            if (sim_ab >= merge_thr) {
+                __syncthreads();
+                if (tid == 0) { seg[2 * si + 2] = a0; merged[si] = 1; }
+                __syncthreads();
+                continue;
+            }
+            const float nca = sqrtf(saa), ncb = sqrtf(sbb);
+            for (int j = wave; j < w; j += 4) {
+                float x[12];
+                if (j == wave) {
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) x[k] = xw[k];
+                } else load_pw(states + (size_t)(ws + j) * SEG_D, lane, x);
+                const float nx = nsq[ws + j - base];
+                const float sp = pw_dot(x, ca) / nx / nca;
+                const float sn = pw_dot(x, cb) / nx / ncb;
+                if (lane == 0) { simp_s[j] = sp; simn_s[j] = sn; }
+            }
+            __syncthreads();
+            for (int i = tid; i < w; i += 256) sweep_s[i] = np_sum_thread(simp_s, i) + np_sum_thread(simn_s + i, w - i);
+            __syncthreads();
+            if (tid == 0) {
+                int best = 0;
+                float bv = sweep_s[0];
+                if (!(bv != bv)) {
+                    for (int i = 1; i < w; ++i) {
+                        const float v = sweep_s[i];
+                        if (!(v <= bv)) { bv = v; best = i; if (v != v) break; }
+                    }
+                }
+                seg[2 * si + 1] = ws + best;
+                seg[2 * si + 2] = ws + best;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        // ---- the run's segments into the utterance's slot table (slots base .. base + nseg - 1; the rest of the run's slots stay dead)
+        for (int k = tid; k < nseg; k += 256) {
+            if constexpr (!GS) { g_slot[2 * (size_t)(base + k)] = seg[2 * k]; g_slot[2 * (size_t)(base + k) + 1] = seg[2 * k + 1]; }
+            g_live[base + k] = merged[k] ? 0 : 1;
+        }
+    }
+}
+
+// live slots in slot order = the reference's table (np.array(segments) without the merged indices, segment_utils.py:130-131)
+__global__ __launch_bounds__(256) void segment_compact_kernel(int T, const float* __restrict__ scratch, size_t slab, int64_t* __restrict__ seg_out,
+                                                              int* __restrict__ nseg_out) {
+    __shared__ int cnt_s[4];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* sl = scratch + (size_t)b * slab;
+    const int* g_slot = (const int*)(sl + 2 * (size_t)T);
+    const int* g_live = g_slot + 2 * ((size_t)T + 1);
+    int running = 0;
+    for (int c0 = 0; c0 < T; c0 += 256) {
+        const int i = c0 + tid;
+        const bool lv = i < T && g_live[i] != 0;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(lv);
+        if (lane == 0) cnt_s[wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += cnt_s[w];
+        const int tot = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+        if (lv) {
+            const int n = off + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            seg_out[((size_t)b * T + n) * 2 + 0] = g_slot[2 * (size_t)i];
+            seg_out[((size_t)b * T + n) * 2 + 1] = g_slot[2 * (size_t)i + 1];
+        }
+        running += tot;
+        __syncthreads();
+    }
+    if (tid == 0) nseg_out[b] = running;
+}
+
+// states[s:e].mean(0) per segment (sylber.py:133): one wave per segment, the utterance's segments spread over gridDim.x workgroups
+__global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restrict__ hidden, int T, const int64_t* __restrict__ seg_out,
+                                                           const int* __restrict__ nseg_out, float* __restrict__ feat_out) {
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* states = hidden + (size_t)b * T * SEG_D;
+    const int n = nseg_out[b];
+    for (int k = blockIdx.x * 4 + wave; k < n; k += gridDim.x * 4) {
+        const int s = (int)seg_out[((size_t)b * T + k) * 2], e = (int)seg_out[((size_t)b * T + k) * 2 + 1];
+        mean_rows<64>(states, s, e, lane, feat_out + ((size_t)b * T + k) * SEG_D);
+    }
+}
+
+
 static size_t segment_tsized_floats(int T) { return 5 * (size_t)T + 5 * ((size_t)T + 1); }
 static size_t segment_lds_bytes(int T) { return ((size_t)2 * SEG_D + 8 + segment_tsized_floats(T)) * 4; }
 static size_t segment_slab_floats(int T) { return (segment_tsized_floats(T) + 63) & ~(size_t)63; }
 
-// floats of global scratch launch_segment needs (0 while an utterance's bookkeeping fits the 160 KiB of LDS)
+// floats of global scratch launch_segment needs: the wide path's per-utterance slab (norms, slot table, and the bookkeeping of runs
+// beyond SEG_LCAP frames); it also covers the one-workgroup-per-utterance kernel's slab for utterances beyond 3940 frames
 size_t segment_scratch_floats(int B, int T, int D) {
     (void)D;
-    return segment_lds_bytes(T) > 160 * 1024 ? (size_t)B * segment_slab_floats(T) : 0;
+    const size_t a = seg_wide_slab_floats(T), o = segment_slab_floats(T);
+    return (size_t)B * (a > o ? a : o);
 }
 
+// mode 0: the wide path (norms / runs / compaction / pooling on all CUs); mode -1: one workgroup per utterance (rounds 1-5; A/B and bitwise reference)
 int launch_segment(const float* hidden, int B, int T, int D, float norm_thr, float merge_thr, int64_t* seg, int* nseg,
-                   float* feat, float* scratch, hipStream_t s) {
+                   float* feat, float* scratch, hipStream_t s, int mode) {
     if (D != SEG_D) { syl_set_error("launch_segment", "feature dim must be 768"); return 1; }
     if (T < 1) { syl_set_error("launch_segment", "T must be >= 1"); return 1; }
+    if (mode >= 0) {
+        if (!scratch) { syl_set_error("launch_segment", "the wide path needs its scratch slab (segment_scratch_floats)"); return 1; }
+        const size_t slab = seg_wide_slab_floats(T);
+        const long rows = (long)B * T;
+        hipLaunchKernelGGL(segment_norms_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, hidden, B, T, scratch, slab);
+        int G = (T + 7) / 8; G = G < 8 ? 8 : (G > 128 ? 128 : G);
+        const int list_cap = ((T + 1) / 2 + G - 1) / G + 1;
+        const size_t lds_l = ((size_t)2 * SEG_D + 16 + list_cap + 5 * SEG_LCAP + 5 * (SEG_LCAP + 1)) * 4;
+        const size_t lds_g = ((size_t)2 * SEG_D + 16 + list_cap) * 4;
+        if (lds_l > 64 * 1024) {
+            static PerDeviceOnce once;
+            if (once.need()) HIP_TRY(hipFuncSetAttribute((const void*)segment_runs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        hipLaunchKernelGGL(segment_runs_kernel<false>, dim3(G, B), dim3(256), lds_l, s, hidden, T, norm_thr, merge_thr, scratch, slab, list_cap);
+        if (T > SEG_LCAP)
+            hipLaunchKernelGGL(segment_runs_kernel<true>, dim3(G, B), dim3(256), lds_g, s, hidden, T, norm_thr, merge_thr, scratch, slab, list_cap);
+        hipLaunchKernelGGL(segment_compact_kernel, dim3(B), dim3(256), 0, s, T, scratch, slab, seg, nseg);
+        if (feat) {
+            int PX = (T + 15) / 16; PX = PX < 1 ? 1 : (PX > 64 ? 64 : PX);
+            hipLaunchKernelGGL(segment_pool_kernel, dim3(PX, B), dim3(256), 0, s, hidden, T, seg, nseg, feat);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const size_t lds = segment_lds_bytes(T);
     if (lds <= 160 * 1024) {
         static PerDeviceOnce once;                       // raise the limit to the full 160 KiB once per device

@@ -245,7 +245,8 @@ class HubertEncoderHIP:
                 out=None):
         """hidden: [B, T, 768] float32 device.  Returns (segments [B,T,2] int64, nseg [B] int32, feats [B,T,768]).
         Runs on the CURRENT torch stream; it touches no encoder workspace, so a caller may run it on a side
-        stream concurrently with the next batch's forward (32 workgroups vs a 256-CU chip)."""
+        stream concurrently with the next batch's forward; it uses the handle's own scratch slab (frame norms, slot table), so the
+        segment calls of one handle must be ordered on one stream."""
         assert hidden.is_cuda and hidden.dtype == torch.float32 and hidden.is_contiguous()
         B, T, D = hidden.shape
         if out is not None:
@@ -309,6 +310,16 @@ class Segmenter:
         self._kcap_seen = 128                                                    # segment slots per utterance the next block is sized for
         self._kcap_recent = collections.deque(maxlen=16)                         # per-batch maxima of the last 16 batches (sizing decays with them)
         self._overlap_d2h = bool(kwargs.get("overlap_d2h", True))               # hidden-state D2H under the segmenter (A/B switch)
+        # which keys of the reference's dict (sylber.py:134-138) a call returns.  Default = all three, the reference's contract.  A caller
+        # that consumes only the tables / pooled features (tokenisation, the resynthesis front half) can drop "hidden_states": that skips
+        # the 49 MB device-to-host copy of a 32 x 10 s batch (0.87 ms of a 7.9 ms call) and its page-locked block (round 6)
+        outs = tuple(kwargs.get("outputs", ("segments", "segment_features", "hidden_states")))
+        bad = [o for o in outs if o not in ("segments", "segment_features", "hidden_states")]
+        if bad or "segments" not in outs:
+            raise ValueError("outputs must contain 'segments' and may add 'segment_features', 'hidden_states' (got %r)" % (outs,))
+        self.outputs = outs
+        self._want_hidden = "hidden_states" in outs
+        self._want_feats = "segment_features" in outs
 
     @staticmethod
     def _load_state_dict(model_ckpt, encoding_layer):
@@ -390,6 +401,11 @@ class Segmenter:
                     f.result()
                     batch[lo:hi].copy_(stage[lo:hi], non_blocking=True)
             slot["event"].record(torch.cuda.current_stream(dev))
+            gtr = self.__dict__.get("_gpu_trace")
+            if gtr is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(dev))
+                gtr.append(("H2D done", ev))
         else:
             batch = torch.zeros(len(rows), lmax, dtype=torch.float32, device=dev)
             for i, r in enumerate(rows):
@@ -450,9 +466,17 @@ class Segmenter:
     def __call__(self, wav_file=None, wav=None, in_second=True):
         tr = self.__dict__.get("_trace")                     # tools/api_timeline.py: list of (label, host time) marks
         mark = (lambda name: tr.append((name, time.perf_counter()))) if tr is not None else (lambda name: None)
+        gtr = self.__dict__.get("_gpu_trace")                # tools/api_timeline.py: list of (label, timing event) recorded on the streams involved
+        def gmark(name, stream=None):
+            if gtr is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(stream if stream is not None else torch.cuda.current_stream(self.speech_model.device))
+                gtr.append((name, ev))
         mark("enter")
+        gmark("enter")
         batch_wavs, is_batch = self._collect(wav_file, wav)
         hidden, _ = self.encode_batch(batch_wavs)
+        gmark("forward done")
         mark("padded, H2D and forward issued")
         # D2H (sylber.py:122-138's .cpu().numpy()) into ONE leased page-locked block (PinnedOutputPool: persistent blocks, no
         # page-locking per call); the numpy results are views of that block -- no second host copy of the 49 MB of hidden
@@ -467,10 +491,11 @@ class Segmenter:
 
         def al(n):
             return (n + 255) & ~255
-        hid_bytes = al(B * T * D * 4)
+        want_h, want_f = self._want_hidden, self._want_feats
+        hid_bytes = al(B * T * D * 4) if want_h else 0
 
         def sizes(kc):
-            return hid_bytes, hid_bytes + al(B * kc * 2 * 8), hid_bytes + al(B * kc * 2 * 8) + al(B * kc * D * 4)
+            return hid_bytes, hid_bytes + al(B * kc * 2 * 8), hid_bytes + al(B * kc * 2 * 8) + (al(B * kc * D * 4) if want_f else 0)
         kcap = min(T, self._kcap_seen)
         o_seg, o_feat, need = sizes(kcap)
         lease = self.out_pool.lease(need) if self.output_memory == "pinned" else None
@@ -481,12 +506,14 @@ class Segmenter:
             copy_s = self._copy_stream = torch.cuda.Stream(device=dev)
         fwd_done = self.__dict__.setdefault("_ev_fwd", torch.cuda.Event())
         fwd_done.record(cur)
-        if self._overlap_d2h:
+        if self._overlap_d2h and want_h:
             with torch.cuda.stream(copy_s):
                 copy_s.wait_event(fwd_done)
                 blk[:B * T * D * 4].view(torch.float32).view(B, T, D).copy_(hidden, non_blocking=True)
+                gmark("hidden states D2H done", copy_s)
             hidden.record_stream(copy_s)
-        seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold)
+        seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold, with_features=want_f)
+        gmark("boundary detection done")
         nseg_pin = self._nseg_pinned(B)
         nseg_pin.copy_(nseg, non_blocking=True)
         counted = self.__dict__.setdefault("_ev_counts", torch.cuda.Event())
@@ -501,7 +528,7 @@ class Segmenter:
         self._note_segments(k)
         if k > kcap:                                         # more segments than the recent batches had: the tables get their own block
             kcap = min(T, (k + 63) & ~63)
-            t_seg, t_feat, t_need = al(0), al(B * kcap * 2 * 8), al(B * kcap * 2 * 8) + al(B * kcap * D * 4)
+            t_seg, t_feat, t_need = al(0), al(B * kcap * 2 * 8), al(B * kcap * 2 * 8) + (al(B * kcap * D * 4) if want_f else 0)
             tl = self.out_pool.lease(t_need) if handed else None
             if tl is not None:
                 towner, tblk = tl
@@ -509,26 +536,29 @@ class Segmenter:
                 pb = torch.empty(t_need, dtype=torch.uint8, pin_memory=True)
                 towner, tblk = pb.numpy(), pb
             o_seg, o_feat = t_seg, t_feat
-        if not self._overlap_d2h:
+        if not self._overlap_d2h and want_h:
             blk[:B * T * D * 4].view(torch.float32).view(B, T, D).copy_(hidden, non_blocking=True)
         tblk[o_seg:o_seg + B * k * 2 * 8].view(torch.int64).view(B, k, 2).copy_(seg[:, :k], non_blocking=True)
-        tblk[o_feat:o_feat + B * k * D * 4].view(torch.float32).view(B, k, D).copy_(feats[:, :k], non_blocking=True)
+        if want_f:
+            tblk[o_feat:o_feat + B * k * D * 4].view(torch.float32).view(B, k, D).copy_(feats[:, :k], non_blocking=True)
+        gmark("tables D2H done")
         cur.wait_stream(copy_s)
         cur.synchronize()
         mark("all D2H done")
-        hidden_h = owner[:B * T * D * 4].view(np.float32).reshape(B, T, D)
+        hidden_h = owner[:B * T * D * 4].view(np.float32).reshape(B, T, D) if want_h else None
         seg_h = towner[o_seg:o_seg + B * k * 2 * 8].view(np.int64).reshape(B, k, 2)
-        feats_h = towner[o_feat:o_feat + B * k * D * 4].view(np.float32).reshape(B, k, D)
+        feats_h = towner[o_feat:o_feat + B * k * D * 4].view(np.float32).reshape(B, k, D) if want_f else None
         outputs = []
         for i in range(B):
             n = int(nseg_h[i])
             segments = seg_h[i, :n].copy() if n > 0 else np.array([])
-            outputs.append({
-                "segments": segments * 1.0 / FRAME_RATE if in_second else segments,
+            o = {"segments": segments * 1.0 / FRAME_RATE if in_second else segments}
+            if want_f:
                 # (a view of the leased block, like hidden_states; a scratch block is reused by the next call, so its rows are copied)
-                "segment_features": (feats_h[i, :n] if handed else feats_h[i, :n].copy()) if n > 0 else np.array([]),
-                "hidden_states": hidden_h[i] if handed else hidden_h[i].copy(),
-            })
+                o["segment_features"] = (feats_h[i, :n] if handed else feats_h[i, :n].copy()) if n > 0 else np.array([])
+            if want_h:
+                o["hidden_states"] = hidden_h[i] if handed else hidden_h[i].copy()
+            outputs.append(o)
         mark("dicts built")
         return outputs if is_batch else outputs[0]
 
@@ -549,6 +579,7 @@ class Segmenter:
             from .streams import concurrent_streams
             st = self._stream_streams = concurrent_streams(2, dev, avoid=[cur])        # H2D, D2H
         h2d, d2h = st
+        want_h, want_f = self._want_hidden, self._want_feats
         counter = {"in": 0}
         NSET = 3                                              # device buffer sets = batches issued ahead + 1
 
@@ -615,7 +646,7 @@ class Segmenter:
             with torch.cuda.stream(cur):
                 hidden = self.speech_model.forward(batch, lengths, out=flat(d, "hid", B_ * T_ * 768, torch.float32).view(B_, T_, 768))
                 out = (flat(d, "seg", B_ * T_ * 2, torch.int64).view(B_, T_, 2), flat(d, "nseg", B_, torch.int32),
-                       flat(d, "feat", B_ * T_ * 768, torch.float32).view(B_, T_, 768))
+                       flat(d, "feat", B_ * T_ * 768, torch.float32).view(B_, T_, 768) if want_f else None)
                 seg, nseg, feats = self.speech_model.segment(hidden, self.norm_threshold, self.merge_threshold, out=out)
             tr = self.__dict__.get("_trace")                  # tools/api_stream_timeline.py: (label, host time[, event]) marks
             done = torch.cuda.Event(enable_timing=tr is not None)
@@ -627,10 +658,10 @@ class Segmenter:
             def al(n):
                 return (n + 255) & ~255
             kcap = min(T, self._kcap_seen)
-            o_cnt = al(B * T * D * 4)
+            o_cnt = al(B * T * D * 4) if want_h else 0
             o_seg = o_cnt + al(B * 4)
             o_feat = o_seg + al(B * kcap * 2 * 8)
-            need = o_feat + al(B * kcap * D * 4)
+            need = o_feat + (al(B * kcap * D * 4) if want_f else 0)
             lease = self.out_pool.lease(need) if self.output_memory == "pinned" else None
             handed = lease is not None
             if handed:
@@ -643,10 +674,12 @@ class Segmenter:
                 owner = blk.numpy()
             with torch.cuda.stream(d2h):
                 d2h.wait_event(done)
-                blk[:B * T * D * 4].view(torch.float32).view(B, T, D).copy_(hidden, non_blocking=True)
+                if want_h:
+                    blk[:B * T * D * 4].view(torch.float32).view(B, T, D).copy_(hidden, non_blocking=True)
                 blk[o_cnt:o_cnt + B * 4].view(torch.int32).copy_(nseg, non_blocking=True)
                 blk[o_seg:o_seg + B * kcap * 2 * 8].view(torch.int64).view(B, kcap, 2).copy_(seg[:, :kcap], non_blocking=True)
-                blk[o_feat:o_feat + B * kcap * D * 4].view(torch.float32).view(B, kcap, D).copy_(feats[:, :kcap], non_blocking=True)
+                if want_f:
+                    blk[o_feat:o_feat + B * kcap * D * 4].view(torch.float32).view(B, kcap, D).copy_(feats[:, :kcap], non_blocking=True)
                 out_ev = torch.cuda.Event()
                 out_ev.record(d2h)
             d["in_free"], d["out_free"] = done, out_ev
@@ -673,26 +706,28 @@ class Segmenter:
                 seg, feats = t["dev"]
                 kslots = min(T, (k + 63) & ~63)
                 o_seg, o_feat = 0, (B * kslots * 2 * 8 + 255) & ~255
-                pb = torch.empty(o_feat + B * kslots * D * 4, dtype=torch.uint8, pin_memory=True)
+                pb = torch.empty(o_feat + (B * kslots * D * 4 if want_f else 0), dtype=torch.uint8, pin_memory=True)
                 pb[o_seg:o_seg + B * kslots * 2 * 8].view(torch.int64).view(B, kslots, 2).copy_(seg[:, :kslots], non_blocking=True)
-                pb[o_feat:o_feat + B * kslots * D * 4].view(torch.float32).view(B, kslots, D).copy_(feats[:, :kslots], non_blocking=True)
+                if want_f:
+                    pb[o_feat:o_feat + B * kslots * D * 4].view(torch.float32).view(B, kslots, D).copy_(feats[:, :kslots], non_blocking=True)
                 torch.cuda.current_stream(dev).synchronize()
                 towner, tcopy = pb.numpy(), False
             else:
                 tcopy = not handed
             t.pop("dev")
-            hidden_h = owner[:B * T * D * 4].view(np.float32).reshape(B, T, D)
+            hidden_h = owner[:B * T * D * 4].view(np.float32).reshape(B, T, D) if want_h else None
             seg_h = towner[o_seg:o_seg + B * kslots * 2 * 8].view(np.int64).reshape(B, kslots, 2)
-            feats_h = towner[o_feat:o_feat + B * kslots * D * 4].view(np.float32).reshape(B, kslots, D)
+            feats_h = towner[o_feat:o_feat + B * kslots * D * 4].view(np.float32).reshape(B, kslots, D) if want_f else None
             outputs = []
             for i in range(B):
                 n = int(nseg_h[i])
                 segments = seg_h[i, :n].copy() if n > 0 else np.array([])
-                outputs.append({
-                    "segments": segments * 1.0 / FRAME_RATE if in_second else segments,
-                    "segment_features": (feats_h[i, :n].copy() if tcopy else feats_h[i, :n]) if n > 0 else np.array([]),
-                    "hidden_states": hidden_h[i] if handed else hidden_h[i].copy(),
-                })
+                o = {"segments": segments * 1.0 / FRAME_RATE if in_second else segments}
+                if want_f:
+                    o["segment_features"] = (feats_h[i, :n].copy() if tcopy else feats_h[i, :n]) if n > 0 else np.array([])
+                if want_h:
+                    o["hidden_states"] = hidden_h[i] if handed else hidden_h[i].copy()
+                outputs.append(o)
             return outputs[0] if t["single"] else outputs
 
         try:

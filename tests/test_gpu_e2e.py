@@ -308,6 +308,37 @@ def test_stream_of_batches_equals_calls(sd):
     assert all(np.array_equal(a["segments"], b["segments"] / 50.0) for a, b in zip(sec[0], ref[0]))
 
 
+def test_outputs_opt_in_skips_hidden_states(sd):
+    """round 6: `outputs=` chooses which keys of the reference's dict (sylber.py:134-138) a call returns.  The default is the reference's
+    contract (all three); without "hidden_states" the 49 MB D2H of a 32 x 10 s batch and its page-locked block are skipped, without
+    "segment_features" the pooling launch too -- the keys that ARE returned hold the same bits, from __call__ and from stream, in both
+    output-memory modes, also through the tables' second fetch"""
+    from sylber_amd import Segmenter
+    rng = np.random.default_rng(5)
+    batches = [[syllable_wave(int(rng.integers(6000, 50000)), 300 + 10 * j + i) for i in range(int(rng.integers(1, 6)))] for j in range(4)]
+    batches.append([syllable_wave(150000, 340 + i) for i in range(2)])
+    full = Segmenter(model_ckpt=sd)
+    assert full.outputs == ("segments", "segment_features", "hidden_states")
+    ref = [full(wav=b, in_second=False) for b in batches]
+    for outs in (("segments", "segment_features"), ("segments",), ("segments", "hidden_states")):
+        for mode in ("pinned", "pageable"):
+            S = Segmenter(model_ckpt=sd, outputs=outs, output_memory=mode)
+            S._kcap_seen = 16
+            for src in ("call", "stream"):
+                got_all = [S(wav=b, in_second=False) for b in batches] if src == "call" else list(S.stream(batches, in_second=False))
+                for got, exp in zip(got_all, ref):
+                    for g, e in zip(got, exp):
+                        assert set(g) == set(outs), (outs, mode, src)
+                        for k in outs:
+                            assert np.array_equal(g[k], e[k], equal_nan=True), (outs, mode, src, k)
+    lean = Segmenter(model_ckpt=sd, outputs=("segments", "segment_features"))
+    lean(wav=batches[0])
+    with pytest.raises(ValueError):
+        Segmenter(model_ckpt=sd, outputs=("hidden_states",))
+    with pytest.raises(ValueError):
+        Segmenter(model_ckpt=sd, outputs=("segments", "logits"))
+
+
 def test_stream_abandoned_early_then_reused(sd):
     """a consumer that stops early (break / close() / an exception) leaves batches in flight whose leased page-locked
     blocks the D2H stream is still writing; the generator's exit waits for those copies before the leases go back, the budget and

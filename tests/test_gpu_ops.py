@@ -91,7 +91,7 @@ def test_attention(lib, B, T, valid, qw):
     assert (o.cpu() - ref).pow(2).mean().sqrt().item() < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11, 40, 60, 80, 85, 90, 91, 95, 97])
+@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11, 40, 51, 57, 60, 80, 85, 90, 91, 95, 97])
 def test_linear_every_tile_config(lib, cfg):
     """every GEMM tile configuration (4-wave 2/3-slot rings, 8-wave staggered big tiles) gives the same
     result, including ragged M / N tails and a strided (overlapping-row) activation operand"""
@@ -129,7 +129,7 @@ def test_linear_split16(lib, cfg):
         assert err < 12 * (f32 - ref).abs().max().item() + 2e-6, (cfg, M, N, K)     # fp32 accumulation noise (a longer serial chain than the CPU's blocked sums)
 
 
-@pytest.mark.parametrize("cfg", [40, 60, 80, 85, 90, 91, 95, 97])
+@pytest.mark.parametrize("cfg", [40, 51, 57, 60, 80, 85, 90, 91, 95, 97])
 def test_gemm8_schedule_variants_bitwise(lib, cfg):
     """the K-loop schedule variants of the 8-wave kernel (where the LDS-DMA of step s+3 is issued) contract in the same
     order: bit-identical to the default schedule on a full-size launch, run to run (a hand-off race would show here)"""
@@ -230,7 +230,7 @@ def test_conv3_layer_every_tile(lib):
         assert (got - ref).abs().max().item() < 2e-2 and (got - ref).pow(2).mean().sqrt().item() < 3e-3, M
 
 
-@pytest.mark.parametrize("tile", [4, 90, 91, 96])
+@pytest.mark.parametrize("tile", [4, 51, 90, 91, 96])
 def test_residual_gemm_tiles(lib, tile):
     """the residual GEMM of an encoder block (out-projection K = 768, FFN2 K = 3072: EPI_F32_RESLN, in place) against torch, and
     bit for bit against the HIP-scheduled 128x192 kernel -- tile 91 with whole tiles runs the K loop that also prefetches the
@@ -254,7 +254,7 @@ def test_residual_gemm_tiles(lib, tile):
         assert (outs[1].cpu() - ref).abs().max().item() < 3e-3, (tile, M, N, K)
 
 
-@pytest.mark.parametrize("tile", [80, 85, 86, 90, 91, 95, 97])
+@pytest.mark.parametrize("tile", [51, 57, 80, 85, 86, 90, 91, 95, 97])
 def test_asm_tiles_persistent_seams(lib, tile):
     """the hand-scheduled kernels as persistent workgroups (more tiles than CUs: the next tile's operands requested before
     the epilogue, counted waits across its stores) return bit for bit what the HIP 8-wave kernel returns, with whole tiles
@@ -270,3 +270,62 @@ def test_asm_tiles_persistent_seams(lib, tile):
             c = torch.full((M, N), -1, dtype=torch.int16, device="cuda")
             _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, act, 0, tile, None), "op_linear16")
             assert torch.equal(c, ref), (tile, M, N, K)
+
+
+NOSPLIT, TAIL = 100000, lambda t: 100000 * (t + 2)      # `tile` argument: + 100000 = never split by rows; + 100000 (t + 2) = split, tail on tile t
+
+
+@pytest.mark.parametrize("tail", [3, 4, 0, 91, 97, 86, 51, 57])
+def test_tail_split_is_bitwise(lib, tail):
+    """round 6 tail policy (gemm_bf16.hip launch_f): a launch whose tile count is not a whole number of rounds of 256 persistent workgroups
+    runs the rows of its full rounds on the chosen tile and the remaining rows, as a second launch over rows [M1, M), on another tile.  Every
+    output element is one fp32 chain over K in the same order whatever tile computes it, so the split changes no bit: 16-bit GELU epilogue
+    (FFN1 / conv shape), the in-place fp32 residual epilogue (out-proj / FFN2, incl. the loop that prefetches the residual rows), the plain
+    fp32 epilogue and the 3-tap conv K order, each with whole and with ragged last row tiles, forced main tile and automatic."""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(600 + tail)
+    # ---- EPI_BF16 + GELU: 94 / 75.x row tiles x 12 column tiles of 256 x 256 = 4.4 / 3.5 rounds
+    for (M, N, K, main) in [(256 * 94, 3072, 768, 97), (19237, 3072, 768, 97), (256 * 94, 3072, 768, -1), (256 * 37, 2304, 256, 91)]:
+        a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+        ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+        outs = []
+        for t in (9010 + NOSPLIT, (main if main >= 0 else 0) + (TAIL(tail) if main >= 0 else 0) + (-1 if main < 0 else 0)):
+            c = torch.full((M, N), -1, dtype=torch.int16, device="cuda")
+            _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 1, 0, t, None), "op_linear16")
+            outs.append(c)
+        assert torch.equal(outs[0], outs[1]), ("bf16", M, N, K, main, tail)
+    # ---- EPI_F32_RESLN in place: 1.47 rounds of 256 x 192 (the 8 x 60 s out-projection / FFN2) and a ragged M
+    for (M, N, K) in [(256 * 94, 768, 768), (256 * 94, 768, 3072), (256 * 70 + 100, 768, 768)]:
+        a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+        pre = torch.randn(M, N, generator=g) * 2.0 + 0.3
+        gamma = 1.0 + 0.2 * torch.randn(N, generator=g); beta = 0.1 * torch.randn(N, generator=g)
+        mean = pre.mean(-1); rstd = (pre.var(-1, unbiased=False) + 1e-5).rsqrt()
+        stats = torch.stack([mean, rstd], -1).contiguous()
+        ad, wd, bd, gd, bed, sd_ = a.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), stats.cuda()
+        outs = []
+        for t in (9004 + NOSPLIT, 91 + TAIL(tail), -1):
+            c = pre.clone().cuda()
+            _lib.check(lib.sylber_op_linear_resln(_p(ad), _p(wd), _p(bd), _p(c), _p(sd_), _p(gd), _p(bed), M, N, K, t, None), "op_linear_resln")
+            outs.append(c)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), ("resln", M, N, K, tail)
+    # ---- plain fp32 epilogue
+    M, N, K = 256 * 41 + 17, 2304, 768
+    a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+    outs = []
+    for t in (9004 + NOSPLIT, 85 + TAIL(tail)):
+        c = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 0, 0, t, None), "op_linear")
+        outs.append(c)
+    assert torch.equal(outs[0], outs[1]), ("f32", tail)
+    # ---- 3-tap conv K order (conv5 of 8 x 60 s: 1.47 rounds of 256 x 256); a tail tile without that order falls back as documented
+    M = 256 * 188
+    R = 2 * M + 1
+    x = torch.randn(R, 512, generator=g); wc = (torch.randn(512, 512, 3, generator=g) / (3 * 512) ** 0.5).contiguous()
+    xd = x.cuda()
+    outs = []
+    for t in (9010 + NOSPLIT, 97 + TAIL(tail), -1):
+        y = torch.full((M, 512), -1, dtype=torch.int16, device="cuda")
+        _lib.check(lib.sylber_op_conv3(_p(xd), ctypes.c_void_p(wc.data_ptr()), _p(y), R, M, t, None), "op_conv3")
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), ("conv3", tail)

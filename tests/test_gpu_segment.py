@@ -13,11 +13,16 @@ from sylber_amd.synth_states import syllable_states
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def enc():
+@pytest.fixture(scope="module", params=["wide", "per_utterance"])
+def enc(request):
+    """both implementations of sylber_segment: the wide path (round 6: frame norms / one workgroup per run of speech frames / compaction /
+    pooling on all CUs) and the one-workgroup-per-utterance kernel of rounds 1-5 (SYLBER_OPT_SEGMENT = -1) -- every case below is
+    checked bit for bit on each"""
     from sylber_amd import HubertEncoderHIP
     from sylber_amd.weights import synthetic_state_dict
-    return HubertEncoderHIP(synthetic_state_dict(0, num_layers=1), num_layers=1)
+    e = HubertEncoderHIP(synthetic_state_dict(0, num_layers=1), num_layers=1)
+    e.set_option(9, 0 if request.param == "wide" else -1)
+    return e
 
 
 def _run(enc, states_list, nt, mt):
@@ -52,7 +57,10 @@ def test_golden_cases_bit_exact(enc, golden_dir):
 
 def test_random_batches_vs_oracle(enc):
     for T, mode, seed0 in [(499, "normal", 100), (499, "edge", 200), (2999, "long", 300), (1000, "degenerate", 400),
-                           (37, "allspeech", 500)]:
+                           (37, "allspeech", 500), (1500, "allspeech", 600), (700, "allspeech", 650), (513, "allspeech", 660),
+                           (512, "allspeech", 670), (1, "allspeech", 680), (2, "normal", 690)]:
+        # (allspeech beyond 512 frames: ONE run of speech frames longer than the wide path keeps in LDS -> its global-slab launch;
+        #  "long": runs of several hundred frames on both sides of that limit in one utterance)
         sts = [syllable_states(T, seed0 + s, mode=mode) for s in range(8)]
         seg, nseg, feats = _run(enc, sts, 2.6, 0.8)
         for j, st in enumerate(sts):

@@ -6,7 +6,7 @@ line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split
 for rep in 1 2; do
   for args in "--no-overlap" "--no-overlap --batch 8 --clip-seconds 60"; do
     echo "== rep $rep  [$args]"
-    echo -n "ref          "; SYLBER_HIP_LIB=$(pwd)/sylber_amd/libsylber_hip_ref.so python bench.py --no-cpu-baseline --no-api $args 2>/dev/null | line
+    echo -n "ref          "; python tools/with_lib.py ref bench.py --no-cpu-baseline --no-api $args 2>/dev/null | line
     for v in $CODES; do
       echo -n "new opt 2=$v  "; python bench.py --no-cpu-baseline --no-api --opt 2=$v $args 2>/dev/null | line
     done

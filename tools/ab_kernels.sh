@@ -2,7 +2,7 @@
 # same-box A/B of two builds (runs ON THE GPU BOX): per-kernel ms per forward of the reference build (sylber_amd/libsylber_hip_ref.so)
 # and of the in-tree build, interleaved; extra arguments go to bench.py (e.g. --no-overlap)
 for rep in 1 2; do
-  SYLBER_HIP_LIB=$(pwd)/sylber_amd/libsylber_hip_ref.so python bench.py --no-cpu-baseline --no-api "$@" 2>/dev/null | tail -1 > /tmp/ab_ref.json
+  python tools/with_lib.py ref bench.py --no-cpu-baseline --no-api "$@" 2>/dev/null | tail -1 > /tmp/ab_ref.json
   python bench.py --no-cpu-baseline --no-api "$@" 2>/dev/null | tail -1 > /tmp/ab_new.json
   python - <<'PY'
 import json

@@ -18,6 +18,6 @@ for rep in range(2):
 PY
 line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms_per_forward']; r=d['roofline']; print('%8.1f audio-s/s  %6.3f ms/step  gemm_out %.4f  gemm_ffn2 %.4f ms  encoder gemms %.4f' % (d['value'], d['ms_per_step'], k['gemm_out'], k['gemm_ffn2'], r['encoder_gemms']['frac']))"; }
 for rep in 1 2 3; do
-  echo -n "ref lib            "; SYLBER_HIP_LIB=$(pwd)/sylber_amd/libsylber_hip_ref.so python bench.py --no-cpu-baseline --no-api "$@" 2>/dev/null | line
+  echo -n "ref lib            "; python tools/with_lib.py ref bench.py --no-cpu-baseline --no-api "$@" 2>/dev/null | line
   echo -n "new                "; python bench.py --no-cpu-baseline --no-api "$@" 2>/dev/null | line
 done

@@ -19,7 +19,7 @@ for (B, T) in [(32, 499), (8, 2999)]:
     ms = ctypes.c_float()
     _lib.check(lib.sylber_debug_attention_bench(B, T, 0, -20, ctypes.byref(ms)), "bench")
     print("B=%d T=%d asm on ALL-ZERO operands (DVFS probe): %.1f us" % (B, T, ms.value * 1e3), flush=True)
-if os.environ.get("SYLBER_HIP_LIB", "").endswith("_exp.so"):
+if os.environ.get("SYLBER_DEV_LIB", "").endswith("_exp.so"):
     names = {1: "no exp", 2: "no softmax", 3: "no MFMA", 4: "no frag reads", 5: "no DMA/barrier", 6: "no max", 7: "MFMA + softmax only", 8: "MFMA only", 9: "data movement only"}
     for (B, T) in [(32, 499), (8, 2999)]:
         for var in sorted(names):

@@ -783,12 +783,18 @@ def emit(fmt, var=0):
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_attn_asm.py -- do not edit; the schedule is documented there.\n")
         f.write("// Expects MF (MFMA mnemonic string literal) and the operands named below in scope.\n")
+        # M0 is re-pointed for every LDS-DMA block; it is a RESERVED register (hipcc refuses it as a clobber), so the statement saves it in
+        # a scalar of its own and restores it (+ the wait state an M0 write needs before the compiler's next LDS-DMA / movrel)
+        f.write("{ int m0_keep_;\n")
         f.write("asm volatile(\n")
+        f.write('    "s_mov_b32 %[m0k], m0\\n"\n')
         for l in lines:
             f.write("    " + l + "\n")
-        f.write("    : " + ",\n      ".join(OPERANDS_OUT) + "\n")
+        f.write('    "s_mov_b32 m0, %[m0k]\\n"\n')
+        f.write('    "s_nop 0\\n"\n')
+        f.write("    : " + ",\n      ".join(OPERANDS_OUT + ['[m0k] "=&s"(m0_keep_)']) + "\n")
         f.write("    : " + ",\n      ".join(OPERANDS_IN) + "\n")
-        f.write('    : "scc", "vcc", "memory", ' + clob + ");   // m0 is written too (reserved register)\n")
+        f.write('    : "scc", "vcc", "memory", ' + clob + "); }\n")
     print("wrote", os.path.normpath(dst), len(lines), "lines")
     return prog
 

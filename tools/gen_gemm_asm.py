@@ -19,7 +19,7 @@ Slot (s+3)&3 = (s-1)&3 was last read during step s-2 and those reads were waited
 """
 import os
 
-OUTDIR = os.environ.get("GEN_GEMM_ASM_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sylber_amd", "build", "gen")
+OUTDIR = os.environ.get("GEN_GEMM_ASM_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sylber_amd", "build", "gen_exp")
 
 FM = FN = 4
 SLOT = 32768
@@ -32,6 +32,22 @@ def mfma(P, kk, fm, fn):
 
 def q(s):
     return f'"{s}\\n"'
+
+
+def write_asm(f, L, outs, ins, clobbers='"scc", "memory"'):
+    """One asm statement that leaves M0 as it found it.  The loops re-point M0 for every LDS-DMA instruction; M0 is a RESERVED register
+    (hipcc refuses it as a clobber: "may lead to undefined behaviour"), so the statement saves it in a scalar of its own and puts it back
+    (s_nop: an M0 write needs a wait state before the compiler's next LDS-DMA / movrel) -- the surrounding code may keep a live M0."""
+    f.write("{ int m0_keep_;\n")
+    f.write("asm volatile(\n")
+    f.write("    " + q("s_mov_b32 %[m0k], m0") + "\n")
+    for l in L:
+        f.write("    " + l + "\n")
+    f.write("    " + q("s_mov_b32 m0, %[m0k]") + "\n")
+    f.write("    " + q("s_nop 0") + "\n")
+    f.write("    : " + ",\n      ".join(list(outs) + ['[m0k] "=&s"(m0_keep_)']) + "\n")
+    f.write("    : " + ",\n      ".join(ins) + "\n")
+    f.write("    : " + clobbers + "); }\n")
 
 
 def reads(Q, slot):
@@ -162,12 +178,7 @@ def emit(var):
         f.write("// GENERATED by tools/gen_gemm_asm.py -- do not edit; the schedule is documented there.\n")
         f.write("// Expects: MF (mnemonic string literal), acc[4][4], fx[2][2][4], fw[2][2][4], ax/axh/aw/awh[2], voff[8], rx, rw,\n")
         f.write("// lbase, koff, nloop in scope.\n")
-        f.write("asm volatile(\n")
-        for l in L:
-            f.write("    " + l + "\n")
-        f.write("    : " + ",\n      ".join(outs) + "\n")
-        f.write("    : " + ",\n      ".join(ins) + "\n")
-        f.write('    : "scc", "memory");   // m0 is written too: a reserved register the compiler re-materialises before each of its own uses\n')
+        write_asm(f, L, outs, ins)
     print("wrote", os.path.normpath(dst), len(L), "lines")
 
 
@@ -297,12 +308,7 @@ def emit_k64(var, opts, fn=4, nw=4):
     dst = os.path.join(OUTDIR, name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (K64 layout) -- do not edit; the schedule is documented there.\n")
-        f.write("asm volatile(\n")
-        for l in L:
-            f.write("    " + l + "\n")
-        f.write("    : " + ",\n      ".join(outs) + "\n")
-        f.write("    : " + ",\n      ".join(ins) + "\n")
-        f.write('    : "scc", "memory");   // m0 is written too (reserved register, re-materialised by the compiler before its own uses)\n')
+        write_asm(f, L, outs, ins)
     print("wrote", os.path.normpath(dst), len(L), "lines")
 
 
@@ -322,7 +328,7 @@ X3 = {}
 def x3_reads(setq, wslot, kk):
     out = []
     h = "h" if wslot else ""
-    for f in range(4):
+    for f in range(X3["fm"]):
         out.append(q(f"ds_read_b128 %[x{setq}{f}], %[ax{kk}] offset:{f * 4096}"))
     for f in range(X3["fn"]):
         out.append(q(f"ds_read_b128 %[w{setq}{f}], %[aw{kk}{h}] offset:{f * 4096}"))
@@ -330,8 +336,8 @@ def x3_reads(setq, wslot, kk):
 
 
 def x3_dma_w(i, wslot):
-    nw, nxp = X3["nw"], 32 // X3["nw"]
-    return (q(f"s_add_u32 m0, %[lbase], {98304 + wslot * X3['bn'] * 128 + (i - nxp) * nw * 1024}"),
+    nw, nxp = X3["nw"], 8 * X3["fm"] // X3["nw"]
+    return (q(f"s_add_u32 m0, %[lbase], {3 * X3['xt'] + wslot * X3['bn'] * 128 + (i - nxp) * nw * 1024}"),
             q(f"buffer_load_dwordx4 %[vo{i}], %[rw], %[koff] offen lds"))
 
 
@@ -363,8 +369,10 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
     ploads = list(ploads)
     vm = vm + len(ploads)
     nw = X3["nw"]
-    nxp, nwp = 32 // nw, X3["bn"] // 8 // nw
-    n_mf, n_rd = 4 * FN_, 4 + FN_
+    FM_ = X3["fm"]
+    nxp, nwp = 8 * FM_ // nw, X3["bn"] // 8 // nw
+    n_mf, n_rd = FM_ * FN_, FM_ + FN_
+    XT = X3["xt"]
     L = [q(f"; ---- X3 step parity {par}: tail_w {int(tail_w)} x_next {int(x_next)} head {int(head)} vmcnt {vm}")]
     nh = min(nwp - 1, (n_mf - 3 + 1) // 2)                   # W pieces issued in slice 3 (positions 3, 5, ...)
     queue = []                                               # (m0 line, dma line) of slices 0-1, W first then X
@@ -410,9 +418,9 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
             if nxt:
                 # X(j+3) goes where step j was read; then rotate the read slot and advance the four X fragment addresses
                 after[1] += [q("s_add_u32 %[xwl], %[lbase], %[xr]"),
-                             q("s_add_u32 %[xr], %[xr], 0x8000"),
-                             q("s_cmp_eq_u32 %[xr], 0x18000"),
-                             q("s_cselect_b32 %[dlt], %[cneg], 0x8000"),
+                             q(f"s_add_u32 %[xr], %[xr], 0x{XT:x}"),
+                             q(f"s_cmp_eq_u32 %[xr], 0x{3 * XT:x}"),
+                             q(f"s_cselect_b32 %[dlt], %[cneg], 0x{XT:x}"),
                              q("s_cselect_b32 %[xr], 0, %[xr]")]
                 after[1] += [q(f"v_add_u32_e32 %[ax{k}], %[dlt], %[ax{k}]") for k in range(4)]
                 rd = x3_reads(S ^ 1, par ^ 1, 0)
@@ -428,7 +436,7 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
                     i += 2
         L.append(q("s_waitcnt lgkmcnt(0)"))
         n = 0
-        for fm in range(4):
+        for fm in range(FM_):
             for fn in range(FN_):
                 L += pre[n]
                 srcc = "0" if (first and kk == 0) else f"%[c{fm}{fn}]"
@@ -439,7 +447,7 @@ def x3_step(par, tail_w, x_next, head, vm, nxt=True, first=False, ploads=()):
     return L
 
 
-def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0, tap=False):
+def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0, tap=False, fm=4):
     """pre_e = E > 0: the residual-prefetch form for the fp32-residual epilogue (EPI_F32_RESLN, tile 91): the loop's last 2 E
     steps are peeled, and the peeled steps plus steps nj-3 and nj-2 carry the 16 FN loads of the wave's residual tile
     (buffer_load_dwordx4, MFMA C layout: lane = row, 4 columns) into registers that stay live until the epilogue: the 50 MB
@@ -447,9 +455,12 @@ def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0, tap=False):
     read costs 9 us with hot and 22 us with cold operands, of a 36 / 58 us out-projection).  Loads retire in order, so each
     step's wait leaves that step's loads outstanding and the next step's wait collects them: they have one K step to arrive,
     like the X pieces.  The statement ends with vmcnt(0): the compiler does not know these registers are load results."""
+    # fm = X fragments (32 rows) per wave: 4 = the 256-row tiles; 3 = their 192-row siblings (round 6: a second tile HEIGHT, so that a launch
+    # whose 256-row tiles leave a partial round of the 256 persistent workgroups can be cut into 3/4-size tiles instead: X slot 24 KiB)
     bn = 64 * fn if nw == 4 else 128 * fn
-    X3.update({"fn": fn, "nw": nw, "bn": bn, "tap": tap})
-    nxp = 32 // nw
+    X3.update({"fn": fn, "nw": nw, "bn": bn, "tap": tap, "fm": fm, "xt": 64 * fm * 128})
+    nxp = 8 * fm // nw
+    assert not (pre_e and fm != 4)
     L = [q("; ---- fragments of (step 0, slice 0)")]
     L += x3_reads(0, 0, 0)
     L += x3_step(0, False, False, True, nxp, first=True)     # j = 0: W(1), X(1), X(2) came with the prologue
@@ -493,14 +504,14 @@ def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0, tap=False):
         L.append(q("s_waitcnt vmcnt(0)"))
     L.append(q("s_barrier"))
     L.append(q("s_nop 15"))
-    outs = [f'[c{m}{f}] "=a"(acc[{m}][{f}])' for m in range(4) for f in range(fn)]
+    outs = [f'[c{m}{f}] "=a"(acc[{m}][{f}])' for m in range(fm) for f in range(fn)]
     # residual registers: the LAST 16 runs (consumed last) in the AGPRs the 128x96 wave tile leaves free, the rest in VGPRs (the fewer registers the
     # kernel holds, the more of the OTHER stream's LayerNorm / conv0 waves fit beside it on the SIMD: bench.py runs two batches in flight)
     for i, nm in enumerate(pre_names):
         m, f, g = int(nm[2]), int(nm[3]), int(nm[4])
         outs.append(f'[{nm}] "=&{"a" if i >= len(pre_names) - 16 else "v"}"(rr[{m}][{f}][{g}])')
     for S in range(2):
-        for f in range(4):
+        for f in range(fm):
             outs.append(f'[x{S}{f}] "=&v"(fx[{S}][{f}])')
         for f in range(fn):
             outs.append(f'[w{S}{f}] "=&v"(fw[{S}][{f}])')
@@ -512,23 +523,18 @@ def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0, tap=False):
     ins = []
     for kk in range(4):
         ins += [f'[aw{kk}] "v"(aw[{kk}])', f'[aw{kk}h] "v"(awh[{kk}])']
-    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range((256 + bn) // 8 // nw)]
+    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range((64 * fm + bn) // 8 // nw)]
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)', '[cneg] "s"(cneg)']
     if tap:
         ins += ['[c2048] "s"(c2048)', '[cm1024] "s"(cm1024)', '[cm896] "s"(cm896)']
     if pre_e:
         ins += ['[vres] "v"(vres)', '[rres] "s"(rres)'] + [f'[sres{m}] "s"(sres[{m}])' for m in range(4)]
     here = os.path.dirname(os.path.abspath(__file__))
-    name = "gemm_asm_x3" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + (f"_p{pre_e}" + (f"c{pre_cols}" if pre_cols and pre_cols != fn else "") if pre_e else "") + ("_t" if tap else "") + ".inc"
+    name = "gemm_asm_x3" + ("" if fm == 4 else f"_m{fm}") + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + (f"_p{pre_e}" + (f"c{pre_cols}" if pre_cols and pre_cols != fn else "") if pre_e else "") + ("_t" if tap else "") + ".inc"
     dst = os.path.join(OUTDIR, name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (X3 ring) -- do not edit; the schedule is documented there.\n")
-        f.write("asm volatile(\n")
-        for l in L:
-            f.write("    " + l + "\n")
-        f.write("    : " + ",\n      ".join(outs) + "\n")
-        f.write("    : " + ",\n      ".join(ins) + "\n")
-        f.write('    : "scc", "memory");   // m0 is written too (reserved register, re-materialised by the compiler before its own uses)\n')
+        write_asm(f, L, outs, ins)
     print("wrote", os.path.normpath(dst), len(L), "lines")
 
 
@@ -740,12 +746,7 @@ def emit_f8(fn=4, lds_scales=False):
     dst = os.path.join(OUTDIR, name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (MXFP8 X3 loop) -- do not edit; the schedule is documented there.\n")
-        f.write("asm volatile(\n")
-        for l in L:
-            f.write("    " + l + "\n")
-        f.write("    : " + ",\n      ".join(outs) + "\n")
-        f.write("    : " + ",\n      ".join(ins) + "\n")
-        f.write('    : "scc", "memory", ' + clob + ");   // m0 is written too (reserved register)\n")
+        write_asm(f, L, outs, ins, '"scc", "memory", ' + clob)
     print("wrote", os.path.normpath(dst), len(L), "lines")
 
 
@@ -768,6 +769,8 @@ def emit_product():
     emit_x3(2, 8, tap=True)          # the 3-tap conv layers: chunk-major K order (tap 0, tap 2, tap 1 per 64-channel chunk)
     emit_x3(2, 4)                    # 256x128 tile on four waves (wave tile 128x64): the loop of the ping-pong kernel's groups
     emit_x3(2, 4, tap=True)
+    emit_x3(3, 4, fm=3)              # 192x192 (tile 51): tile 91's loop on three row fragments per wave
+    emit_x3(2, 8, fm=3)              # 192x256 on eight waves (tile 57): tile 97's
     for cols in (1, 2, 3):
         emit_x3(3, 4, pre_e=4, pre_cols=cols)          # K = 768 (12 steps): nothing left in the loop
         emit_x3(3, 4, pre_e=7, pre_cols=cols)          # K >= 1152 (FFN2, K = 3072: 48 steps, the last 17 unrolled)
@@ -778,7 +781,7 @@ def emit_product():
 
 def emit_experiments():
     """knock-out / schedule variants, timing only (results wrong by construction).  Never committed: build.py generates
-    them into sylber_amd/build/gen/ for a SYLBER_EXPERIMENTS=1 build (library name libsylber_hip_exp.so)"""
+    them into sylber_amd/build/gen_exp/ for a SYLBER_EXPERIMENTS=1 build (library name libsylber_hip_exp.so)"""
     for v in sorted(VARIANTS):
         if v:
             emit(v)
@@ -795,7 +798,7 @@ if __name__ == "__main__":
         emit_product()
     elif what == "experiments":
         if not os.environ.get("GEN_GEMM_ASM_OUT"):
-            OUTDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sylber_amd", "build", "gen")
+            OUTDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sylber_amd", "build", "gen_exp")
         os.makedirs(OUTDIR, exist_ok=True)
         emit_experiments()
     elif what == "hashes":

@@ -5,7 +5,7 @@ ROOT=$(pwd); OUT=$ROOT/gpurun_out/seqk; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/new -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-overlap > $OUT/new.log 2>&1
 if [ -f $ROOT/sylber_amd/libsylber_hip_ref.so ]; then
-  SYLBER_HIP_LIB=$ROOT/sylber_amd/libsylber_hip_ref.so rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ref -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-overlap > $OUT/ref.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ref -- python $ROOT/tools/with_lib.py ref $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-overlap > $OUT/ref.log 2>&1
 fi
 for w in ref new; do
   f=$(find $OUT/$w -name '*kernel_stats.csv' | head -1)
