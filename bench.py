@@ -97,6 +97,8 @@ def parse_args():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `other_configs` block (BASELINE configs[3] long-form, configs[4] fp8 and the split16 parity mode, "
                          "10 steps each in this same process after the headline run; N = 1, default workload only)")
+    ap.add_argument("--no-exchange-rehearsal", action="store_true",
+                    help="skip the one-rank RCCL self-test child of `other_configs` (the N > 1 code path on this one GPU)")
     ap.add_argument("--agreement-clips", type=int, default=0,
                     help="also report bf16-vs-fp32 segment agreement on this many synthetic clips (fp32 parity mode as truth)")
     return ap.parse_args()
@@ -237,7 +239,38 @@ def roofline_by_peak(kernels: dict, B: int, clip_samples: int, precision: str) -
     return out
 
 
-def measure_other_config(torch, dev, sd, streams4, precision: str, B: int, clip_seconds: float, steps: int = 10, warmup: int = 3) -> dict:
+def exchange_rehearsal(timeout_s: int = 150) -> dict:
+    """BASELINE configs[2] cannot be measured on a one-GPU box; what CAN be is the N > 1 code path itself: a child process runs this script
+    with --exchange-selftest (one-rank RCCL communicator, scatter / gather to self inside every step) and its figure is reported beside the
+    resident one of the same child -- what the collectives cost the persistent GEMM workgroups they share the chip with, with zero
+    remote bytes.  A child, not this process: a communicator that hangs must not take the headline line with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--exchange-selftest", "--no-api", "--no-cpu-baseline", "--no-other-configs", "--steps", "10",
+           "--warmup", "3", "--exchange-timeout", str(max(30, timeout_s - 60))]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "the self-test child did not finish within %d s" % timeout_s}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "self-test child exited %d: %s" % (r.returncode, (r.stderr or "")[-300:])}
+    d = json.loads(lines[-1])
+    res = d.get("resident_shards") or {}
+    out = {"value": d.get("value"), "unit": "audio-sec/s", "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"),
+           "resident_ms_per_step_same_process": res.get("ms_per_step"),
+           "what": "one-rank RCCL self-test of the N > 1 step (ShardedSegmenter.run_stream: scatter + asynchronous gather to self in every step, "
+                   "two engines); NOT a multi-GPU measurement", "child_wall_s": round(time.perf_counter() - t0, 1)}
+    if res.get("ms_per_step") and d.get("ms_per_step"):
+        out["overhead_vs_resident"] = round(d["ms_per_step"] / res["ms_per_step"] - 1.0, 4)
+    for k in ("exchange_detail", "exchange_error", "results_left_sharded"):
+        if d.get(k) is not None:
+            out[k] = d[k]
+    return out
+
+
+def measure_other_config(torch, dev, sd, streams4, precision: str, B: int, clip_seconds: float, steps: int = 10, warmup: int = 3,
+                         agreement_clips: int = 0) -> dict:
     """One more BASELINE configuration in THIS process, timed like the headline (two batches in flight on independent handles,
     boundary detection on side streams, inputs resident in HBM, device-wide synchronize on both sides of exactly `steps` steps),
     followed by a profiling pass for its own roofline."""
@@ -245,6 +278,8 @@ def measure_other_config(torch, dev, sd, streams4, precision: str, B: int, clip_
     from sylber_amd.synth import noise_batch
     clip_samples = int(round(clip_seconds * 16000))
     encs = [HubertEncoderHIP(sd, device=str(dev), precision=precision) for _ in range(2)]
+    for e_ in encs:
+        e_.set_batches_in_flight(2)
     T_frames = encs[0].num_frames(clip_samples)
     batch = noise_batch(B, clip_samples, seed=0).to(dev)
     mains, sides = streams4[:2], streams4[2:4]
@@ -279,6 +314,8 @@ def measure_other_config(torch, dev, sd, streams4, precision: str, B: int, clip_
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     enc = encs[0]
+    enc.set_batches_in_flight(1)                      # the per-kernel pass: this handle alone on the chip (see main())
+    enc.forward(batch, None)
     enc.set_profiling(True)
     nprof = 3
     for _ in range(nprof):
@@ -292,6 +329,19 @@ def measure_other_config(torch, dev, sd, streams4, precision: str, B: int, clip_
            "roofline": dict(roofline_by_peak(kernels, B, clip_samples, precision), attention=attention_roofline(kernels, B, T_frames, precision)),
            "kernel_ms_per_forward": {k: kernels[k] for k in ("attention", "conv0_gn_gelu", "posconv", "layernorm", "segment") if k in kernels},
            "workspace_gb": round(enc.workspace_bytes() / 2 ** 30, 2)}
+    if precision in ("fp16", "mixed16"):
+        # does anything come near the format's limit?  (the audit launches run outside every timed region)
+        enc.fp16_audit(start=True)
+        enc.forward(batch, None)
+        aud = enc.fp16_audit()
+        enc.set_option(10, 0)
+        out["fp16_audit"] = {"saturated_values": sum(v["saturated"] for v in aud.values()), "largest_magnitude": max([v["max_abs"] for v in aud.values()] or [0.0]),
+                             "limit": 65504.0, "stage_of_largest": max(aud, key=lambda k: aud[k]["max_abs"]) if aud else None,
+                             "what": "sylber_get_fp16_audit over one forward of this workload (synthetic weights): values clamped at +-65504 and the largest "
+                                     "16-bit activation magnitude over all stages"}
+    if agreement_clips > 0:
+        from sylber_amd.agreement import segment_agreement
+        out["segment_agreement"] = segment_agreement(sd, enc, agreement_clips, device=str(dev))
     del encs, enc, bufs, batch
     torch.cuda.empty_cache()
     return out
@@ -381,6 +431,8 @@ def main():
     NPIPE = 1 if args.no_overlap else max(1, args.inflight)
     encs = [HubertEncoderHIP(sd, device=str(dev), precision=args.precision) for _ in range(NPIPE)]
     enc = encs[0]
+    for e_ in encs:                                  # the timed steps keep NPIPE batches in flight: the handles share the chip (GEMM tile choice only)
+        e_.set_batches_in_flight(NPIPE)
     if args.graph:
         for e_ in encs:
             e_.set_graph_mode(True)
@@ -710,6 +762,11 @@ def main():
                         "traffic_note": "no PMC pass for the parity mode", "flops_per_forward": gemm_fl,
                         "ms_per_forward": kernels["gemm_f32"]}
     if rank == 0 and args.precision != "fp32":
+        # the per-kernel pass runs ONE handle with nothing else on the chip: it tells the library so (SYLBER_OPT_GEMM_MODEL: the tiles a
+        # synchronous caller gets), where the timed steps above declared NPIPE batches in flight; `roofline.tile_selection` says which
+        if not any(kv.startswith("12=") for kv in args.opt):
+            enc.set_batches_in_flight(1)
+            enc.forward(my_batch, None)                  # (first use of a tile: function attributes, instruction cache)
         enc.set_profiling(True)
         nprof = max(3, min(args.steps, 10))
         for _ in range(nprof):
@@ -718,6 +775,8 @@ def main():
         torch.cuda.synchronize(dev)
         prof = enc.get_profile()
         enc.set_profiling(False)
+        if not any(kv.startswith("12=") for kv in args.opt):
+            enc.set_batches_in_flight(NPIPE)
         kernels = {k: round(v / nprof, 4) for k, v in prof.items()}      # ms per forward
         fl = gemm_flops_per_forward(B, clip_samples)
         ms_of = {k: sum(kernels.get(a, 0.0) for a in GEMM_ALIASES.get(k, (k,))) for k in fl}
@@ -748,6 +807,9 @@ def main():
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "avg_launch_ms": round(gemm_ms / max(n_launch, 1), 4), "flops_per_forward": gemm_fl,
                     "per_launch_tflops": {k: round(fl[k] / (ms_of[k] * 1e-3) / 1e12, 1) for k in fl if ms_of[k] > 0}}
+        roofline["tile_selection"] = ("per-kernel pass: one handle alone on the chip, GEMM tiles as the library picks them for one batch in flight "
+                                      "(SYLBER_OPT_GEMM_MODEL 0); the timed steps keep %d batches in flight and declare it (model %s). Same kernels and "
+                                      "bits, the tile of a launch may differ where the batch shape leaves a partial round" % (NPIPE, "5" if NPIPE >= 2 else "0"))
         roofline["by_operand_type"] = roofline_by_peak(kernels, B, clip_samples, args.precision)
         roofline["attention"] = attention_roofline(kernels, B, T_frames, args.precision)
         if args.precision == "fp8":
@@ -846,13 +908,36 @@ def main():
     if (rank == 0 and world == 1 and not args.no_other_configs and args.precision == "bf16" and B == BATCH_PER_GPU
             and clip_samples == CLIP_SAMPLES and not args.ragged and not args.opt and args.gemm_tile < 0):
         other = {}
-        for name, (prec, b_, secs) in {"configs[3] long-form 8 x 60 s, bf16": ("bf16", 8, 60.0),
-                                       "configs[4] fp8 (MXFP8 attention + FFN / projection GEMMs), 32 x 10 s": ("fp8", BATCH_PER_GPU, CLIP_SECONDS),
-                                       "split16 (segment tables bit-identical to the fp32 reference), 32 x 10 s": ("split16", BATCH_PER_GPU, CLIP_SECONDS)}.items():
+        for name, (prec, b_, secs, agree) in {"configs[3] long-form 8 x 60 s, bf16": ("bf16", 8, 60.0, 0),
+                                              "configs[4] fp8 (MXFP8 attention + FFN / projection GEMMs), 32 x 10 s": ("fp8", BATCH_PER_GPU, CLIP_SECONDS, 0),
+                                              "fp16 (IEEE half operands, same MFMA rate; 5x the table agreement of bf16), 32 x 10 s": ("fp16", BATCH_PER_GPU, CLIP_SECONDS, 64),
+                                              "split16 (segment tables bit-identical to the fp32 reference), 32 x 10 s": ("split16", BATCH_PER_GPU, CLIP_SECONDS, 0)}.items():
             try:
-                other[name] = measure_other_config(torch, dev, sd, pool_st if len(pool_st) >= 4 else concurrent_streams(4, dev), prec, b_, secs)
+                other[name] = measure_other_config(torch, dev, sd, pool_st if len(pool_st) >= 4 else concurrent_streams(4, dev), prec, b_, secs,
+                                                   agreement_clips=agree)
             except Exception as e:  # noqa: BLE001 - the headline line must survive a failing side measurement
                 other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.no_exchange_rehearsal:
+            torch.cuda.synchronize(dev)
+            other["configs[2] rehearsal: the N > 1 step on a one-rank RCCL communicator, 32 x 10 s"] = exchange_rehearsal()
+
+    # ---- box-speed normaliser: boxes of the pool differ by +-4-5 % (more than a round's gains), and every figure above moves with the box.
+    # One fixed, shape-independent launch series of the same library -- the 4096^3 bf16 GEMM loop, hot operands -- lets a reader
+    # normalise a slow box: value / box_speed is comparable across runs
+    box_speed = None
+    if rank == 0 and world == 1:
+        try:
+            import ctypes as _ct
+            from sylber_amd import _lib as _l
+            torch.cuda.synchronize(dev)
+            ms_ = _ct.c_float()
+            _l.check(_l.load().sylber_debug_gemm_bench(4096, 4096, 4096, 4096, 0, 0, -1, 30, _ct.byref(ms_)), "gemm_bench")
+            box_speed = {"gemm_4096_cubed_tflops": round(2.0 * 4096 ** 3 / (ms_.value * 1e-3) / 1e12, 1), "us_per_launch": round(ms_.value * 1e3, 1),
+                         "what": "30 back-to-back launches of this library's 4096^3 bf16 GEMM (plain 16-bit epilogue, hot operands, automatic tile) right "
+                                 "after the measurements above: the same kernel family as 55 % of the step, one fixed shape -- a per-box yardstick "
+                                 "(round-5/6 boxes: 1290-1345 TF)"}
+        except Exception as e:  # noqa: BLE001
+            box_speed = {"error": "%s: %s" % (type(e).__name__, e)}
 
     seg_stats = None
     if rank == 0:
@@ -877,6 +962,8 @@ def main():
             line["exchange_error"] = exchange_error
         if agreement is not None:
             line["segment_agreement"] = agreement
+        if box_speed is not None:
+            line["box_speed"] = box_speed
         if other is not None:
             line["other_configs"] = other
         if args.skip_segment:

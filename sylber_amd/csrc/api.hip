@@ -91,6 +91,7 @@ struct sylber_ctx {
     int opt_audit16 = 0;
     unsigned* audit_dev = nullptr;                                 // [AUDIT_STAGES][2]: saturated count, max |x| as half bits
     int opt_segment = 0;                                           // boundary detection: 0 wide (all CUs), -1 one workgroup per utterance
+    int opt_gemm_model = 0;                                        // 5: round-5 tile cost model (A/B switch)
     int opt_gemm_h192 = 0;                                         // -1: no 192-row tiles in the cost model (A/B switch)
     int opt_gemm_tail = 0;                                         // row split of multi-round GEMM launches: 0 auto, -1 never, k + 1 = tail tile id k
     int opt_attn8 = 0;                                             // SYLBER_FP8: attention core on MXFP8 operands (0 / 1 on, -1 off)
@@ -307,6 +308,7 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
             break;
         }
         case SYLBER_OPT_SEGMENT: c->opt_segment = value < 0 ? -1 : 0; break;
+        case SYLBER_OPT_GEMM_MODEL: c->opt_gemm_model = value == 5 ? 5 : (value == 2 ? 2 : 0); break;
         case SYLBER_OPT_GEMM_H192: c->opt_gemm_h192 = value < 0 ? -1 : 0; break;
         case SYLBER_OPT_GEMM_TAIL: c->opt_gemm_tail = value < 0 ? -1 : (value > 0 ? value + 1 : 0); break;   // k > 0: tail tile id k (stored id + 1)
         default: syl_set_error("sylber_set_option", "unknown option key"); return 1;
@@ -547,7 +549,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         GemmArgs a = {};
         a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w[i];
         a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = split ? ACT_GELU_ERF7 : ACT_GELU_FAST;
-        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.tune_tail = c->opt_gemm_tail; a.tune_h192 = c->opt_gemm_h192;  a.fmt = c->fmt_conv;
+        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.tune_tail = c->opt_gemm_tail; a.tune_h192 = c->opt_gemm_h192; a.tune_model = c->opt_gemm_model;  a.fmt = c->fmt_conv;
         a.x_lo = src_lo; a.w_lo = (long)512 * CK[i] * 512; a.out_lo = dst_lo;
         a.kpat = (CK[i] == 3 && c->fmt_conv != FMT_SPLIT) ? 1 : 0;      // chunk-major K order (weights packed to match at create)
         static const char* nm[7] = {"", "gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_conv6"};
@@ -631,7 +633,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
             GemmArgs g = {};
             g.X = hbf; g.ldx = 768; g.W = d.wqkv; g.M = M; g.N = 2304; g.K = 768; g.bias = d.bqkv;
             g.out0 = q; g.out1 = k; g.out2 = vt; g.Tp = p.Tp; g.Tpv = p.Tpv; g.T = p.T;
-            g.tune_cfg = c->opt_gemm_cfg; g.tune_persist = c->opt_gemm_persist; g.tune_tail = c->opt_gemm_tail; g.tune_h192 = c->opt_gemm_h192;  g.fmt = c->fmt;
+            g.tune_cfg = c->opt_gemm_cfg; g.tune_persist = c->opt_gemm_persist; g.tune_tail = c->opt_gemm_tail; g.tune_h192 = c->opt_gemm_h192; g.tune_model = c->opt_gemm_model;  g.fmt = c->fmt;
             g.x_lo = p.lo_hbf; g.w_lo = (long)2304 * 768; g.out_lo = p.lo_qk; g.out2_lo = p.lo_vt;
             RUN("gemm_qkv", launch_gemm_bf16(EPI_QK, g, s));
             if (aud_e && (audit16(c, AUD_Q, q, M, 768, 768, s) || audit16(c, AUD_K, k, M, 768, 768, s) ||
@@ -652,7 +654,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         GemmArgs o = {};
         o.X = ctx; o.ldx = 768; o.W = d.wo; o.M = M; o.N = 768; o.K = 768; o.bias = d.bo;
         o.out0 = pre; o.ld0 = 768; o.res = pre; o.ldres = 768; o.ln_stats = stats; o.ln_gamma = res_g; o.ln_beta = res_b;
-        o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist; o.tune_tail = c->opt_gemm_tail; o.tune_h192 = c->opt_gemm_h192;  o.fmt = c->fmt; o.tune_pre = c->opt_resln_pre;
+        o.tune_cfg = c->opt_gemm_cfg; o.tune_persist = c->opt_gemm_persist; o.tune_tail = c->opt_gemm_tail; o.tune_h192 = c->opt_gemm_h192; o.tune_model = c->opt_gemm_model;  o.fmt = c->fmt; o.tune_pre = c->opt_resln_pre;
         o.x_lo = p.lo_ctx; o.w_lo = (long)768 * 768;
         // out-projection + LayerNorm 1 as ONE launch on full-row tiles (gemm_rowln.hip) where the batch fills the chip
         o.out1 = hbf; o.ln_stats_out = stats; o.ln_gamma_out = d.ln1w; o.ln_beta_out = d.ln1b;
@@ -674,14 +676,14 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         } else {
         GemmArgs f1 = {};
         f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = split ? ACT_GELU_ERF7 : ACT_GELU_FAST;
-        f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist; f1.tune_tail = c->opt_gemm_tail; f1.tune_h192 = c->opt_gemm_h192;  f1.fmt = c->fmt;
+        f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist; f1.tune_tail = c->opt_gemm_tail; f1.tune_h192 = c->opt_gemm_h192; f1.tune_model = c->opt_gemm_model;  f1.fmt = c->fmt;
         f1.x_lo = p.lo_hbf; f1.w_lo = (long)3072 * 768; f1.out_lo = p.lo_ffn;
         RUN("gemm_ffn1", launch_gemm_bf16(EPI_BF16, f1, s));
         if (aud_e && audit16(c, AUD_FFN1, ffn, M, 3072, 3072, s)) return 1;
         GemmArgs f2 = {};
         f2.X = ffn; f2.ldx = 3072; f2.W = d.w2; f2.M = M; f2.N = 768; f2.K = 3072; f2.bias = d.b2;
         f2.out0 = pre; f2.ld0 = 768; f2.res = pre; f2.ldres = 768; f2.ln_stats = stats; f2.ln_gamma = d.ln1w; f2.ln_beta = d.ln1b;
-        f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist; f2.tune_tail = c->opt_gemm_tail; f2.tune_h192 = c->opt_gemm_h192;  f2.fmt = c->fmt; f2.tune_pre = c->opt_resln_pre;
+        f2.tune_cfg = c->opt_gemm_cfg; f2.tune_persist = c->opt_gemm_persist; f2.tune_tail = c->opt_gemm_tail; f2.tune_h192 = c->opt_gemm_h192; f2.tune_model = c->opt_gemm_model;  f2.fmt = c->fmt; f2.tune_pre = c->opt_resln_pre;
         f2.x_lo = p.lo_ffn; f2.w_lo = (long)768 * 3072;
         RUN("gemm_ffn2", launch_gemm_bf16(EPI_F32_RESLN, f2, s));
         }
@@ -1277,7 +1279,7 @@ static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t
     }
     g.tune_cfg = cfg < 0 ? 0 : (cfg % 1000) + 1;
     g.tune_persist = cfg >= 9000 ? -1 : (cfg >= 1000 ? cfg / 1000 : 0);    // cfg = persist * 1000 + tile (9000 + tile: persist = -1)
-    g.tune_h192 = no_h192 ? -1 : 0;
+    g.tune_h192 = no_h192 ? -1 : 0; g.tune_model = no_h192 ? 5 : 0;
     g.tune_tail = tail_code == 0 ? 0 : (tail_code == 1 ? -1 : tail_code - 1);   // act + 100 t: t = 1 never split, t >= 2 force tail tile id t - 2
     TmpBuf trb;
     if (g_gemm_trace_out) {

@@ -876,7 +876,10 @@ static int launch_cfg8p(const GemmArgs& a, hipStream_t s) {
 #define GEMM_SPLIT_US 4.0           // what the second launch of a split costs (dispatch gap + a second prologue)
 #endif
 #ifndef GEMM_H192_EFF
-#define GEMM_H192_EFF 0.95          // the 192-row tiles' efficiency relative to their 256-row siblings
+#define GEMM_H192_EFF 0.90          // the 192-row tiles' efficiency relative to their 256-row siblings (in-forward: full rounds at 0.845 instead of 0.75 of the time)
+#endif
+#ifndef GEMM_PR0_ASM
+#define GEMM_PR0_ASM 0.4            // cost of an (almost) empty partial round of the persistent hand-scheduled tiles, relative to a full round
 #endif
 #define GEMM_CU_MACS_PER_US 1.8e6   // one CU's rate on these loops (256 x 256 x 768 MACs in ~28 us)
 
@@ -938,7 +941,7 @@ static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
 //     Measured not to pay with the tiles that exist (see below): kept as a forced option and as the test vehicle of m_begin.
 template <int EPI, int ACT, int FMT>
 static int launch_f(const GemmArgs& a, hipStream_t s) {
-    struct Cfg { int id, bm, bn, per_cu; double eff; };
+    struct Cfg { int id, bm, bn, per_cu; double eff, pr0; };
     // 80 / 90: the hand-scheduled 4-wave kernels (gemm_asm.hip).  Their K loop runs ~25 % above the 8-wave kernel's, but one
     // wave per SIMD leaves a tile's prologue and epilogue uncovered (~9 us + ~5 us of GELU against a 17 us K = 768 loop), so
     // they are rated for long K only (same-box tools/gemm_bench.py: conv1-4 +3-10 %, FFN2 +7 %, K = 768 shapes -5-20 %).
@@ -949,26 +952,49 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     const bool x3 = FMT != FMT_SPLIT;
     // 86 = the X3 loop on a 256x128 tile / four waves: slower per FLOP than 97 (923 vs 974 TF on conv1), but a launch of 64 row tiles
     // x 512 columns (conv6) fills 256 CUs with it and half of them with 256x256 tiles: 22.0 vs 29.7 us
-    // 51 / 57 = tiles 91 / 97 at 192 rows (round 6): 6 % fewer FLOPs per staged byte, rated GEMM_H192_EFF of their siblings; they win where their
-    // tile count fills the last round of 256 workgroups and the 256-row count does not
+    // 51 / 57 = tiles 91 / 97 at 192 rows (round 6), rated GEMM_H192_EFF of their siblings (fewer FLOPs per staged byte)
+    //
+    // Round 6 re-fitted the model to IN-FORWARD launch times (sequential profile, cold activations, seven batch shapes x every tile forced:
+    // tools/tile_pick_sweep.py -> profiles/r06_tile_pick.md) instead of the hot micro-benchmark it came from:
+    //   * a PARTIAL last round is not a whole round.  Tiles beyond the last full round fill a fraction f of the launch's slots; that round
+    //     costs pr0 + (1 - pr0) f of a full one: pr0 = 0 for the two-per-CU kernels (measured proportional: q,k,v on 128x192 takes 4.4
+    //     round-times for 4.4 rounds of tiles), 0.4 for the persistent hand-scheduled tiles (a 0.41-full round of tile 91 costs 0.63, a
+    //     0.47-full one 0.70), 1 for the 8-wave hipcc kernel (its 3.3 rounds cost 4)
+    //   * the hipcc 8-wave kernel (10) was rated 1.20 for every epilogue; with the fp32-residual epilogue it runs at 1.0 (FFN2 1.93 vs
+    //     1.15 ms per forward at 8 x 60 s) and was being picked for q,k,v / out-proj wherever its tile count rounded well
+    //   * q,k,v: the 128x192 two-per-CU kernel is rated 1.09 (0.614 vs 0.645 ms per forward on tile 91 at 32 x 10 s, 0.89 vs 1.00 at 8 x 60 s)
+    // tune_model = 5 (SYLBER_OPT_GEMM_MODEL: "this handle shares the chip with another in-flight batch") = the round-5 constants, whole rounds, no
+    // 192-row tiles: with two batches in flight the other stream's kernels take the CUs a partial round leaves idle, and that selection measured
+    // fastest there on five batch shapes (profiles/r06_tile_model_ab.md); alone on the chip it is the slower one.
+    const bool r5 = a.tune_model == 5;
     constexpr int NCFG = 9;
-    const Cfg cfgs[NCFG] = {{3, 128, 128, 2, 0.93}, {4, 128, 192, 2, 1.00}, {10, 256, 256, 1, 1.20},
-                            {x3 ? 85 : 80, 256, 256, 1, long_k ? 1.28 : 1.10}, {91, 256, 192, 1, long_k ? 1.10 : 1.04},
-                            {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27}, {86, 256, 128, 1, 1.10},
-                            {51, 192, 192, 1, (long_k ? 1.10 : 1.04) * GEMM_H192_EFF}, {57, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF}};
-    // cost of configuration i over `rows` rows: rounds x (tile area per CU) / eff.  A two-per-CU configuration whose tiles leave every
-    // CU with at most ONE workgroup is charged one tile per CU, at the lower efficiency of a workgroup that runs alone (GEMM_SOLO_EFF:
-    // nobody covers its prologue / epilogue) -- the tail of a split launch is usually such a launch
+    const double e10 = r5 || EPI == EPI_BF16 ? 1.20 : (EPI == EPI_QK ? 1.15 : 1.00);
+    const double e4 = !r5 && EPI == EPI_QK ? 1.09 : 1.00;
+    // tune_model = 2: "throughput" -- the handle is one of several in flight (bench.py's pipeline, Segmenter.stream's neighbours): the CUs a
+    // partial round leaves idle are taken by the other stream's kernels, so a partial round costs only its share (pr0 = 0 for every tile)
+    const bool thr = a.tune_model == 2;
+    const double pa = r5 ? 1.0 : (thr ? 0.0 : GEMM_PR0_ASM), p2 = r5 ? 1.0 : 0.0, p10 = thr ? 0.0 : 1.0;
+    const Cfg cfgs[NCFG] = {{3, 128, 128, 2, r5 ? 0.93 : 0.95, p2}, {4, 128, 192, 2, e4, p2}, {10, 256, 256, 1, e10, p10},
+                            {x3 ? 85 : 80, 256, 256, 1, long_k ? (r5 ? 1.28 : 1.20) : 1.10, pa}, {91, 256, 192, 1, long_k ? 1.10 : 1.04, pa},
+                            {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27, pa}, {86, 256, 128, 1, 1.10, pa},
+                            {51, 192, 192, 1, (long_k ? 1.10 : 1.04) * GEMM_H192_EFF, pa}, {57, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa}};
+    // cost of configuration i over `rows` rows: (full rounds + cost of the partial round) x (tile area per CU) / eff
     auto cost_of = [&](int i, long rows) -> double {
         const Cfg& c = cfgs[i];
         if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, c.id))) return 1e300;   // only tiles that exist for this epilogue / format
-        if ((c.id == 51 || c.id == 57) && a.tune_h192 < 0) return 1e300;
+        if ((c.id == 51 || c.id == 57) && (a.tune_h192 < 0 || r5)) return 1e300;
         const long tm = (rows + c.bm - 1) / c.bm, tn = (a.N + c.bn - 1) / c.bn;
         if (c.id == 86 && tm * tn < 192) return 1e300;      // (measured for launches that fill the chip; small batches keep their tiles)
-        if (c.per_cu == 2 && tm * tn <= 256) return (double)c.bm * c.bn / (c.eff * GEMM_SOLO_EFF);
-        const long slots = 256L * c.per_cu;
-        const long rounds = (tm * tn + slots - 1) / slots;
-        return (double)rounds * c.per_cu * c.bm * c.bn / c.eff;
+        const long slots = 256L * c.per_cu, tiles = tm * tn;
+        const long full = tiles / slots, rem = tiles - full * slots;
+        double rounds = (double)full;
+        if (rem > 0) {
+            // a two-per-CU kernel whose partial round leaves every CU at most ONE workgroup: that workgroup runs alone (nobody covers
+            // its prologue / epilogue), GEMM_SOLO_EFF of the paired rate
+            if (!r5 && c.per_cu == 2 && full == 0 && rem <= 256) rounds = 0.5 / GEMM_SOLO_EFF;
+            else rounds += c.pr0 + (1.0 - c.pr0) * (double)rem / (double)slots;
+        }
+        return rounds * c.per_cu * c.bm * c.bn / c.eff;
     };
     auto pick = [&](long rows, double* cost) -> int {
         int best = 0;

@@ -53,6 +53,7 @@ struct GemmArgs {
     int tune_pre;                 // residual GEMMs on tile 91: -1 no residual prefetch in the K loop, 1..3 fragment columns prefetched, 0 default
     int m_begin;                  // the launch covers rows [m_begin, M) (0 = all): the tail launch of a row-split GEMM (launch_f, "tail policy");
                                   // row indices stay absolute everywhere (operands, epilogues, the row -> (utterance, frame) maps)
+    int tune_model;               // 5: the round-5 cost model of launch_f (A/B switch); 0: the current one
     int tune_h192;                // -1: the cost model leaves the 192-row tiles (51 / 57) out (A/B switch)
     int tune_tail;                // tail policy of multi-round launches: 0 automatic, -1 never split, k > 0 = force a split with tail tile id k - 1
 };

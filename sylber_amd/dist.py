@@ -31,6 +31,10 @@ class ShardedSegmenter:
     def __init__(self, engine, norm_threshold: float = 2.6, merge_threshold: float = 0.8, group=None,
                  always_collective: bool = False, segment_on_side_stream: bool = True):
         self.engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
+        if len(self.engines) >= 2:                       # run_stream keeps one batch in flight per engine: they share the chip
+            for e_ in self.engines:
+                if hasattr(e_, "set_batches_in_flight"):
+                    e_.set_batches_in_flight(len(self.engines))
         self.engine = self.engines[0]
         self.norm_threshold = norm_threshold
         self.merge_threshold = merge_threshold

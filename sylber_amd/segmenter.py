@@ -234,6 +234,12 @@ class HubertEncoderHIP:
         _lib.check(st, "sylber_forward")
         return out
 
+    def set_batches_in_flight(self, n: int) -> None:
+        """tell the handle whether it owns the chip (n = 1, the default: a synchronous caller) or shares it with other in-flight batches on other
+        handles / streams (n >= 2: bench.py's pipeline, ShardedSegmenter's engines).  Only the GEMM tile choice depends on it
+        (SYLBER_OPT_GEMM_MODEL, include/sylber_hip.h); results are bit-identical."""
+        self.set_option(12, 5 if int(n) >= 2 else 0)
+
     def set_graph_mode(self, enable: bool = True) -> None:
         """Replay the forward's ~110 kernel launches from a captured hipGraph (per (B, Lmax, input, output buffers);
         captured on the second call with the same key).  For launch-bound small batches; pass ``out=`` and reuse the
@@ -278,6 +284,24 @@ class HubertEncoderHIP:
     def workspace_bytes(self) -> int:
         return int(self.lib.sylber_workspace_bytes(self.handle))
 
+    def fp16_audit(self, start: bool = False):
+        """fp16 headroom audit (include/sylber_hip.h SYLBER_OPT_FP16_AUDIT; precision "fp16" / "mixed16" only -- the other modes have nothing to
+        saturate).  ``fp16_audit(start=True)`` (re)starts it: from then on every forward scans each 16-bit activation buffer behind its
+        producer.  ``fp16_audit()`` returns ``{stage: {"saturated": values clamped at +-65504, "max_abs": largest magnitude}}`` since the
+        start (synchronises the device), or ``{}`` when it never ran.  A non-zero ``saturated`` anywhere means the checkpoint does not fit
+        IEEE half there: use "bf16" or "split16"."""
+        if start:
+            self.set_option(10, 1)
+            return None
+        cap = 32
+        names = (ctypes.c_char_p * cap)()
+        sat = (ctypes.c_uint32 * cap)()
+        mx = (ctypes.c_float * cap)()
+        n = self.lib.sylber_get_fp16_audit(self.handle, names, sat, mx, cap)
+        if n < 0:
+            _lib.check(1, "sylber_get_fp16_audit")
+        return {names[i].decode(): {"saturated": int(sat[i]), "max_abs": float(mx[i])} for i in range(n)}
+
 
 class Segmenter:
     """Same signature as the reference's ``Segmenter`` (sylber/model/sylber.py:30-39, 63)."""
@@ -306,7 +330,8 @@ class Segmenter:
         if self.output_memory not in ("pinned", "pageable"):
             raise ValueError("output_memory must be 'pinned' or 'pageable'")
         self.out_pool = PinnedOutputPool(max_leased=int(kwargs.get("max_pinned_batches", 4)))
-        self._fill_threads = max(1, int(kwargs.get("host_pad_threads", 2)))     # host padding of tensor inputs (encode_batch)
+        self._fill_threads = max(1, int(kwargs.get("host_pad_threads", 4)))     # host padding of tensor inputs (encode_batch)
+        self._fill_groups = max(1, int(kwargs.get("host_pad_groups", 2 * self._fill_threads)))   # row groups the padding + H2D of a batch is cut into
         self._kcap_seen = 128                                                    # segment slots per utterance the next block is sized for
         self._kcap_recent = collections.deque(maxlen=16)                         # per-batch maxima of the last 16 batches (sizing decays with them)
         self._overlap_d2h = bool(kwargs.get("overlap_d2h", True))               # hidden-state D2H under the segmenter (A/B switch)
@@ -365,9 +390,12 @@ class Segmenter:
     def encode_batch(self, batch_wavs: Sequence[torch.Tensor]):
         """Pads to the batch max (sylber.py:93-118) and runs the HIP forward.  Returns the device
         hidden states [B,T,768] (full padded T, like the reference) and the per-row lengths."""
+        tr = self.__dict__.get("_trace")
+        mark = (lambda name: tr.append((name, time.perf_counter()))) if tr is not None else (lambda name: None)
         rows, lengths = self._rows(batch_wavs)
         lmax = max(lengths)
         dev = self.speech_model.device
+        mark("  rows collected")
         if all(not r.is_cuda for r in rows):
             # host inputs: pad on the host into a pinned staging buffer and cross PCIe once (a row-by-row copy loop
             # costs a host round trip per utterance).  Two buffers rotate, each with the event of the H2D copy that last
@@ -378,7 +406,9 @@ class Segmenter:
             # the intra-op thread pool (128 threads on the MI355X boxes), which made one call cost anything from 10 ms
             # to 1.8 s (tools/api_profile.py: 9.4-9.9 ms with one thread, 9.8-188 ms with the default pool)
             stage_np = stage.numpy()
+            mark("  staging buffer free")
             batch = torch.empty(len(rows), lmax, dtype=torch.float32, device=dev)
+            mark("  device batch allocated")
 
             def fill(lo, hi):
                 for i in range(lo, hi):
@@ -390,7 +420,9 @@ class Segmenter:
             # private thread pool (numpy's copy releases the GIL) and each group crosses PCIe as soon as it is padded, so the
             # H2D of group g runs under the padding of group g + 1
             nrow = len(rows)
-            ngrp = min(self._fill_threads, max(1, nrow // 8)) if nrow * lmax >= (1 << 20) else 1
+            # round 6: twice as many groups as threads -- with one group per thread both groups finish together and the copies only
+            # START when the padding is over (tools/api_timeline.py: H2D done 1.25 ms into the call against 0.26 + 0.37 of work)
+            ngrp = min(self._fill_groups, max(1, nrow // 4)) if nrow * lmax >= (1 << 20) else 1
             if ngrp <= 1:
                 fill(0, nrow)
                 batch.copy_(stage, non_blocking=True)
@@ -401,6 +433,7 @@ class Segmenter:
                     f.result()
                     batch[lo:hi].copy_(stage[lo:hi], non_blocking=True)
             slot["event"].record(torch.cuda.current_stream(dev))
+            mark("  padded, H2D issued")
             gtr = self.__dict__.get("_gpu_trace")
             if gtr is not None:
                 ev = torch.cuda.Event(enable_timing=True)

@@ -67,6 +67,50 @@ def test_fp16_conversions_saturate_instead_of_overflowing():
     assert bool(torch.isfinite(e16.forward(x, None)).all())
 
 
+def test_fp16_headroom_audit_reports_saturation(engines):
+    """round 6: the fp16 modes clamp at +-65504 on conversion, so a checkpoint that outgrows IEEE half is clamped silently.
+    The audit (SYLBER_OPT_FP16_AUDIT / sylber_get_fp16_audit) scans every 16-bit activation buffer behind its producer: with the synthetic
+    weights nothing saturates and every stage reports a finite, positive headroom figure; with conv layer 1's gain inflated 1e5x the
+    clamped values are COUNTED at that stage (and downstream of it), while the hidden states stay finite; the audit changes no result
+    and costs nothing when off; the other precisions have nothing to audit."""
+    from sylber_amd import HubertEncoderHIP
+    e16, _, ebf = engines
+    x = torch.cat([syllable_wave(24000, 40 + i) for i in range(3)], 0).cuda().contiguous()
+    ref = e16.forward(x, None).clone()
+    assert e16.fp16_audit() == {} or all(v["saturated"] == 0 for v in e16.fp16_audit().values())
+    e16.fp16_audit(start=True)
+    h = e16.forward(x, None)
+    aud = e16.fp16_audit()
+    assert torch.equal(h, ref)                                              # the scan reads, nothing else
+    assert set(aud) == {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "ln512", "proj_xpad", "layernorm", "q", "k", "v",
+                        "context", "ffn1"}
+    assert all(v["saturated"] == 0 for v in aud.values()), aud
+    assert all(0.0 < v["max_abs"] < 65504.0 for v in aud.values()), aud
+    # the stage maxima are the buffers' real maxima: conv6's against the stage output read back through stop_stage
+    conv6 = e16.forward(x, None, stop_stage=1)
+    assert abs(aud["conv6"]["max_abs"] - float(conv6.abs().max())) <= 1e-3 * aud["conv6"]["max_abs"] or aud["conv6"]["max_abs"] >= float(conv6.abs().max())
+    e16.set_option(10, 0)
+    # a checkpoint that does NOT fit: counted where it clamps
+    sd = {k: v.clone() for k, v in synthetic_state_dict(0).items()}
+    sd["feature_extractor.conv_layers.1.conv.weight"] *= 1.0e5             # (4000x peaks at 55 424 on this input: inside the format)
+    hot = HubertEncoderHIP(sd, precision="fp16")
+    hot.fp16_audit(start=True)
+    hh = hot.forward(x, None)
+    a2 = hot.fp16_audit()
+    assert bool(torch.isfinite(hh).all())
+    assert a2["conv0"]["saturated"] == 0 and a2["conv1"]["saturated"] > 0 and a2["conv1"]["max_abs"] == 65504.0, a2
+    n1 = a2["conv1"]["saturated"]
+    hot.forward(x, None)
+    assert hot.fp16_audit()["conv1"]["saturated"] == 2 * n1                  # accumulates over forwards until restarted
+    hot.fp16_audit(start=True)
+    assert all(v["saturated"] == 0 for v in hot.fp16_audit().values())
+    # bf16 (8 exponent bits) has no such limit: the audit of a bf16 handle stays empty-handed
+    ebf.fp16_audit(start=True)
+    ebf.forward(x, None)
+    assert all(v["saturated"] == 0 and v["max_abs"] == 0.0 for v in ebf.fp16_audit().values())
+    ebf.set_option(10, 0)
+
+
 def test_mixed16_conv_stack_fp16_encoder_bf16(engines, golden_dir):
     """precision="mixed16" (SYLBER_MIXED16): the conv stack is bit-identical to the fp16 mode's, the encoder stages are
     within the bf16 tolerance of the reference goldens, and the hidden states are closer to fp32 than bf16's (about half

@@ -25,6 +25,19 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sequential --
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-other-configs --no-overlap > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-other-configs --no-overlap > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/pmc_mfma -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-other-configs --no-overlap > $OUT/pmc_mfma.log 2>&1
+# round 6: the same passes for BASELINE configs[4] (fp8) and configs[3] (8 x 60 s), so that the `other_configs` rooflines of the
+# bench line are reproducible from profiles/ (kernel durations + HBM traffic per launch)
+for cfg in "fp8 --precision fp8" "longform --batch 8 --clip-seconds 60"; do
+  set -- $cfg; tag=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$tag -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-other-configs --no-overlap "$@" > $OUT/trace_$tag.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$tag -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-other-configs --no-overlap "$@" > $OUT/pmc_fetch_$tag.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$tag -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-other-configs --no-overlap "$@" > $OUT/pmc_write_$tag.log 2>&1
+  mkdir -p $OUT/traffic_$tag
+  cp $(find $OUT/trace_$tag -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_${tag}_sequential.csv
+  cp $(find $OUT/pmc_fetch_$tag -name '*counter_collection.csv' | head -1) $OUT/traffic_$tag/FETCH_SIZE_counter_collection.csv
+  cp $(find $OUT/pmc_write_$tag -name '*counter_collection.csv' | head -1) $OUT/traffic_$tag/WRITE_SIZE_counter_collection.csv
+  rm -rf $OUT/trace_$tag $OUT/pmc_fetch_$tag $OUT/pmc_write_$tag
+done
 cd $ROOT
 cp $(find $OUT/pmc_mfma -name '*counter_collection.csv' | head -1) $OUT/mfma_counters.csv
 rm -rf $OUT/pmc_mfma

@@ -9,6 +9,12 @@ python tools/pmc_mfma.py $F/mfma_counters.csv profiles/${R}_mfma_util.md > /dev/
 cp $F/kernel_stats_pipelined.csv profiles/${R}_kernel_stats_pipelined.csv
 cp $F/kernel_stats_sequential.csv profiles/${R}_kernel_stats_sequential.csv
 for n in bf16 fp16 fp8 fp32 split16 longform sequential ragged exchange_selftest; do tail -1 $F/bench_$n.json > profiles/${R}_bench_$n.json; done
+for tag in fp8 longform; do
+  if [ -d $F/traffic_$tag ]; then
+    python tools/pmc_traffic.py $F/traffic_$tag profiles/${R}_hbm_traffic_$tag > /dev/null || true
+    cp $F/kernel_stats_${tag}_sequential.csv profiles/${R}_kernel_stats_${tag}_sequential.csv
+  fi
+done
 python - "$R" <<'PY'
 import json, sys
 R = sys.argv[1]

@@ -59,7 +59,7 @@ def main():
         print("| tile | " + " | ".join(keys) + " | sum |")
         print("|---|" + "---:|" * (len(keys) + 1))
         allk = list(keys) + ["sum"]
-        best = {k: min(rows[t][k] for t in tiles if t >= 0) for k in allk}
+        best = {k: min([rows[t][k] for t in tiles if t >= 0] or [0.0]) for k in allk}
         for t in tiles:
             print("| %s | " % ("auto" if t < 0 else str(t)) + " | ".join("%.4f%s" % (rows[t][k], "*" if t >= 0 and rows[t][k] == best[k] else "") for k in allk) + " |")
         sys.stdout.flush()
