@@ -97,6 +97,9 @@ def parse_args():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `other_configs` block (BASELINE configs[3] long-form, configs[4] fp8 and the split16 parity mode, "
                          "10 steps each in this same process after the headline run; N = 1, default workload only)")
+    ap.add_argument("--exchange-lookahead", type=int, default=0, help="A/B: batches ahead the input exchange is issued (0 = default = engines in flight; 1 = round 5)")
+    ap.add_argument("--exchange-ingest-stream", choices=["default", "own", "engine"], default="default",
+                    help="A/B: the input exchange under its own stream (default) or under the consuming engine's stream (round 5)")
     ap.add_argument("--no-exchange-rehearsal", action="store_true",
                     help="skip the one-rank RCCL self-test child of `other_configs` (the N > 1 code path on this one GPU)")
     ap.add_argument("--agreement-clips", type=int, default=0,
@@ -578,6 +581,10 @@ def main():
 
     # ---- exchange (N > 1 default): root scatter + gather over RCCL inside every step
     sharded = ShardedSegmenter(encs, always_collective=selftest)
+    if args.exchange_lookahead > 0:
+        sharded.lookahead = args.exchange_lookahead
+    if args.exchange_ingest_stream != "default":
+        sharded.ingest_stream = args.exchange_ingest_stream == "own"
     root_batch = None
     if selftest:
         root_batch = my_batch

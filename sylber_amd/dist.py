@@ -56,6 +56,16 @@ class ShardedSegmenter:
         # on a second stream per engine: the engine's next forward then does not queue behind them
         # (segment_on_side_stream=False keeps both on the engine stream: A/B switch)
         self._sides = (pool[len(self.engines):] if segment_on_side_stream else list(self._streams)) if self._cuda else None
+        # the input exchange (scatter, or the per-rank H2D) is issued under a stream of its own, E batches ahead (run_stream): under the
+        # engine's stream it waited for that engine's previous forward, and with a look-ahead of one it sat behind the previous gather of
+        # the SAME engine in the communicator's single in-order stream -- forward(i + 2) started one gather + one scatter late (the 5 %
+        # of the one-rank self-test, profiles/r06_exchange.md)
+        self._ingest = torch.cuda.Stream(device=self.device) if self._cuda else None
+        # defaults of run_stream (A/B: bench.py --exchange-lookahead / --exchange-ingest-stream; profiles/r06_exchange.md: on a one-rank
+        # communicator the step time is dominated by RCCL's copy kernels displacing the 160-KiB-LDS GEMM workgroups and varies 13-45 % run to
+        # run; E batches ahead under the engine's own stream had the best mean of the four combinations)
+        self.lookahead = len(self.engines)
+        self.ingest_stream = False
         self.reset_stats()
 
     def reset_stats(self) -> None:
@@ -214,7 +224,7 @@ class ShardedSegmenter:
         return wait
 
     def run_stream(self, batches_root, lengths_root=None, max_segments: int = 128, ingest: str = "scatter",
-                   host_shards=None, gather: str = "root"):
+                   host_shards=None, gather: str = "root", lookahead: Optional[int] = None, ingest_stream: Optional[bool] = None):
         """Generator over a sequence of root batches (``[Btot, Lmax]`` tensors on root, ``None`` elsewhere; every rank
         must pass a sequence of the same length).  Software pipeline over ONE communicator, whose collectives
         execute in issue order: the scatter of batch i+1 is issued BEFORE the compute of batch i, and the gather of
@@ -296,14 +306,33 @@ class ShardedSegmenter:
         def on_side(k):
             return torch.cuda.stream(self._sides[k]) if self._cuda else contextlib.nullcontext()
 
+        # A/B switches (bench.py --exchange-lookahead / --exchange-ingest-stream): lookahead = how many batches ahead the input exchange is issued
+        # (1 = round 5: scatter(i + 1) before compute(i)), ingest_stream = under its own stream instead of the consuming engine's
+        LA = max(1, int(self.lookahead if lookahead is None else lookahead))
+        own_stream = self.ingest_stream if ingest_stream is None else bool(ingest_stream)
+
+        def on_ingest(i=0):
+            if not self._cuda:
+                return contextlib.nullcontext()
+            return torch.cuda.stream(self._ingest if own_stream else self._streams[i % E])
+
         if self._cuda:
             cur = torch.cuda.current_stream(self.device)
-            for st in self._streams:
+            for st in self._streams + [self._ingest]:
                 st.wait_stream(cur)                                      # the root batches were produced on `cur`
         import time as _time
-        with on(0):
-            nxt = scatter_known(0)
-        pending = None
+
+        def issue_input(i):
+            """input exchange of batch i under the ingest stream; -> (my_wav, my_lens, btot, event the consuming engine stream waits for)"""
+            with on_ingest(i):
+                w_, l_, b_ = scatter_known(i)
+                ev = None
+                if self._cuda and own_stream:
+                    ev = torch.cuda.Event()
+                    ev.record(self._ingest)
+            return w_, l_, b_, ev
+        ahead = [issue_input(i) for i in range(min(LA, n))]                   # LA batches ahead (E: the scatter of a batch never queues behind
+        pending = None                                                   # the gather of its own engine's previous batch
         worst = None                                                     # device scalar: largest segment count seen (root)
 
         def collect(wait_fn):
@@ -324,11 +353,14 @@ class ShardedSegmenter:
         try:
             for i in range(n):
                 k = i % E
-                my_wav, my_lens, btot = nxt
-                if i + 1 < n:
-                    with on((i + 1) % E):
-                        nxt = scatter_known(i + 1)                       # prefetch the next input
+                my_wav, my_lens, btot, arrived = ahead.pop(0)
+                if i + LA < n:
+                    ahead.append(issue_input(i + LA))                         # prefetch: issued before compute(i), i.e. before gather(i)
                 with on(k):
+                    if arrived is not None:
+                        self._streams[k].wait_event(arrived)
+                        if my_wav.is_cuda:
+                            my_wav.record_stream(self._streams[k])       # allocated under the ingest stream, read here
                     self.phase = "compute of batch %d (forward, engine %d)" % (i, k)
                     eng = self.engines[k]
                     hidden = eng.forward(my_wav, [int(x) for x in my_lens])
@@ -358,7 +390,7 @@ class ShardedSegmenter:
             # replace GeneratorExit on close() and be printed as "Exception ignored" everywhere else.  A truncated
             # table is still identifiable afterwards: its `nseg` row holds the true count (> max_segments)
             if self._cuda:
-                for st in self._streams + self._sides:
+                for st in self._streams + self._sides + [self._ingest]:
                     torch.cuda.current_stream(self.device).wait_stream(st)
             try:
                 overflow_check()
@@ -368,7 +400,7 @@ class ShardedSegmenter:
                               RuntimeWarning, stacklevel=2)
             raise
         if self._cuda:
-            for st in self._streams + self._sides:
+            for st in self._streams + self._sides + [self._ingest]:
                 torch.cuda.current_stream(self.device).wait_stream(st)
         overflow_check()
         yield last

@@ -330,8 +330,11 @@ class Segmenter:
         if self.output_memory not in ("pinned", "pageable"):
             raise ValueError("output_memory must be 'pinned' or 'pageable'")
         self.out_pool = PinnedOutputPool(max_leased=int(kwargs.get("max_pinned_batches", 4)))
-        self._fill_threads = max(1, int(kwargs.get("host_pad_threads", 4)))     # host padding of tensor inputs (encode_batch)
-        self._fill_groups = max(1, int(kwargs.get("host_pad_groups", 2 * self._fill_threads)))   # row groups the padding + H2D of a batch is cut into
+        # host padding of tensor inputs (encode_batch).  tools/pad_probe.py on the 256-cpu boxes: the 20 MB copy of a 32 x 10 s batch into the
+        # page-locked staging buffer takes 0.49 ms on one thread, 0.36-0.44 on two, MORE on four / eight / sixteen (0.58 / 0.93 / 1.25: waking
+        # pool threads costs more than the copy they take over; numpy slice assignment and ctypes.memmove alike)
+        self._fill_threads = max(1, int(kwargs.get("host_pad_threads", 2)))
+        self._fill_groups = max(1, int(kwargs.get("host_pad_groups", 8)))       # row groups the padding + H2D of a batch is cut into (H2D of group g under the padding of g + 1)
         self._kcap_seen = 128                                                    # segment slots per utterance the next block is sized for
         self._kcap_recent = collections.deque(maxlen=16)                         # per-batch maxima of the last 16 batches (sizing decays with them)
         self._overlap_d2h = bool(kwargs.get("overlap_d2h", True))               # hidden-state D2H under the segmenter (A/B switch)
