@@ -16,6 +16,10 @@ extern "C" {
  * operands cold (1 GiB written between the launches, each launch timed by its own event pair) */
 int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
                             int32_t iters, float* ms_out);
+/* the tile id the cost model of the 16-bit GEMM launcher picks for a launch (csrc/gemm_bf16.hip TileModel): host arithmetic only, no device touched.
+ * epi / act as the forward passes them (0 = 16-bit out, 3 = q,k,v, 6 = fp32 residual + LayerNorm; act 1 = GELU), fmt 0 bf16 / 1 fp16,
+ * model = SYLBER_OPT_GEMM_MODEL, kpat = 1 for the 3-tap conv K order.  tests/test_abi.py pins the choices of the headline shapes. */
+int sylber_debug_gemm_pick(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t act, int32_t fmt, int32_t model, int32_t kpat);
 /* the same launch through the TRACE instantiation of the 8-wave 256x256 kernel (s_memtime stamps around the phases of its K
  * loop): out20 = 2 x 10 shader-cycle counters of workgroup 0's waves 0 and 4 (csrc/api.hip sylber_debug_gemm_trace) */
 int sylber_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, unsigned long long* out20,

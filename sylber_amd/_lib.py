@@ -82,6 +82,7 @@ EXPORTS = {
 # include/sylber_hip_dev.h: development aids (tools/ only)
 DEV_EXPORTS = {
     "sylber_debug_gemm_bench": (c_int, [c_int32] * 8 + [POINTER(c_float)]),
+    "sylber_debug_gemm_pick": (c_int, [c_int32] * 8),
     "sylber_debug_gemm_trace": (c_int, [c_int32] * 6 + [POINTER(ctypes.c_uint64), POINTER(c_float)]),
     "sylber_debug_attention_bench": (c_int, [c_int32] * 4 + [POINTER(c_float)]),
     "sylber_debug_poison_workspace": (c_int, [c_void_p, c_int32]),

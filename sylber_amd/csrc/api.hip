@@ -1326,6 +1326,14 @@ static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t
     return rc;
 }
 
+// which tile the cost model of launch_gemm_bf16 picks (host arithmetic only; no device is touched): epi / act as GemmEpi / GemmAct, fmt 0 bf16 / 1 fp16,
+// model = SYLBER_OPT_GEMM_MODEL (0: the handle owns the chip, 5: shares it), kpat = 1 for the 3-tap conv K order
+extern "C" int sylber_debug_gemm_pick(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t act, int32_t fmt, int32_t model, int32_t kpat) {
+    GemmArgs g = {};
+    g.M = M; g.N = N; g.K = K; g.act = act; g.fmt = fmt; g.tune_model = model; g.kpat = kpat;
+    return gemm_pick_tile(epi, g);
+}
+
 extern "C" int sylber_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t epi, int32_t act, int32_t cfg,
                                        int32_t iters, float* ms_out) {
     return gemm_bench_impl(M, N, K, ldx, epi, act, cfg, iters, ms_out, nullptr);

@@ -939,48 +939,59 @@ static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
 //     3/4-size tiles at 192 rows)
 //   * a row split: rows of the full rounds on the chosen tile, rows [M1, M) as a second launch on another tile (GemmArgs::m_begin).
 //     Measured not to pay with the tiles that exist (see below): kept as a forced option and as the test vehicle of m_begin.
-template <int EPI, int ACT, int FMT>
-static int launch_f(const GemmArgs& a, hipStream_t s) {
-    struct Cfg { int id, bm, bn, per_cu; double eff, pr0; };
-    // 80 / 90: the hand-scheduled 4-wave kernels (gemm_asm.hip).  Their K loop runs ~25 % above the 8-wave kernel's, but one
-    // wave per SIMD leaves a tile's prologue and epilogue uncovered (~9 us + ~5 us of GELU against a 17 us K = 768 loop), so
-    // they are rated for long K only (same-box tools/gemm_bench.py: conv1-4 +3-10 %, FFN2 +7 %, K = 768 shapes -5-20 %).
-    const bool asm_ok = FMT != FMT_SPLIT && gemm_asm_applicable(EPI, a) && a.K >= 256;
-    const bool long_k = a.K >= 1024;
-    // 95: the same loop on eight waves (two per SIMD share the epilogue's VALU work): the GELU GEMMs, K = 768 included.
-    // 85 / 91 / 97 = 80 / 90 / 95 with three ring slots for X (bf16 only): never slower hot, 5-15 % faster on cold activations
-    const bool x3 = FMT != FMT_SPLIT;
-    // 86 = the X3 loop on a 256x128 tile / four waves: slower per FLOP than 97 (923 vs 974 TF on conv1), but a launch of 64 row tiles
-    // x 512 columns (conv6) fills 256 CUs with it and half of them with 256x256 tiles: 22.0 vs 29.7 us
-    // 51 / 57 = tiles 91 / 97 at 192 rows (round 6), rated GEMM_H192_EFF of their siblings (fewer FLOPs per staged byte)
-    //
-    // Round 6 re-fitted the model to IN-FORWARD launch times (sequential profile, cold activations, seven batch shapes x every tile forced:
-    // tools/tile_pick_sweep.py -> profiles/r06_tile_pick.md) instead of the hot micro-benchmark it came from:
-    //   * a PARTIAL last round is not a whole round.  Tiles beyond the last full round fill a fraction f of the launch's slots; that round
-    //     costs pr0 + (1 - pr0) f of a full one: pr0 = 0 for the two-per-CU kernels (measured proportional: q,k,v on 128x192 takes 4.4
-    //     round-times for 4.4 rounds of tiles), 0.4 for the persistent hand-scheduled tiles (a 0.41-full round of tile 91 costs 0.63, a
-    //     0.47-full one 0.70), 1 for the 8-wave hipcc kernel (its 3.3 rounds cost 4)
-    //   * the hipcc 8-wave kernel (10) was rated 1.20 for every epilogue; with the fp32-residual epilogue it runs at 1.0 (FFN2 1.93 vs
-    //     1.15 ms per forward at 8 x 60 s) and was being picked for q,k,v / out-proj wherever its tile count rounded well
-    //   * q,k,v: the 128x192 two-per-CU kernel is rated 1.09 (0.614 vs 0.645 ms per forward on tile 91 at 32 x 10 s, 0.89 vs 1.00 at 8 x 60 s)
-    // tune_model = 5 (SYLBER_OPT_GEMM_MODEL: "this handle shares the chip with another in-flight batch") = the round-5 constants, whole rounds, no
-    // 192-row tiles: with two batches in flight the other stream's kernels take the CUs a partial round leaves idle, and that selection measured
-    // fastest there on five batch shapes (profiles/r06_tile_model_ab.md); alone on the chip it is the slower one.
-    const bool r5 = a.tune_model == 5;
-    constexpr int NCFG = 9;
-    const double e10 = r5 || EPI == EPI_BF16 ? 1.20 : (EPI == EPI_QK ? 1.15 : 1.00);
-    const double e4 = !r5 && EPI == EPI_QK ? 1.09 : 1.00;
-    // tune_model = 2: "throughput" -- the handle is one of several in flight (bench.py's pipeline, Segmenter.stream's neighbours): the CUs a
-    // partial round leaves idle are taken by the other stream's kernels, so a partial round costs only its share (pr0 = 0 for every tile)
-    const bool thr = a.tune_model == 2;
-    const double pa = r5 ? 1.0 : (thr ? 0.0 : GEMM_PR0_ASM), p2 = r5 ? 1.0 : 0.0, p10 = thr ? 0.0 : 1.0;
-    const Cfg cfgs[NCFG] = {{3, 128, 128, 2, r5 ? 0.93 : 0.95, p2}, {4, 128, 192, 2, e4, p2}, {10, 256, 256, 1, e10, p10},
-                            {x3 ? 85 : 80, 256, 256, 1, long_k ? (r5 ? 1.28 : 1.20) : 1.10, pa}, {91, 256, 192, 1, long_k ? 1.10 : 1.04, pa},
-                            {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27, pa}, {86, 256, 128, 1, 1.10, pa},
-                            {51, 192, 192, 1, (long_k ? 1.10 : 1.04) * GEMM_H192_EFF, pa}, {57, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa}};
-    // cost of configuration i over `rows` rows: (full rounds + cost of the partial round) x (tile area per CU) / eff
-    auto cost_of = [&](int i, long rows) -> double {
-        const Cfg& c = cfgs[i];
+// The tile cost model (shared by launch_f and the CPU-tier regression test through sylber_debug_gemm_pick): configuration table and cost of
+// configuration i over `rows` rows of launch `a`, for epilogue EPI and operand format FMT.
+struct TileCfg { int id, bm, bn, per_cu; double eff, pr0; };
+struct TileModel {
+    static constexpr int NCFG = 9;
+    TileCfg cfgs[NCFG];
+    bool asm_ok, r5;
+    int EPI;
+    const GemmArgs* a;
+    TileModel(int EPI_, int FMT, const GemmArgs& a_) : EPI(EPI_), a(&a_) {
+        const GemmArgs& a = a_;
+        // 80 / 90: the hand-scheduled 4-wave kernels (gemm_asm.hip).  Their K loop runs ~25 % above the 8-wave kernel's, but one
+        // wave per SIMD leaves a tile's prologue and epilogue uncovered (~9 us + ~5 us of GELU against a 17 us K = 768 loop), so
+        // they are rated for long K only (same-box tools/gemm_bench.py: conv1-4 +3-10 %, FFN2 +7 %, K = 768 shapes -5-20 %).
+        asm_ok = FMT != FMT_SPLIT && gemm_asm_applicable(EPI, a) && a.K >= 256;
+        const bool long_k = a.K >= 1024;
+        // 95: the same loop on eight waves (two per SIMD share the epilogue's VALU work): the GELU GEMMs, K = 768 included.
+        // 85 / 91 / 97 = 80 / 90 / 95 with three ring slots for X (bf16 only): never slower hot, 5-15 % faster on cold activations
+        const bool x3 = FMT != FMT_SPLIT;
+        // 86 = the X3 loop on a 256x128 tile / four waves: slower per FLOP than 97 (923 vs 974 TF on conv1), but a launch of 64 row tiles
+        // x 512 columns (conv6) fills 256 CUs with it and half of them with 256x256 tiles: 22.0 vs 29.7 us
+        // 51 / 57 = tiles 91 / 97 at 192 rows (round 6), rated GEMM_H192_EFF of their siblings (fewer FLOPs per staged byte)
+        //
+        // Round 6 re-fitted the model to IN-FORWARD launch times (sequential profile, cold activations, seven batch shapes x every tile forced:
+        // tools/tile_pick_sweep.py -> profiles/r06_tile_pick.md) instead of the hot micro-benchmark it came from:
+        //   * a PARTIAL last round is not a whole round.  Tiles beyond the last full round fill a fraction f of the launch's slots; that round
+        //     costs pr0 + (1 - pr0) f of a full one: pr0 = 0.4 for the persistent hand-scheduled tiles (a 0.41-full round of tile 91 costs 0.63, a
+        //     0.47-full one 0.70) and for the two-per-CU kernels, 1 for the 8-wave hipcc kernel (its 3.3 rounds cost 4)
+        //   * the hipcc 8-wave kernel (10) was rated 1.20 for every epilogue; with the fp32-residual epilogue it runs at 1.0 (FFN2 1.93 vs
+        //     1.15 ms per forward at 8 x 60 s) and was being picked for q,k,v / out-proj wherever its tile count rounded well
+        //   * q,k,v: the 128x192 two-per-CU kernel is rated 1.09 (0.614 vs 0.645 ms per forward on tile 91 at 32 x 10 s, 0.89 vs 1.00 at 8 x 60 s)
+        // tune_model = 5 (SYLBER_OPT_GEMM_MODEL: "this handle shares the chip with another in-flight batch") = the round-5 constants, whole rounds, no
+        // 192-row tiles: with two batches in flight the other stream's kernels take the CUs a partial round leaves idle, and that selection measured
+        // fastest there on five batch shapes (profiles/r06_tile_model_ab.md); alone on the chip it is the slower one.
+        r5 = a.tune_model == 5;
+        const double e10 = r5 || EPI == EPI_BF16 ? 1.20 : (EPI == EPI_QK ? 1.15 : 1.00);
+        const double e4 = !r5 && EPI == EPI_QK ? 1.09 : 1.00;
+        // tune_model = 2: "throughput" -- the handle is one of several in flight (bench.py's pipeline, Segmenter.stream's neighbours): the CUs a
+        // partial round leaves idle are taken by the other stream's kernels, so a partial round costs only its share (pr0 = 0 for every tile)
+        const bool thr = a.tune_model == 2;
+        // (two-per-CU kernels: q,k,v's 4.4 rounds cost 4.4 round-times, but FFN2's 0.75 of a round costs 0.90 of one and 1.47 rounds cost 1.6: the same
+        //  pr0 as the persistent tiles fits all three within 5 %; charging them proportionally made the model take 128x192 for FFN2 where tile 51 is 10-15 % faster)
+        const double pa = r5 ? 1.0 : (thr ? 0.0 : GEMM_PR0_ASM), p2 = r5 ? 1.0 : (thr ? 0.0 : GEMM_PR0_ASM), p10 = thr ? 0.0 : 1.0;
+        const TileCfg init[NCFG] = {{3, 128, 128, 2, r5 ? 0.93 : 0.95, p2}, {4, 128, 192, 2, e4, p2}, {10, 256, 256, 1, e10, p10},
+                                {x3 ? 85 : 80, 256, 256, 1, long_k ? (r5 ? 1.28 : 1.20) : (!r5 && EPI == EPI_QK ? 1.00 : 1.10), pa},   // (q,k,v on 85: 0.795 vs 0.691 ms on 128x192 at 24 x 15 s)
+                                {91, 256, 192, 1, long_k ? 1.10 : 1.04, pa},
+                                {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27, pa}, {86, 256, 128, 1, 1.10, pa},
+                                {51, 192, 192, 1, (long_k ? 1.10 : 1.04) * GEMM_H192_EFF, pa}, {57, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa}};
+        for (int i = 0; i < NCFG; ++i) cfgs[i] = init[i];
+    }
+    double cost_of(int i, long rows) const {
+        const GemmArgs& a = *this->a;
+        const TileCfg& c = cfgs[i];
         if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, c.id))) return 1e300;   // only tiles that exist for this epilogue / format
         if ((c.id == 51 || c.id == 57) && (a.tune_h192 < 0 || r5)) return 1e300;
         const long tm = (rows + c.bm - 1) / c.bm, tn = (a.N + c.bn - 1) / c.bn;
@@ -995,8 +1006,9 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
             else rounds += c.pr0 + (1.0 - c.pr0) * (double)rem / (double)slots;
         }
         return rounds * c.per_cu * c.bm * c.bn / c.eff;
-    };
-    auto pick = [&](long rows, double* cost) -> int {
+
+    }
+    int pick(long rows, double* cost) const {
         int best = 0;
         double best_cost = 1e300;
         for (int i = 0; i < NCFG; ++i) {
@@ -1005,7 +1017,21 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
         }
         *cost = best_cost;
         return best;
-    };
+    }
+};
+int gemm_pick_tile(int epi, const GemmArgs& a) {
+    TileModel m(epi, a.fmt, a);
+    double c;
+    return m.cfgs[m.pick(a.M - a.m_begin, &c)].id;
+}
+
+template <int EPI, int ACT, int FMT>
+static int launch_f(const GemmArgs& a, hipStream_t s) {
+    const TileModel tm_(EPI, FMT, a);
+    const TileCfg* cfgs = tm_.cfgs;
+    constexpr int NCFG = TileModel::NCFG;
+    auto cost_of = [&](int i, long rows) -> double { return tm_.cost_of(i, rows); };
+    auto pick = [&](long rows, double* cost) -> int { return tm_.pick(rows, cost); };
     const long rows = a.M - a.m_begin;
     double whole_cost;
     const int best = pick(rows, &whole_cost);
@@ -1019,7 +1045,7 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
         int bi = -1;
         for (int i = 0; i < NCFG; ++i) if (cfgs[i].id == cfg) bi = i;
         if (bi >= 0 && cost_of(bi, rows) < 1e299) {
-            const Cfg& c = cfgs[bi];
+            const TileCfg& c = cfgs[bi];
             const long tm = (rows + c.bm - 1) / c.bm, tn = (a.N + c.bn - 1) / c.bn, slots = 256L * c.per_cu;
             const long full = (tm * tn) / slots, rem = tm * tn - full * slots;
             const long main_tiles_m = full * slots / tn;        // whole row tiles inside the full rounds

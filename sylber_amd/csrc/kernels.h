@@ -59,6 +59,8 @@ struct GemmArgs {
 };
 
 int launch_gemm_bf16(int epi, const GemmArgs& a, hipStream_t s);
+// the tile id launch_gemm_bf16's cost model picks for this launch (host arithmetic only: no GPU needed; tests/test_abi.py pins the headline shapes)
+int gemm_pick_tile(int epi, const GemmArgs& a);
 // residual GEMM + the LayerNorm that follows it in one launch (gemm_rowln.hip): N = 768, full rows per workgroup
 bool gemm_rowln_applicable(const GemmArgs& a);
 int launch_gemm_rowln(const GemmArgs& a, hipStream_t s);
