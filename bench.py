@@ -100,6 +100,9 @@ def parse_args():
     ap.add_argument("--exchange-lookahead", type=int, default=0, help="A/B: batches ahead the input exchange is issued (0 = default = engines in flight; 1 = round 5)")
     ap.add_argument("--exchange-ingest-stream", choices=["default", "own", "engine"], default="default",
                     help="A/B: the input exchange under its own stream (default) or under the consuming engine's stream (round 5)")
+    ap.add_argument("--exchange-fresh-results", action="store_true",
+                    help="A/B: the gathered tensors of every step freshly allocated (run_stream's default) instead of from its buffer ring "
+                         "(reuse_results=True: valid until 2 x engines - 1 further batches have been yielded)")
     ap.add_argument("--no-exchange-rehearsal", action="store_true",
                     help="skip the one-rank RCCL self-test child of `other_configs` (the N > 1 code path on this one GPU)")
     ap.add_argument("--agreement-clips", type=int, default=0,
@@ -580,7 +583,7 @@ def main():
         return evs
 
     # ---- exchange (N > 1 default): root scatter + gather over RCCL inside every step
-    sharded = ShardedSegmenter(encs, always_collective=selftest)
+    sharded = ShardedSegmenter(encs, always_collective=selftest, streams=pool_st if len(pool_st) >= 2 * len(encs) else None)
     if args.exchange_lookahead > 0:
         sharded.lookahead = args.exchange_lookahead
     if args.exchange_ingest_stream != "default":
@@ -599,14 +602,20 @@ def main():
 
     gather_mode = {"m": args.gather}
 
+    host_issue = {"s": 0.0, "n": 0}
+
     def exchange_steps(n):
         evs = []
         src = [root_batch] * n if rank == 0 else [None] * n
+        t_issue0 = time.perf_counter()
         for _o in sharded.run_stream(src, None, max_segments=min(T_frames, 192), ingest=args.ingest,
-                                     host_shards=[host_shard] * n if host_shard is not None else None, gather=gather_mode["m"]):
+                                     host_shards=[host_shard] * n if host_shard is not None else None, gather=gather_mode["m"],
+                                     reuse_results=not args.exchange_fresh_results):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream(dev))
             evs.append(ev)
+        # host time to ISSUE the n steps (nothing in the loop waits for the GPU): if this is the step time, the step is host-bound
+        host_issue["s"], host_issue["n"] = time.perf_counter() - t_issue0, n
         return evs
 
     ex_txt = ("root scatter over RCCL in every step, results left on their ranks (gather=none)" if args.gather == "none" else
@@ -705,7 +714,9 @@ def main():
         try:
             exchange_steps(args.warmup)                  # (its own warm-up, so that the counters below cover K steps only)
             sharded.reset_stats()
+            ms0_ = torch.cuda.memory_stats(dev)
             x_elapsed, x_med = timed(exchange_steps, warmup=0)
+            ms1_ = torch.cuda.memory_stats(dev)
             st_ = sharded.stats
             x_info = {"per_rank_ms_per_step": per_rank.get("last"),
                       "root_wait_ms_per_step": round(1e3 * st_["wait_s"] / max(st_["steps"], 1), 3),
@@ -713,7 +724,14 @@ def main():
                       "scatter_bytes_per_step_root": st_["scatter_bytes"] // max(st_["steps"], 1),
                       "gather_bytes_per_step_root": st_["gather_bytes"] // max(st_["steps"], 1),
                       "h2d_bytes_per_step_rank0": st_["h2d_bytes"] // max(st_["steps"], 1),
-                      "ingest": args.ingest}
+                      "ingest": args.ingest,
+                      "streams_moved_off_the_communicators_queue_rank0": getattr(sharded, "comm_queue_collisions", None),
+                      "host_issue_ms_per_step_by_phase_rank0": {k_: round(1e3 * v_ / max(st_["steps"], 1), 3) for k_, v_ in st_["host_s"].items()},
+                      # a hipMalloc inside the timed steps synchronises the device (the caching allocator could not reuse a block that another
+                      # stream still holds): must be 0 in steady state
+                      "device_mallocs_during_timing_rank0": int(ms1_.get("num_device_alloc", 0) - ms0_.get("num_device_alloc", 0)),
+                      "alloc_retries_during_timing_rank0": int(ms1_.get("num_alloc_retries", 0) - ms0_.get("num_alloc_retries", 0)),
+                      "reserved_gb_rank0": round(ms1_.get("reserved_bytes.all.current", 0) / 2 ** 30, 2)}
             if args.no_exchange and not selftest:
                 secondary = ("exchange", x_elapsed, x_med)
             else:

@@ -13,6 +13,8 @@ features.  No collective sits inside the compute path.
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -29,7 +31,7 @@ class ShardedSegmenter:
     own HIP stream: the memory-bound phases of one batch then run under the MFMA phases of the other."""
 
     def __init__(self, engine, norm_threshold: float = 2.6, merge_threshold: float = 0.8, group=None,
-                 always_collective: bool = False, segment_on_side_stream: bool = True):
+                 always_collective: bool = False, segment_on_side_stream: bool = True, streams=None):
         self.engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
         if len(self.engines) >= 2:                       # run_stream keeps one batch in flight per engine: they share the chip
             for e_ in self.engines:
@@ -47,10 +49,30 @@ class ShardedSegmenter:
         self._coll = self.world > 1 or (always_collective and dist.is_initialized())
         self._cuda = torch.device(self.device).type == "cuda"
         # streams that share a hardware queue run one after the other (sylber_amd/streams.py): probe for independent ones
+        # `streams`: 2 x engines streams the caller already holds (bench.py passes the ones its resident steps ran on).  A process that leases
+        # MORE independent streams than it needs fills every hardware queue (GPU_MAX_HW_QUEUES) with its own streams, and RCCL's internal
+        # stream then has to share a queue with one of them: its copies, which wait for a batch's boundary detection, sit in front of the
+        # other engine's next forward and the two batches in flight run one after the other (6-8 ms per step instead of 5:
+        # profiles/r06_exchange.md)
         pool = None
         if self._cuda:
-            from .streams import concurrent_streams
-            pool = concurrent_streams(2 * len(self.engines), self.device)
+            if streams is not None:
+                pool = list(streams)
+                assert len(pool) >= 2 * len(self.engines), "streams= must hold 2 x engines streams"
+            else:
+                from .streams import concurrent_streams
+                pool = concurrent_streams(2 * len(self.engines), self.device)
+        # ... and none of them may share its hardware queue with the communicator's own stream (streams.serialised_with_communicator: which queue
+        # RCCL's stream lands on changes from one process start to the next).  Collective: every rank constructs its ShardedSegmenter at the same point.
+        self.comm_queue_collisions = 0
+        if self._cuda and self._coll and hasattr(torch.cuda, "_sleep") and not os.environ.get("SYLBER_NO_STREAM_PROBE"):
+            from .streams import concurrent_streams, serialised_with_communicator
+            for j_ in range(2 * len(self.engines)):               # ONE probe per stream: the same number of collectives on every rank
+                if serialised_with_communicator(pool[j_], self.group):
+                    self.comm_queue_collisions += 1
+                    others = [p_ for i_, p_ in enumerate(pool) if i_ != j_]
+                    # a stream independent of the colliding one is off the communicator's queue too (no second probe: no further collective)
+                    pool[j_] = concurrent_streams(1, self.device, avoid=others + [pool[j_]])[0]
         self._streams = pool[:len(self.engines)] if self._cuda else None
         # boundary detection (one workgroup per utterance, ~0.25 ms of latency on 32 CUs) and the gather that follows it run
         # on a second stream per engine: the engine's next forward then does not queue behind them
@@ -71,7 +93,10 @@ class ShardedSegmenter:
     def reset_stats(self) -> None:
         """counters of ``run_stream`` (what the N > 1 bench line reports): host seconds this rank spent blocked in the
         gather hand-over, bytes it sent / received through the communicator, H2D bytes of the per-rank ingest"""
-        self.stats = {"steps": 0, "wait_s": 0.0, "scatter_bytes": 0, "gather_bytes": 0, "h2d_bytes": 0}
+        self.stats = {"steps": 0, "wait_s": 0.0, "scatter_bytes": 0, "gather_bytes": 0, "h2d_bytes": 0,
+                      # host seconds run_stream spent ISSUING each phase (nothing in it waits for the GPU: a step whose issue time exceeds its GPU
+                      # time is host-bound -- found in round 6: the one-rank self-test was)
+                      "host_s": {"input": 0.0, "forward": 0.0, "segment": 0.0, "gather": 0.0, "collect": 0.0}}
         # what this rank was doing last (a watchdog-tripped bench line names it: "which collective hung")
         self.phase = "idle"
 
@@ -148,7 +173,8 @@ class ShardedSegmenter:
         return self.gather(hidden, seg, nseg, feats, btot)
 
     # ---- overlapped stream of batches --------------------------------------------------------------
-    def gather_async(self, hidden, seg, nseg, feats, btot: int, max_segments: int, check: bool = True):
+    def gather_async(self, hidden, seg, nseg, feats, btot: int, max_segments: int, check: bool = True, ring_set=None, rbuf=None,
+                     ring_results: bool = False):
         """Like ``gather`` but with asynchronous collectives and WITHOUT the host round trip that trims the pooled
         features to the global max segment count: the first ``max_segments`` slots are exchanged instead.  Returns a
         zero-argument ``wait`` function.  An utterance with more segments than that is an error: with ``check`` the
@@ -156,7 +182,15 @@ class ShardedSegmenter:
         count ONCE after its loop (``wait.nmax`` = device scalar), so that no step contains a host synchronisation."""
         W = self.world
         k = max(1, min(int(max_segments), seg.shape[1]))
-        parts = [hidden.contiguous(), seg[:, :k].contiguous(), nseg.contiguous(), feats[:, :k].contiguous()]
+        if ring_set is not None and rbuf is not None:
+            # the packed [:, :k] copies go into the set's own buffers (run_stream's ring: no allocation in steady state)
+            seg_k = rbuf(ring_set, "seg_k", (seg.shape[0], k, 2), seg.dtype)
+            seg_k.copy_(seg[:, :k])
+            feats_k = rbuf(ring_set, "feat_k", (feats.shape[0], k, feats.shape[2]), feats.dtype)
+            feats_k.copy_(feats[:, :k])
+            parts = [hidden, seg_k, nseg, feats_k]
+        else:
+            parts = [hidden.contiguous(), seg[:, :k].contiguous(), nseg.contiguous(), feats[:, :k].contiguous()]
 
         def too_many(n):
             return RuntimeError("an utterance has %d segments, more than max_segments=%d" % (n, k))
@@ -179,9 +213,14 @@ class ShardedSegmenter:
             wait1.nmax = nmax
             return wait1
         fulls, works = [], []
-        for t in parts:
+        for j_, t in enumerate(parts):
             # root receives straight into the slices of ONE [W * Bper, ...] tensor: no concatenation copy afterwards
-            full = torch.empty((W * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) if self.rank == 0 else None
+            if self.rank != 0:
+                full = None
+            elif ring_results and ring_set is not None and rbuf is not None:
+                full = rbuf(ring_set, "full%d" % j_, (W * t.shape[0],) + tuple(t.shape[1:]), t.dtype)
+            else:
+                full = torch.empty((W * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             o = list(full.view((W, t.shape[0]) + tuple(t.shape[1:])).unbind(0)) if self.rank == 0 else None
             works.append(dist.gather(t, o, dst=0, group=self.group, async_op=True))
             fulls.append(full)
@@ -201,6 +240,7 @@ class ShardedSegmenter:
         wait.nmax = None
         _keep = parts                                      # the sources must outlive the collectives
         wait.keep = _keep
+        wait.works = works                                 # (run_stream's ring: the next writer of these source buffers waits for them)
         return wait
 
     def keep_local(self, hidden, seg, nseg, feats, mine: int, max_segments: int):
@@ -224,7 +264,8 @@ class ShardedSegmenter:
         return wait
 
     def run_stream(self, batches_root, lengths_root=None, max_segments: int = 128, ingest: str = "scatter",
-                   host_shards=None, gather: str = "root", lookahead: Optional[int] = None, ingest_stream: Optional[bool] = None):
+                   host_shards=None, gather: str = "root", lookahead: Optional[int] = None, ingest_stream: Optional[bool] = None,
+                   reuse_results: bool = False):
         """Generator over a sequence of root batches (``[Btot, Lmax]`` tensors on root, ``None`` elsewhere; every rank
         must pass a sequence of the same length).  Software pipeline over ONE communicator, whose collectives
         execute in issue order: the scatter of batch i+1 is issued BEFORE the compute of batch i, and the gather of
@@ -240,6 +281,12 @@ class ShardedSegmenter:
         ``[rank * Bper, min((rank + 1) * Bper, Btot))`` of each batch (``hidden, seg[:, :max_segments], nseg, feats[:, :max_segments]``)
         and checks its own overflow; the deployment of a corpus job whose ranks write their own shards, and the upper bound of what
         the root gather can reach.  The overflow test of ``max_segments`` runs once, after the last step: a batch yielded
+        ``reuse_results=True`` (a consumer that is done with a batch's tensors before it asks for the fourth batch after it -- a corpus
+        loop that writes each result out, ``bench.py``): the gathered tensors root yields come from the same ring as the step's other buffers
+        and are valid until ``2 x engines - 1`` further batches have been yielded (GPU-side: the gather that overwrites them waits for the
+        work the consumer had queued on its stream when it asked for the next batch).  Default False: fresh tensors every step (the caching
+        allocator then has to find ~68 MB per step that another stream just released, and calls hipMalloc -- a device synchronisation -- about
+        once per step: profiles/r06_exchange.md).
         EARLIER may therefore carry a table truncated to ``max_segments`` rows (its ``nseg`` row still holds the true count,
         so ``nseg[i] > max_segments`` identifies it); the error is raised when the generator is exhausted; ``close()`` /
         garbage collection of a generator the consumer abandoned early issue a ``RuntimeWarning`` instead (``GeneratorExit`` path below)."""
@@ -270,19 +317,46 @@ class ShardedSegmenter:
             dist.broadcast(lens_all, src=0, group=self.group)
         lens_h = lens_all.tolist()
 
+        # Device buffers of the steps come from a RING of grow-only sets, not from the caching allocator (round 6): a step allocated ~190 MB
+        # (input block, hidden states, tables, pooled features, their packed copies) under two or three streams and handed them to RCCL's
+        # stream; blocks shared between streams come back late, so the allocator kept calling hipMalloc in steady state -- 2.4 times per
+        # step, each one a device synchronisation: THAT was the 5-65 % "cost of the exchange" of the one-rank self-test
+        # (profiles/r06_exchange.md).  Set (i // E) % RING_DEPTH of engine i % E serves batch i; before a set is written again the engine's
+        # stream waits for the gather that last read it.  Only where results are COPIED out before they reach the caller (root gather over a
+        # communicator, engines that take out=): with gather="none" or a world of one the caller receives the engine's own tensors.
+        E_ = len(self.engines)
+        RING_DEPTH = 2
+        use_ring = (self._cuda and self._coll and gather == "root"
+                    and all(getattr(e_, "supports_out", False) for e_ in self.engines))
+        ring = self.__dict__.setdefault("_ring", {}) if use_ring else None
+
+        def ring_set(i):
+            return ring.setdefault((i % E_, (i // E_) % RING_DEPTH), {"works": None})
+
+        def rbuf(d, key, shape, dtype):
+            numel = 1
+            for x in shape:
+                numel *= int(x)
+            b = d.get(key)
+            if b is None or b.numel() < numel or b.dtype != dtype:
+                if b is not None:
+                    torch.cuda.synchronize(self.device)          # (grow-only: a larger batch shape than any before)
+                b = d[key] = torch.empty(int(numel * 1.1) + 64, dtype=dtype, device=self.device)
+            return b[:numel].view(*shape)
+
         def scatter_known(i):
             btot, lmax = int(shapes_h[i][0]), int(shapes_h[i][1])
             bper = (btot + W - 1) // W
             mine = (lens_h[i][:btot] + [lmax] * (bper * W - btot))[self.rank * bper:(self.rank + 1) * bper]
             if ingest == "per-rank":
                 src = host_shards[i]
-                my_wav = torch.empty(bper, lmax, dtype=torch.float32, device=self.device)
+                my_wav = rbuf(ring_set(i), "wav", (bper, lmax), torch.float32) if use_ring else torch.empty(bper, lmax, dtype=torch.float32, device=self.device)
                 my_wav.copy_(src, non_blocking=True)
                 self.stats["h2d_bytes"] += my_wav.numel() * 4
                 return my_wav, mine, btot
             if not self._coll:
                 return batches[i], mine, btot
-            my_wav = torch.empty(bper, lmax, dtype=torch.float32, device=self.device)
+            my_wav = rbuf(ring_set(i), "wav", (bper, lmax), torch.float32) if use_ring else torch.empty(bper, lmax, dtype=torch.float32, device=self.device)
             self.stats["scatter_bytes"] += my_wav.numel() * 4 * ((W - 1) if self.rank == 0 else 1)
             chunks = None
             if self.rank == 0:
@@ -322,8 +396,17 @@ class ShardedSegmenter:
                 st.wait_stream(cur)                                      # the root batches were produced on `cur`
         import time as _time
 
+        hs = self.stats["host_s"]
+
         def issue_input(i):
             """input exchange of batch i under the ingest stream; -> (my_wav, my_lens, btot, event the consuming engine stream waits for)"""
+            t_h = _time.perf_counter()
+            try:
+                return _issue_input(i)
+            finally:
+                hs["input"] += _time.perf_counter() - t_h
+
+        def _issue_input(i):
             with on_ingest(i):
                 w_, l_, b_ = scatter_known(i)
                 ev = None
@@ -356,6 +439,7 @@ class ShardedSegmenter:
                 my_wav, my_lens, btot, arrived = ahead.pop(0)
                 if i + LA < n:
                     ahead.append(issue_input(i + LA))                         # prefetch: issued before compute(i), i.e. before gather(i)
+                t_h = _time.perf_counter()
                 with on(k):
                     if arrived is not None:
                         self._streams[k].wait_event(arrived)
@@ -363,25 +447,61 @@ class ShardedSegmenter:
                             my_wav.record_stream(self._streams[k])       # allocated under the ingest stream, read here
                     self.phase = "compute of batch %d (forward, engine %d)" % (i, k)
                     eng = self.engines[k]
-                    hidden = eng.forward(my_wav, [int(x) for x in my_lens])
+                    rs = None
+                    if use_ring:
+                        rs = ring_set(i)
+                        if rs["works"] is not None:                      # the gather that last read this set's buffers (RING_DEPTH x E batches ago)
+                            for wk in rs["works"]:
+                                wk.wait()                                # (stream-side wait of the engine's stream; long done in steady state)
+                            rs["works"] = None
+                        T_ = eng.num_frames(my_wav.shape[1])
+                        hidden = eng.forward(my_wav, [int(x) for x in my_lens], out=rbuf(rs, "hid", (my_wav.shape[0], T_, 768), torch.float32))
+                    else:
+                        hidden = eng.forward(my_wav, [int(x) for x in my_lens])
                     ready = None
                     if self._cuda:
                         ready = torch.cuda.Event()
                         ready.record(self._streams[k])
+                hs["forward"] += _time.perf_counter() - t_h
+                t_h = _time.perf_counter()
                 with on_side(k):
                     if ready is not None:
                         self._sides[k].wait_event(ready)
                         hidden.record_stream(self._sides[k])             # allocated under the engine stream, read here
                     self.phase = "segmentation of batch %d (engine %d, side stream)" % (i, k)
-                    seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold)
+                    if rs is not None:
+                        B_, T_ = hidden.shape[0], hidden.shape[1]
+                        seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold,
+                                                       out=(rbuf(rs, "seg", (B_, T_, 2), torch.int64), rbuf(rs, "nseg", (B_,), torch.int32),
+                                                            rbuf(rs, "feat", (B_, T_, 768), torch.float32)))
+                    else:
+                        seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold)
                     self.phase = "issue of the asynchronous gather of batch %d" % i
+                    hs["segment"] += _time.perf_counter() - t_h
+                    t_h = _time.perf_counter()
                     if gather == "none":
                         bper_ = hidden.shape[0]
                         wait = self.keep_local(hidden, seg, nseg, feats, max(0, min(bper_, btot - self.rank * bper_)), max_segments)
                     else:
-                        wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False)
+                        if rs is not None and reuse_results and rs.get("consumed") is not None:
+                            self._sides[k].wait_event(rs["consumed"])   # the caller's queued work on the results this gather overwrites
+                        wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False, ring_set=rs, rbuf=rbuf if rs is not None else None,
+                                                 ring_results=reuse_results)
+                        if rs is not None:
+                            rs["works"] = getattr(wait, "works", None)
+                            wait.ring_set = rs
+                hs["gather"] += _time.perf_counter() - t_h
                 if pending is not None:
-                    yield collect(pending)
+                    yielded = pending
+                    t_h = _time.perf_counter()
+                    res_ = collect(pending)
+                    hs["collect"] += _time.perf_counter() - t_h
+                    yield res_
+                    # (resumed: whatever the consumer does with that batch is queued on its stream by now)
+                    if use_ring and reuse_results and getattr(yielded, "ring_set", None) is not None:
+                        ev_c = torch.cuda.Event()
+                        ev_c.record(torch.cuda.current_stream(self.device))
+                        yielded.ring_set["consumed"] = ev_c
                 pending = wait
             last = collect(pending)
         except GeneratorExit:

@@ -134,6 +134,8 @@ class PinnedOutputPool:
 class HubertEncoderHIP:
     """The (1) boundary of include/sylber_hip.h: weights -> handle, waveform batch -> hidden states."""
 
+    supports_out = True          # forward / segment take caller-owned output tensors (out=): ShardedSegmenter.run_stream's buffer ring
+
     def __init__(self, state_dict: Dict[str, torch.Tensor], num_layers: int = NUM_LAYERS, device: str = "cuda",
                  precision: str = "bf16"):
         self.lib = _lib.load()

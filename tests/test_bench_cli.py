@@ -70,3 +70,16 @@ def test_attention_roofline_accounting():
     assert abs(r["achieved"] - 9 * 4.0 * 32 * 12 * 499 * 499 * 64 / 0.333e-3 / 1e12) < 0.1 and r["peak"] == 2500.0
     assert bench.attention_roofline({"attention": 0.38}, 32, 499, "fp8")["peak"] == 5000.0
     assert bench.attention_roofline({}, 32, 499, "bf16") is None
+
+
+def test_exchange_rehearsal_child_failure_is_reported_not_raised():
+    """the one-rank RCCL self-test of `other_configs` runs as a CHILD process so that a communicator that fails or hangs cannot take the
+    headline line with it: without a GPU the child dies at once, and the parent gets an `error` entry (not an exception, not a fake figure)"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: the child would run the real self-test")
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.exchange_rehearsal(timeout_s=300)
+    assert set(r) == {"error"} and "self-test child" in r["error"]

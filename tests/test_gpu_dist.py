@@ -80,6 +80,26 @@ def test_sharded_hip_engine_through_rccl_one_rank(sd):
         S = ShardedSegmenter([HubertEncoderHIP(sd), HubertEncoderHIP(sd)], always_collective=True)
         assert S._coll
         _check_against_segmenter(S, sd)
+        # round 6: run_stream's buffer ring (no allocation in steady state) with reuse_results=True -- the tensors root yields are valid
+        # until 2 x engines - 1 further batches have been yielded, so a consumer that copies each batch out at once sees exactly what the
+        # synchronous step returns, over more batches than the ring has sets, with batch shapes that grow and shrink
+        sets = [LENS, LENS[1:4], LENS[::-1], LENS[:2], LENS, LENS[2:], LENS[::-1], LENS[:3], LENS, LENS[1:]]
+        batches = _batches(sets)
+        sync = [S.step(b, ls) for b, ls in zip(batches, sets)]
+        got = []
+        for out in S.run_stream(batches, sets, max_segments=96, reuse_results=True):
+            got.append(tuple(t.clone() for t in out))
+        torch.cuda.synchronize()
+        assert len(got) == len(sync)
+        for a, b in zip(sync, got):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+            for i, n in enumerate(a[2].tolist()):
+                assert torch.equal(a[1][i, :n], b[1][i, :n]) and torch.equal(a[3][i, :n], b[3][i, :n])
+        m0 = torch.cuda.memory_stats()["num_device_alloc"]
+        for out in S.run_stream(batches, sets, max_segments=96, reuse_results=True):
+            pass
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_stats()["num_device_alloc"] - m0 <= 2, "the stream of batches still allocates device memory in steady state"
     finally:
         dist.destroy_process_group()
 
@@ -177,3 +197,22 @@ def test_pipeline_streams_are_on_different_hardware_queues():
     assert not serialised(st[0], st[1])                      # the two compute streams
     assert sum(serialised(st[i], st[j]) for i in range(4) for j in range(i + 1, 4)) <= 1   # (4 hardware queues by default)
     assert serialised(st[0], st[0])                          # the probe itself: one stream against itself is serial
+
+
+def test_concurrent_streams_are_leased_not_shared():
+    """the probed set of independent streams is shared by the whole process, so two owners used to be handed the SAME streams and
+    serialised against each other.  Streams are leased: a second caller gets streams nobody holds while there are any, a released stream goes
+    out again first, and an index-less 'cuda' device means the current device."""
+    import torch
+    from sylber_amd import streams as S
+    S._LEASES.clear()                                        # (earlier tests of this process hold leases they never return)
+    a = S.concurrent_streams(2, "cuda")
+    b = S.concurrent_streams(2, "cuda:0")
+    ids = lambda st: {int(x.cuda_stream) for x in st}
+    assert len(ids(a)) == 2 and len(ids(b)) == 2
+    assert not (ids(a) & ids(b)), "two owners were handed the same streams while unused independent ones existed"
+    S.release_streams(a)
+    c = S.concurrent_streams(2, "cuda:0")
+    assert ids(c) == ids(a), "released streams go out again before anything is shared"
+    S.release_streams(b)
+    S.release_streams(c)

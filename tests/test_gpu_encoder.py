@@ -138,6 +138,35 @@ def test_residual_prefetch_option_bitwise(sd):
         assert torch.equal(e.forward(x), ref), v
 
 
+def test_tile_selection_options_bitwise(sd):
+    """round 6: which tiles a handle's GEMM launches get depends on whether it owns the chip (SYLBER_OPT_GEMM_MODEL 0, default) or shares it with
+    another in-flight batch (5 = set_batches_in_flight(2)), on the 192-row tiles (SYLBER_OPT_GEMM_H192) and on a forced row split
+    (SYLBER_OPT_GEMM_TAIL) -- and never changes a bit: every output element is one fp32 chain over K in the same order whatever tile computes
+    it.  Batch shapes that leave partial rounds of 256 tiles (where the selections actually differ), fp16 included; and an utterance's hidden
+    states are the same alone and inside such a batch under either selection."""
+    from sylber_amd import HubertEncoderHIP
+    for (b, n, prec) in [(24, 160000, "bf16"), (5, 481000, "bf16"), (12, 240000, "fp16")]:
+        x = noise_batch(b, n, seed=600 + b).cuda()
+        ref = None
+        for opts in ((), ((12, 5),), ((11, -1),), ((8, 4),), ((8, 51),), ((12, 5), (8, 3))):
+            e = HubertEncoderHIP(sd, precision=prec)
+            for k, v in opts:
+                e.set_option(k, v)
+            out = e.forward(x)
+            if ref is None:
+                ref = out
+                one = e.forward(x[1:2].contiguous())
+                assert torch.equal(one[0], ref[1]), (b, n, prec)
+            assert torch.equal(out, ref), (b, n, prec, opts)
+            del e
+    e = HubertEncoderHIP(sd)
+    e.set_batches_in_flight(2)
+    x = noise_batch(24, 160000, seed=624).cuda()
+    a = e.forward(x)
+    e.set_batches_in_flight(1)
+    assert torch.equal(e.forward(x), a)
+
+
 def test_long_form_config(enc, sd):
     """BASELINE configs[3] at its stated batch: 8 x 60 s clips (T = 2999: O(T^2) attention, 192k-step GroupNorm).
     At this size the CPU oracle would take minutes, so the full batch is checked through size-independent properties

@@ -1,0 +1,7 @@
+set -x
+mkdir -p gpurun_out/r06v
+cd $GRAFT_REPO_ROOT
+for rep in 1 2 3; do
+timeout 300 python bench.py --exchange-selftest --no-api --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 2>>gpurun_out/r06v/err.txt | tail -1 > gpurun_out/r06v/A_$rep.json
+done
+timeout 300 python bench.py --exchange-selftest --no-api --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 --exchange-fresh-results --exchange-lookahead 1 2>>gpurun_out/r06v/err.txt | tail -1 > gpurun_out/r06v/B_1.json
