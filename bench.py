@@ -100,6 +100,10 @@ def parse_args():
     ap.add_argument("--exchange-lookahead", type=int, default=0, help="A/B: batches ahead the input exchange is issued (0 = default = engines in flight; 1 = round 5)")
     ap.add_argument("--exchange-ingest-stream", choices=["default", "own", "engine"], default="default",
                     help="A/B: the input exchange under its own stream (default) or under the consuming engine's stream (round 5)")
+    ap.add_argument("--gc-in-timing", action="store_true", help="A/B: leave Python's cyclic garbage collector enabled inside the timed regions")
+    ap.add_argument("--exchange-side-delay", type=int, default=-1, help="A/B: iterations by which run_stream issues a batch's side-stream work late (default 1; 0 = rounds 2-5)")
+    ap.add_argument("--exchange-default-stream", action="store_true",
+                    help="A/B: consume the exchange steps on the process's default stream (rounds 2-5) instead of ShardedSegmenter.consumer_stream()")
     ap.add_argument("--exchange-fresh-results", action="store_true",
                     help="A/B: the gathered tensors of every step freshly allocated (run_stream's default) instead of from its buffer ring "
                          "(reuse_results=True: valid until 2 x engines - 1 further batches have been yielded)")
@@ -500,12 +504,22 @@ def main():
     def timed(run_steps, warmup=None):
         """contract: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize, MAX over ranks.
         run_steps(n) returns one timing-enabled event per step (recorded where the step's last kernel was issued)."""
+        import gc
         run_steps(args.warmup if warmup is None else warmup)
         barrier()
-        t0 = time.perf_counter()
-        evs = run_steps(args.steps)
-        torch.cuda.synchronize(dev)
-        mine = time.perf_counter() - t0                  # this rank's own K steps (before the closing barrier)
+        # no cyclic garbage collection inside the timed region (A/B: --gc-in-timing): the exchange loop creates a few hundred container objects per
+        # step, which triggers a full collection every few steps, and a full collection of this process's heap (torch, numpy, the weights' Python
+        # side) stops the host thread for 40-120 ms -- the GPU drains and idles (profiles/r06_exchange.md: the "erratic" one-rank self-test)
+        if not args.gc_in_timing:
+            gc.collect()
+            gc.disable()
+        try:
+            t0 = time.perf_counter()
+            evs = run_steps(args.steps)
+            torch.cuda.synchronize(dev)
+            mine = time.perf_counter() - t0              # this rank's own K steps (before the closing barrier)
+        finally:
+            gc.enable()
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         per_rank["last"] = [round(1e3 * x / args.steps, 3) for x in all_ranks(mine)]
@@ -584,6 +598,8 @@ def main():
 
     # ---- exchange (N > 1 default): root scatter + gather over RCCL inside every step
     sharded = ShardedSegmenter(encs, always_collective=selftest, streams=pool_st if len(pool_st) >= 2 * len(encs) else None)
+    if args.exchange_side_delay >= 0:
+        sharded.side_delay = args.exchange_side_delay
     if args.exchange_lookahead > 0:
         sharded.lookahead = args.exchange_lookahead
     if args.exchange_ingest_stream != "default":
@@ -608,15 +624,22 @@ def main():
         evs = []
         src = [root_batch] * n if rank == 0 else [None] * n
         t_issue0 = time.perf_counter()
+        # consumed under a stream of its own: the default stream shares a hardware queue with one of the pipeline's streams more often than not, and
+        # every batch handed over puts a wait for its gather into the consumer's stream (ShardedSegmenter.consumer_stream)
+        import contextlib as _cl
+        cons = sharded.consumer_stream() if not args.exchange_default_stream else None
+        with (torch.cuda.stream(cons) if cons is not None else _cl.nullcontext()):
+            _exchange_loop(src, n, evs)
+        host_issue["s"], host_issue["n"] = time.perf_counter() - t_issue0, n
+        return evs
+
+    def _exchange_loop(src, n, evs):
         for _o in sharded.run_stream(src, None, max_segments=min(T_frames, 192), ingest=args.ingest,
                                      host_shards=[host_shard] * n if host_shard is not None else None, gather=gather_mode["m"],
                                      reuse_results=not args.exchange_fresh_results):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream(dev))
             evs.append(ev)
-        # host time to ISSUE the n steps (nothing in the loop waits for the GPU): if this is the step time, the step is host-bound
-        host_issue["s"], host_issue["n"] = time.perf_counter() - t_issue0, n
-        return evs
 
     ex_txt = ("root scatter over RCCL in every step, results left on their ranks (gather=none)" if args.gather == "none" else
               "root scatter + gather over RCCL in every step (run_stream: gather(i) overlapped with compute(i+1))"
@@ -725,7 +748,6 @@ def main():
                       "gather_bytes_per_step_root": st_["gather_bytes"] // max(st_["steps"], 1),
                       "h2d_bytes_per_step_rank0": st_["h2d_bytes"] // max(st_["steps"], 1),
                       "ingest": args.ingest,
-                      "streams_moved_off_the_communicators_queue_rank0": getattr(sharded, "comm_queue_collisions", None),
                       "host_issue_ms_per_step_by_phase_rank0": {k_: round(1e3 * v_ / max(st_["steps"], 1), 3) for k_, v_ in st_["host_s"].items()},
                       # a hipMalloc inside the timed steps synchronises the device (the caching allocator could not reuse a block that another
                       # stream still holds): must be 0 in steady state

@@ -62,17 +62,6 @@ class ShardedSegmenter:
             else:
                 from .streams import concurrent_streams
                 pool = concurrent_streams(2 * len(self.engines), self.device)
-        # ... and none of them may share its hardware queue with the communicator's own stream (streams.serialised_with_communicator: which queue
-        # RCCL's stream lands on changes from one process start to the next).  Collective: every rank constructs its ShardedSegmenter at the same point.
-        self.comm_queue_collisions = 0
-        if self._cuda and self._coll and hasattr(torch.cuda, "_sleep") and not os.environ.get("SYLBER_NO_STREAM_PROBE"):
-            from .streams import concurrent_streams, serialised_with_communicator
-            for j_ in range(2 * len(self.engines)):               # ONE probe per stream: the same number of collectives on every rank
-                if serialised_with_communicator(pool[j_], self.group):
-                    self.comm_queue_collisions += 1
-                    others = [p_ for i_, p_ in enumerate(pool) if i_ != j_]
-                    # a stream independent of the colliding one is off the communicator's queue too (no second probe: no further collective)
-                    pool[j_] = concurrent_streams(1, self.device, avoid=others + [pool[j_]])[0]
         self._streams = pool[:len(self.engines)] if self._cuda else None
         # boundary detection (one workgroup per utterance, ~0.25 ms of latency on 32 CUs) and the gather that follows it run
         # on a second stream per engine: the engine's next forward then does not queue behind them
@@ -88,7 +77,28 @@ class ShardedSegmenter:
         # run; E batches ahead under the engine's own stream had the best mean of the four combinations)
         self.lookahead = len(self.engines)
         self.ingest_stream = False
+        self.side_delay = 0                       # A/B: iterations by which a batch's side-stream work is issued late (run_stream; no measured effect)
+        # run_stream freezes the garbage collector's view of the heap while it runs (gc.freeze): the loop makes a few hundred container objects per
+        # step, which triggers a full collection every few steps, and a full collection of a process that holds torch, numpy and the weights'
+        # Python side stops the host thread for 40-120 ms -- the GPU drains and idles.  THAT was the "5-65 % overhead" of the one-rank self-test
+        # that round 6 chased through allocators, streams and hardware queues (profiles/r06_exchange.md); frozen, a collection only walks what the
+        # loop itself created
+        self.freeze_gc = True
         self.reset_stats()
+
+    def consumer_stream(self):
+        """A stream for the CONSUMER of ``run_stream`` that shares its hardware queue with none of the pipeline's streams.  Every batch handed over
+        makes the consumer's current stream wait for that batch's gather; if that stream sits on the hardware queue of an engine's stream (the
+        process's default stream usually does: streams.py), the wait lands IN FRONT of that engine's next forward and the batches in flight run
+        one after the other -- from one process start to the next the one-rank self-test ran at 5.1 or at 6-9 ms per step for exactly this
+        reason (profiles/r06_exchange.md).  ``with torch.cuda.stream(S.consumer_stream()): for out in S.run_stream(...)``."""
+        if not self._cuda:
+            return None
+        cs = self.__dict__.get("_consumer")
+        if cs is None:
+            from .streams import concurrent_streams
+            cs = self._consumer = concurrent_streams(1, self.device, avoid=list(self._streams) + list(self._sides))[0]
+        return cs
 
     def reset_stats(self) -> None:
         """counters of ``run_stream`` (what the N > 1 bench line reports): host seconds this rank spent blocked in the
@@ -96,7 +106,7 @@ class ShardedSegmenter:
         self.stats = {"steps": 0, "wait_s": 0.0, "scatter_bytes": 0, "gather_bytes": 0, "h2d_bytes": 0,
                       # host seconds run_stream spent ISSUING each phase (nothing in it waits for the GPU: a step whose issue time exceeds its GPU
                       # time is host-bound -- found in round 6: the one-rank self-test was)
-                      "host_s": {"input": 0.0, "forward": 0.0, "segment": 0.0, "gather": 0.0, "collect": 0.0}}
+                      "host_s": {"input": 0.0, "forward": 0.0, "segment": 0.0, "gather": 0.0, "collect": 0.0, "consumer": 0.0, "loop": 0.0}}
         # what this rank was doing last (a watchdog-tripped bench line names it: "which collective hung")
         self.phase = "idle"
 
@@ -433,70 +443,93 @@ class ShardedSegmenter:
             k = max(1, min(int(max_segments), 1 << 30))
             if worst is not None and int(worst) > k:
                 raise RuntimeError("an utterance has %d segments, more than max_segments=%d" % (int(worst), k))
-        try:
-            for i in range(n):
-                k = i % E
-                my_wav, my_lens, btot, arrived = ahead.pop(0)
-                if i + LA < n:
-                    ahead.append(issue_input(i + LA))                         # prefetch: issued before compute(i), i.e. before gather(i)
+        # (A/B switch, no measured effect: the side-stream work of batch i issued DELAY iterations late)
+        DELAY = max(0, int(self.side_delay)) if self._cuda else 0
+        deferred = []
+
+        def issue_side(i, k, hidden, ready, rs, btot):
+            eng = self.engines[k]
+            t_h = _time.perf_counter()
+            with on_side(k):
+                if ready is not None:
+                    self._sides[k].wait_event(ready)
+                    hidden.record_stream(self._sides[k])             # allocated under the engine stream, read here
+                self.phase = "segmentation of batch %d (engine %d, side stream)" % (i, k)
+                if rs is not None:
+                    B_, T_ = hidden.shape[0], hidden.shape[1]
+                    seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold,
+                                                   out=(rbuf(rs, "seg", (B_, T_, 2), torch.int64), rbuf(rs, "nseg", (B_,), torch.int32),
+                                                        rbuf(rs, "feat", (B_, T_, 768), torch.float32)))
+                else:
+                    seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold)
+                self.phase = "issue of the asynchronous gather of batch %d" % i
+                hs["segment"] += _time.perf_counter() - t_h
                 t_h = _time.perf_counter()
-                with on(k):
-                    if arrived is not None:
-                        self._streams[k].wait_event(arrived)
-                        if my_wav.is_cuda:
-                            my_wav.record_stream(self._streams[k])       # allocated under the ingest stream, read here
-                    self.phase = "compute of batch %d (forward, engine %d)" % (i, k)
-                    eng = self.engines[k]
-                    rs = None
-                    if use_ring:
-                        rs = ring_set(i)
-                        if rs["works"] is not None:                      # the gather that last read this set's buffers (RING_DEPTH x E batches ago)
-                            for wk in rs["works"]:
-                                wk.wait()                                # (stream-side wait of the engine's stream; long done in steady state)
-                            rs["works"] = None
-                        T_ = eng.num_frames(my_wav.shape[1])
-                        hidden = eng.forward(my_wav, [int(x) for x in my_lens], out=rbuf(rs, "hid", (my_wav.shape[0], T_, 768), torch.float32))
-                    else:
-                        hidden = eng.forward(my_wav, [int(x) for x in my_lens])
-                    ready = None
-                    if self._cuda:
-                        ready = torch.cuda.Event()
-                        ready.record(self._streams[k])
-                hs["forward"] += _time.perf_counter() - t_h
-                t_h = _time.perf_counter()
-                with on_side(k):
-                    if ready is not None:
-                        self._sides[k].wait_event(ready)
-                        hidden.record_stream(self._sides[k])             # allocated under the engine stream, read here
-                    self.phase = "segmentation of batch %d (engine %d, side stream)" % (i, k)
+                if gather == "none":
+                    bper_ = hidden.shape[0]
+                    wait = self.keep_local(hidden, seg, nseg, feats, max(0, min(bper_, btot - self.rank * bper_)), max_segments)
+                else:
+                    if rs is not None and reuse_results and rs.get("consumed") is not None:
+                        self._sides[k].wait_event(rs["consumed"])   # the caller's queued work on the results this gather overwrites
+                    wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False, ring_set=rs, rbuf=rbuf if rs is not None else None,
+                                             ring_results=reuse_results)
                     if rs is not None:
-                        B_, T_ = hidden.shape[0], hidden.shape[1]
-                        seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold,
-                                                       out=(rbuf(rs, "seg", (B_, T_, 2), torch.int64), rbuf(rs, "nseg", (B_,), torch.int32),
-                                                            rbuf(rs, "feat", (B_, T_, 768), torch.float32)))
-                    else:
-                        seg, nseg, feats = eng.segment(hidden, self.norm_threshold, self.merge_threshold)
-                    self.phase = "issue of the asynchronous gather of batch %d" % i
-                    hs["segment"] += _time.perf_counter() - t_h
+                        rs["works"] = getattr(wait, "works", None)
+                        wait.ring_set = rs
+            hs["gather"] += _time.perf_counter() - t_h
+            return wait
+
+        import gc as _gc
+        frozen = False
+        if self.freeze_gc and _gc.isenabled():
+            _gc.freeze()          # (no collect() first: a full collection of this heap IS the 40-120 ms this avoids); the long-lived heap leaves the collector's sight until the stream ends
+            frozen = True
+        t_loop = _time.perf_counter()
+        try:
+            for step in range(n + DELAY):
+                hs["loop"] = _time.perf_counter() - t_loop               # (host time of the steps issued so far, the consumer's share included)
+                if step < n:
+                    i = step
+                    k = i % E
+                    my_wav, my_lens, btot, arrived = ahead.pop(0)
+                    if i + LA < n:
+                        ahead.append(issue_input(i + LA))                     # prefetch: issued before compute(i), i.e. before gather(i)
                     t_h = _time.perf_counter()
-                    if gather == "none":
-                        bper_ = hidden.shape[0]
-                        wait = self.keep_local(hidden, seg, nseg, feats, max(0, min(bper_, btot - self.rank * bper_)), max_segments)
-                    else:
-                        if rs is not None and reuse_results and rs.get("consumed") is not None:
-                            self._sides[k].wait_event(rs["consumed"])   # the caller's queued work on the results this gather overwrites
-                        wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False, ring_set=rs, rbuf=rbuf if rs is not None else None,
-                                                 ring_results=reuse_results)
-                        if rs is not None:
-                            rs["works"] = getattr(wait, "works", None)
-                            wait.ring_set = rs
-                hs["gather"] += _time.perf_counter() - t_h
+                    with on(k):
+                        if arrived is not None:
+                            self._streams[k].wait_event(arrived)
+                            if my_wav.is_cuda:
+                                my_wav.record_stream(self._streams[k])       # allocated under the ingest stream, read here
+                        self.phase = "compute of batch %d (forward, engine %d)" % (i, k)
+                        eng = self.engines[k]
+                        rs = None
+                        if use_ring:
+                            rs = ring_set(i)
+                            if rs["works"] is not None:                      # the gather that last read this set's buffers (RING_DEPTH x E batches ago)
+                                for wk in rs["works"]:
+                                    wk.wait()                                # (stream-side wait of the engine's stream; long done in steady state)
+                                rs["works"] = None
+                            T_ = eng.num_frames(my_wav.shape[1])
+                            hidden = eng.forward(my_wav, [int(x) for x in my_lens], out=rbuf(rs, "hid", (my_wav.shape[0], T_, 768), torch.float32))
+                        else:
+                            hidden = eng.forward(my_wav, [int(x) for x in my_lens])
+                        ready = None
+                        if self._cuda:
+                            ready = torch.cuda.Event()
+                            ready.record(self._streams[k])
+                    hs["forward"] += _time.perf_counter() - t_h
+                    deferred.append((i, k, hidden, ready, rs, btot))
+                if step < DELAY:
+                    continue
+                wait = issue_side(*deferred.pop(0))
                 if pending is not None:
                     yielded = pending
                     t_h = _time.perf_counter()
                     res_ = collect(pending)
                     hs["collect"] += _time.perf_counter() - t_h
+                    t_h = _time.perf_counter()
                     yield res_
+                    hs["consumer"] += _time.perf_counter() - t_h           # (what the caller did between two batches)
                     # (resumed: whatever the consumer does with that batch is queued on its stream by now)
                     if use_ring and reuse_results and getattr(yielded, "ring_set", None) is not None:
                         ev_c = torch.cuda.Event()
@@ -505,6 +538,9 @@ class ShardedSegmenter:
                 pending = wait
             last = collect(pending)
         except GeneratorExit:
+            if frozen:
+                _gc.unfreeze()
+                frozen = False
             # the consumer stopped early (close(), garbage collection, interpreter shutdown): re-join the engine and side streams to
             # the caller's stream, and check the batches it already holds -- but only WARN: an exception raised from here would
             # replace GeneratorExit on close() and be printed as "Exception ignored" everywhere else.  A truncated
@@ -519,6 +555,8 @@ class ShardedSegmenter:
                 warnings.warn("ShardedSegmenter.run_stream abandoned early: %s (tables yielded so far may be truncated to max_segments rows)" % e,
                               RuntimeWarning, stacklevel=2)
             raise
+        if frozen:
+            _gc.unfreeze()
         if self._cuda:
             for st in self._streams + self._sides + [self._ingest]:
                 torch.cuda.current_stream(self.device).wait_stream(st)

@@ -780,6 +780,13 @@ class Segmenter:
         budget = self.out_pool.max_leased
         self.out_pool.max_leased = budget + NSET
         pending = []
+        # (round 6) the loop makes a few hundred container objects per batch; the full garbage collection they trigger every few batches walks the
+        # whole heap of the process (torch, numpy, ...) and stops this thread for 40-120 ms while the GPU drains.  gc.freeze() takes the long-lived
+        # heap out of the collector's sight for the duration of the stream (profiles/r06_exchange.md)
+        import gc as _gc
+        frozen = bool(self.__dict__.get("_freeze_gc", True)) and _gc.isenabled()
+        if frozen:
+            _gc.freeze()                                                 # (no collect() first: a full collection of this heap is the 40-120 ms this avoids)
         try:
             nxt = issue_input(first)
             i = 0
@@ -803,6 +810,8 @@ class Segmenter:
                 if ev is not None:
                     ev.synchronize()
             pending.clear()
+            if frozen:
+                _gc.unfreeze()
             self.out_pool.max_leased = budget
             self.out_pool.trim()
 

@@ -139,41 +139,3 @@ def concurrent_streams(n: int, device, avoid: Sequence[torch.cuda.Stream] = (), 
             if s not in kept:
                 kept.append(s)
     return lease(kept)
-
-
-def serialised_with_communicator(stream: torch.cuda.Stream, group=None, mbytes: int = 48) -> bool:
-    """True when kernels on ``stream`` run one after the other with the collectives of ``group`` (torch.distributed over RCCL).  c10d issues every
-    collective of a communicator on ONE internal stream of its own, and that stream lands on one of the process's hardware queues like any
-    other; if it is the queue of a compute stream, a gather that waits for batch i's boundary detection sits in FRONT of the next forward
-    queued there and a two-batches-in-flight pipeline runs its batches one after the other (measured on a one-rank communicator: 5.0 ms per step
-    or 6.0-7.2, from one process start to the next: profiles/r06_exchange.md).  Probe: a spin kernel on ``stream`` against a collective issued
-    from another stream at the same moment -- a gather-to-self on a one-rank group, an all-reduce of ``mbytes`` MiB otherwise.  COLLECTIVE: every
-    rank of ``group`` must call it at the same point (ShardedSegmenter's constructor does)."""
-    import torch.distributed as dist
-    dev = stream.device
-    src = torch.zeros(mbytes << 18, dtype=torch.float32, device=dev)          # mbytes MiB
-    dst = torch.empty_like(src)
-    other = torch.cuda.Stream(device=dev)
-    one = dist.get_world_size(group) == 1
-
-    def both(with_spin, with_coll):
-        best = None
-        for _ in range(3):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            if with_spin:
-                with torch.cuda.stream(stream):
-                    torch.cuda._sleep(_PROBE_CYCLES)
-            w = None
-            if with_coll:
-                with torch.cuda.stream(other):
-                    w = (dist.gather(src, [dst], dst=dist.get_rank(), group=group, async_op=True) if one
-                         else dist.all_reduce(dst, group=group, async_op=True))
-            torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t0) * 1e3
-            del w
-            best = dt if best is None else min(best, dt)
-        return best
-    both(True, True)                                          # warm-up (first collective of a communicator, clocks)
-    spin, coll, pair = both(True, False), both(False, True), both(True, True)
-    return pair > max(spin, coll) + 0.6 * min(spin, coll)

@@ -54,4 +54,34 @@ probe("dist.all_reduce 49 MB async_op=True", lambda: dist.all_reduce(dst, async_
 probe("dist.broadcast 128 B", lambda: dist.broadcast(small, src=0))
 if hasattr(dist, "batch_isend_irecv"):
     probe("batch_isend_irecv to self 49 MB", lambda: dist.batch_isend_irecv([dist.P2POp(dist.isend, src, 0), dist.P2POp(dist.irecv, dst, 0)]))
+
+# several collectives back to back behind the same pending work (what one step of run_stream issues: four gathers)
+def burst(name, mk, count=4, reps=4):
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        ts = []
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(cyc)
+            ws = []
+            for j in range(count):
+                t0 = time.perf_counter()
+                ws.append(mk(j))
+                ts.append((time.perf_counter() - t0) * 1e3)
+        torch.cuda.synchronize()
+        print("%-58s host ms per call: %s" % (name, " ".join("%.3f" % t for t in ts)), flush=True)
+
+
+dsts = [torch.empty_like(src) for _ in range(4)]
+burst("4 x dist.gather 49 MB async, same stream", lambda j: dist.gather(src, [dsts[j]], dst=0, async_op=True))
+burst("4 x torch copy_ 49 MB, same stream", lambda j: dsts[j].copy_(src, non_blocking=True))
+side2 = torch.cuda.Stream(device=dev)
+
+
+def alt(j):
+    with torch.cuda.stream(side if j % 2 == 0 else side2):
+        return dist.gather(src, [dsts[j]], dst=0, async_op=True)
+
+
+burst("4 x dist.gather 49 MB async, alternating two streams", alt)
+burst("8 x dist.gather 128 B async, same stream", lambda j: dist.gather(small, [small_dst], dst=0, async_op=True), count=8)
 dist.destroy_process_group()
