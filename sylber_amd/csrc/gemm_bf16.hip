@@ -909,9 +909,9 @@ static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
             }
             return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
-        case 51: case 57: case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 86: case 87: case 88: case 89: case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 98:
+        case 51: case 57: case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 86: case 87: case 88: case 89: case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 47: case 98:
             // hand-scheduled K loop; a forced tile without an instantiation for this epilogue falls back to 128x192 (sylber_hip.h)
-            if (gemm_asm_has_tile(EPI, a, cfg) || (cfg != 51 && cfg != 57 && cfg != 60 && cfg != 80 && cfg != 85 && cfg != 86 && cfg != 90 && cfg != 91 && cfg != 95 && cfg != 96 && cfg != 97 && gemm_asm_applicable(EPI, a))) {
+            if (gemm_asm_has_tile(EPI, a, cfg) || (cfg != 51 && cfg != 57 && cfg != 60 && cfg != 80 && cfg != 85 && cfg != 86 && cfg != 90 && cfg != 91 && cfg != 95 && cfg != 96 && cfg != 97 && cfg != 47 && gemm_asm_applicable(EPI, a))) {
                 GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm(EPI, b, s);
             }
             break;

@@ -68,6 +68,9 @@ int launch_gemm_rowln(const GemmArgs& a, hipStream_t s);
 bool gemm_asm_applicable(int epi, const GemmArgs& a);
 bool gemm_asm_has_tile(int epi, const GemmArgs& a, int tile);
 int launch_gemm_asm(int epi, const GemmArgs& a, hipStream_t s);
+// tile 47 (gemm_asm16.hip): tile 97's geometry on v_mfma_f32_16x16x32; forced only (its own fp32 grouping over K)
+bool gemm_asm16_has_tile(int epi, const GemmArgs& a);
+int launch_gemm_asm16(int epi, const GemmArgs& a, hipStream_t s);
 
 // MXFP8 GEMM (gemm_mxfp8.hip): e4m3 operands [rows][K] with one E8M0 scale per 32 elements along K stored
 // K-pair-major [K/64][rows_pitch][2] (common.h mx_scale_index; pitches are multiples of 8, and the scale arrays of

@@ -230,6 +230,54 @@ def test_conv3_layer_every_tile(lib):
         assert (got - ref).abs().max().item() < 2e-2 and (got - ref).pow(2).mean().sqrt().item() < 3e-3, M
 
 
+def test_tile47_mfma16(lib):
+    """tile 47 = tile 97's geometry with the K loop on v_mfma_f32_16x16x32 (csrc/gemm_asm16.hip; forced only): an output element's fp32 chain adds
+    32-k blocks where every other tile adds 16-k blocks, so it is held to the torch reference at the tolerance of the other tiles and to tile 97
+    within fp32 rounding of the accumulator (NOT bit for bit), run-to-run reproducible, on whole and ragged tiles, several rounds of the
+    persistent walk, with and without GELU, and on the 3-tap conv K order"""
+    from sylber_amd import _lib
+    g = torch.Generator().manual_seed(47)
+    for (M, N, K, act) in [(700, 768, 768, 1), (1000, 512, 1536, 1), (333, 3072, 768, 0), (257, 768, 3072, 1), (16384, 3072, 768, 1), (4096, 4096, 4096, 0)]:
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+        outs = {}
+        for cfg in (47, 97, 47):
+            c = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(lib.sylber_op_linear(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, act, 0, cfg, None), "op_linear")
+            if cfg in outs:
+                assert torch.equal(c, outs[cfg]), ("run to run", M, N, K)
+            outs[cfg] = c
+        rows = torch.randint(0, M, (min(M, 512),))
+        ref = _bf(a[rows]) @ _bf(w).T + b
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        got = outs[47][rows.cuda()].cpu()
+        assert (got - ref).abs().max().item() < (2e-3 if K < 4096 else 2e-2), (M, N, K)
+        # against tile 97 (fp32 rows): fp32 accumulation noise only, three orders below the bf16 operand rounding
+        d = (outs[47] - outs[97]).abs().max().item()
+        assert d <= 2e-5 * outs[97].abs().max().item() + 1e-6, (M, N, K, d)
+    # the 3-tap stride-2 conv layers' chunk-major K order (TP:160-175), against torch's conv and against tile 97
+    for M in (70000, 257):
+        R = 2 * M + 1
+        x = torch.randn(R, 512, generator=g)
+        w = torch.randn(512, 512, 3, generator=g) / (3 * 512) ** 0.5
+        xd = x.cuda()
+        wc = w.contiguous()
+        ys = {}
+        for tile in (47, 97):
+            y = torch.full((M, 512), -1, dtype=torch.int16, device="cuda")
+            _lib.check(lib.sylber_op_conv3(_p(xd), ctypes.c_void_p(wc.data_ptr()), _p(y), R, M, tile, None), "op_conv3")
+            ys[tile] = y.view(torch.bfloat16).float()
+        rows = torch.randint(0, M, (256,))
+        got = ys[47][rows.cuda()].cpu()
+        xr = torch.stack([_bf(x[2 * rows + t]) for t in range(3)], -1)
+        ref = torch.nn.functional.gelu(torch.einsum("rct,oct->ro", xr, _bf(w)))
+        assert (got - ref).abs().max().item() < 2e-2 and (got - ref).pow(2).mean().sqrt().item() < 3e-3, M
+        assert ((ys[47] - ys[97]).abs() > 0).float().mean().item() < 0.02, M
+
+
 @pytest.mark.parametrize("tile", [4, 51, 90, 91, 96])
 def test_residual_gemm_tiles(lib, tile):
     """the residual GEMM of an encoder block (out-projection K = 768, FFN2 K = 3072: EPI_F32_RESLN, in place) against torch, and

@@ -539,6 +539,207 @@ def emit_x3(fn=4, nw=4, pre_e=0, pre_cols=0, tap=False, fm=4):
 
 
 # ======================================================================================================================
+# Y3 (round 6, tile id 47): the X3 ring loop of tile 97 on v_mfma_f32_16x16x32_bf16 -- the instruction shape the vendor library issues on this
+# part.  profiles/r06_mfma_shape.md: under the package power cap a register-only stream of 16x16x32 sustains 8.5 % more FLOP/s than 32x32x16 (a
+# quarter of the accumulator traffic per instruction, half per FLOP).  Same LDS image, same LDS-DMA pieces, same ring, same barrier count as X3; what
+# changes is how a wave cuts its 128 x (32 FN) tile into instructions and therefore which bytes a fragment register holds:
+#   * a fragment = 16 rows x 32 k: lane l reads row l % 16, 16-byte chunk (4 h + l / 16) ^ swizzle(row) of K-step slice h (two slices of 32 k per
+#     step where X3 has four of 16 k); the wave holds GX = 2 FM X fragments (its tokens) and GW = 2 FN W fragments per slice
+#   * a slice = GX x GW MFMAs of 16 cycles, X-fragment-major: X fragment i is dead behind its GW MFMAs and is REFILLED IN PLACE with fragment i of the
+#     next slice (one ds_read_b128 per GW MFMAs, a register ring instead of X3's two fragment sets); W fragments are double-buffered by slice parity
+#   * in-order LDS returns make every wait a count: the generator keeps the queue of outstanding reads and emits lgkmcnt(#younger) before the
+#     first MFMA that needs a fragment (asserted identical at the loop's back edge)
+#   * slice 1 of step j: behind X fragment GB's MFMAs -- every read of step j has been issued in slice 0 -- vmcnt + lgkmcnt(0) + s_barrier, then
+#     the burst of step j+1's first fragments (X 0..GB, all W) and the first pieces of W(j+2), as in X3
+# The fp32 chain of an output element adds 32-k blocks where the 32x32x16 loops add 16-k blocks: results are NOT bit-identical to the other
+# tiles, so this tile is never picked by the cost model -- it is the measured answer to "what does the instruction shape buy in the real loop".
+Y3 = {}
+
+
+class ReadQueue:
+    """outstanding ds_reads in issue order; LDS operations of a wave return in order"""
+    def __init__(self):
+        self.q = []
+
+    def issue(self, tag):
+        assert tag not in self.q, tag
+        self.q.append(tag)
+        assert len(self.q) <= 15, "lgkmcnt is a 4-bit counter"
+
+    def need(self, *tags):
+        """asm lines that make every one of `tags` available (nothing when earlier waits already covered them)"""
+        idx = [self.q.index(t) for t in tags if t in self.q]
+        if not idx:
+            return []
+        i = max(idx)
+        n = len(self.q) - i - 1
+        self.q = self.q[i + 1:]
+        return [q(f"s_waitcnt lgkmcnt({n})")]
+
+    def drain(self):
+        self.q = []
+
+
+def y3_read_x(rq, i, h):
+    rq.issue(("x", i))
+    return q(f"ds_read_b128 %[x{i}], %[ax{h}] offset:{i * 2048}")
+
+
+def y3_read_w(rq, P, j, wslot):
+    rq.issue(("w", P, j))
+    return q(f"ds_read_b128 %[w{P}{j}], %[aw{P}{'h' if wslot else ''}] offset:{j * 2048}")
+
+
+def y3_dma_w(i, wslot):
+    nw, nxp = Y3["nw"], 8 * Y3["fm"] // Y3["nw"]
+    return (q(f"s_add_u32 m0, %[lbase], {3 * Y3['xt'] + wslot * Y3['bn'] * 128 + (i - nxp) * nw * 1024}"),
+            q(f"buffer_load_dwordx4 %[vo{i}], %[rw], %[koff] offen lds"))
+
+
+def y3_dma_x(i):
+    return (q(f"s_add_u32 m0, %[xwl], {i * Y3['nw'] * 1024}"),
+            q(f"buffer_load_dwordx4 %[vo{i}], %[rx], %[kofx] offen lds"))
+
+
+def y3_step(rq, par, tail_w, x_next, head, vm, nxt=True, first=False):
+    """one K step (64 k) of parity par (= its W slot): slice 0 carries the rest of W(j+1) and X(j+2), slice 1 the barrier, the first
+    fragments of step j+1 and the first pieces of W(j+2)"""
+    GX, GW, nw, GB = 2 * Y3["fm"], 2 * Y3["fn"], Y3["nw"], Y3["gb"]
+    nxp, nwp = 8 * Y3["fm"] // nw, Y3["bn"] // 8 // nw
+    n_mf = GX * GW
+    XT = Y3["xt"]
+    L = [q(f"; ---- Y3 step parity {par}: tail_w {int(tail_w)} x_next {int(x_next)} head {int(head)} vmcnt {vm}")]
+    nh = min(nwp - 1, (n_mf - (GB + 1) * GW) // 4)           # W pieces issued behind the barrier (one per four MFMAs)
+    queue = []
+    if tail_w:
+        queue += [y3_dma_w(i, par ^ 1) for i in range(nxp + nh, nxp + nwp)]
+    if x_next:
+        xq = [y3_dma_x(i) for i in range(nxp)]
+        if not Y3.get("tap"):
+            xq[0] = (q("s_add_u32 %[kofx], %[koff], 128") + "\n    " + xq[0][0], xq[0][1])
+        queue += xq
+    bump = tail_w or x_next
+    for h in range(2):
+        P = h
+        pre = [[] for _ in range(n_mf)]
+        after = [[] for _ in range(n_mf)]
+        if h == 0:
+            # W fragments of slice 1 (set 1; this step's W slot): one per MFMA from MFMA 1 on; X fragment i of slice 1 behind group i
+            for j in range(GW):
+                after[1 + j].append(("rw", 1, j, par))
+            for i in range(GX):
+                after[i * GW + GW - 1].append(("rx", i, 1))
+            pos = 2
+            stride = 4 if 2 + 4 * (len(queue) - 1) < n_mf else 2
+            while queue:
+                assert pos < n_mf
+                a, b = queue.pop(0)
+                pre[pos].append(a)
+                after[pos].append(b)
+                if not queue and bump:
+                    after[pos].append(q("s_add_u32 %[koff], %[koff], 128"))
+                    if x_next and Y3.get("tap"):
+                        after[pos] += x3_tap_update()
+                pos += stride
+        else:
+            bpos = (GB + 1) * GW - 1                          # behind X fragment GB's last MFMA
+            after[bpos].append(("barrier",))
+            if nxt:
+                after[bpos] += [q("s_add_u32 %[xwl], %[lbase], %[xr]"),
+                                q(f"s_add_u32 %[xr], %[xr], 0x{XT:x}"),
+                                q(f"s_cmp_eq_u32 %[xr], 0x{3 * XT:x}"),
+                                q(f"s_cselect_b32 %[dlt], %[cneg], 0x{XT:x}"),
+                                q("s_cselect_b32 %[xr], 0, %[xr]")]
+                after[bpos] += [q(f"v_add_u32_e32 %[ax{k}], %[dlt], %[ax{k}]") for k in range(2)]
+                burst = [("rx", 0, 0)] + [("rw", 0, j, par ^ 1) for j in range(GW)] + [("rx", i, 0) for i in range(1, GB + 1)]
+                for n, r in enumerate(burst):
+                    after[min(bpos + n, n_mf - 1)].append(r)
+                for i in range(GB + 1, GX):
+                    after[i * GW + GW - 1].append(("rx", i, 0))
+            if head:
+                pos = bpos + 2
+                for p_ in range(nh):
+                    assert pos < n_mf
+                    a, b = y3_dma_w(nxp + p_, par)
+                    pre[pos].append(a)
+                    after[pos].append(b)
+                    pos += 4
+        n = 0
+        for i in range(GX):
+            L += rq.need(("x", i), *([("w", P, j) for j in range(GW)] if i == 0 else []))
+            for j in range(GW):
+                L += pre[n]
+                srcc = "0" if (first and h == 0) else f"%[c{i}{j}]"
+                L.append(f'MF " %[c{i}{j}], %[w{P}{j}], %[x{i}], {srcc}\\n"')
+                for item in after[n]:
+                    if isinstance(item, tuple):
+                        if item[0] == "barrier":
+                            L.append(q(f"s_waitcnt vmcnt({vm}) lgkmcnt(0)"))
+                            L.append(q("s_barrier"))
+                            rq.drain()
+                        elif item[0] == "rx":
+                            L.append(y3_read_x(rq, item[1], item[2]))
+                        else:
+                            L.append(y3_read_w(rq, item[1], item[2], item[3]))
+                    else:
+                        L.append(item)
+                n += 1
+    assert not queue
+    return L
+
+
+def emit_y3(fn=2, nw=8, tap=False, fm=4, gb=3):
+    bn = 64 * fn if nw == 4 else 128 * fn
+    Y3.update({"fn": fn, "nw": nw, "bn": bn, "tap": tap, "fm": fm, "xt": 64 * fm * 128, "gb": gb})
+    GX, GW = 2 * fm, 2 * fn
+    nxp = 8 * fm // nw
+    rq = ReadQueue()
+    L = [q("; ---- fragments of (step 0, slice 0)")]
+    L.append(y3_read_x(rq, 0, 0))
+    for j in range(GW):
+        L.append(y3_read_w(rq, 0, j, 0))
+    for i in range(1, GX):
+        L.append(y3_read_x(rq, i, 0))
+    L += y3_step(rq, 0, False, False, True, nxp, first=True)     # j = 0: W(1), X(1), X(2) came with the prologue
+    entry = list(rq.q)
+    L.append(q("s_cmp_eq_u32 %[nloop], 0"))
+    L.append(q("s_cbranch_scc1 L_gemmy_tail_%="))
+    L.append(q("L_gemmy_loop_%=:"))
+    L += y3_step(rq, 1, True, True, True, nxp)
+    L += y3_step(rq, 0, True, True, True, nxp)
+    assert rq.q == entry, "the read queue must be the same at the loop's back edge"
+    L.append(q("s_sub_u32 %[nloop], %[nloop], 1"))
+    L.append(q("s_cmp_lg_u32 %[nloop], 0"))
+    L.append(q("s_cbranch_scc1 L_gemmy_loop_%="))
+    L.append(q("L_gemmy_tail_%=:"))
+    L += y3_step(rq, 1, True, True, True, nxp)                   # j = nj - 3
+    L += y3_step(rq, 0, True, False, False, 0)                   # j = nj - 2
+    L += y3_step(rq, 1, False, False, False, 0, nxt=False)       # j = nj - 1
+    assert not rq.q
+    L.append(q("s_barrier"))
+    L.append(q("s_nop 15"))
+    outs = [f'[c{i}{j}] "=a"(acc[{i}][{j}])' for i in range(GX) for j in range(GW)]
+    outs += [f'[x{i}] "=&v"(fx[{i}])' for i in range(GX)]
+    outs += [f'[w{P}{j}] "=&v"(fw[{P}][{j}])' for P in range(2) for j in range(GW)]
+    outs += [f'[ax{k}] "+&v"(axc[{k}])' for k in range(2)]
+    outs += ['[koff] "+&s"(koff)', '[nloop] "+&s"(nloop)', '[xr] "+&s"(xr)', '[xwl] "=&s"(xwl)', '[dlt] "=&s"(dlt)']
+    outs += ['[kofx] "+&s"(kofx)', '[ph] "+&s"(ph)', '[dk] "=&s"(dk)'] if tap else ['[kofx] "=&s"(kofx)']
+    ins = []
+    for P in range(2):
+        ins += [f'[aw{P}] "v"(aw[{P}])', f'[aw{P}h] "v"(awh[{P}])']
+    ins += [f'[vo{i}] "v"(voff[{i}])' for i in range((64 * fm + bn) // 8 // nw)]
+    ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)', '[cneg] "s"(cneg)']
+    if tap:
+        ins += ['[c2048] "s"(c2048)', '[cm1024] "s"(cm1024)', '[cm896] "s"(cm896)']
+    name = "gemm_asm_y3" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + ("_t" if tap else "") + ".inc"
+    dst = os.path.join(OUTDIR, name)
+    with open(dst, "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_asm.py (Y3: the X3 ring on 16x16x32 MFMAs) -- do not edit; the schedule is documented there.\n")
+        write_asm(f, L, outs, ins)
+    print("wrote", os.path.normpath(dst), len(L), "lines")
+
+
+# ======================================================================================================================
 # MXFP8 form of the X3 loop (BASELINE configs[4], gemm_asm_f8.hip): the SAME byte geometry -- 256 rows x 128-byte LDS rows per
 # operand and K step, three X slots, two W slots, one barrier per step, the same LDS-DMA pieces and the same fragment addresses
 # (chunk (2 kk + h) ^ swizzle of a row) -- but a row is 128 e4m3 values, contracted by v_mfma_scale_f32_32x32x64_f8f6f4: a K step is
@@ -774,6 +975,8 @@ def emit_product():
     for cols in (1, 2, 3):
         emit_x3(3, 4, pre_e=4, pre_cols=cols)          # K = 768 (12 steps): nothing left in the loop
         emit_x3(3, 4, pre_e=7, pre_cols=cols)          # K >= 1152 (FFN2, K = 3072: 48 steps, the last 17 unrolled)
+    emit_y3(2, 8)                    # tile 47: tile 97's geometry on 16x16x32 MFMAs (forced only: its own fp32 grouping)
+    emit_y3(2, 8, tap=True)
     emit_f8(4)
     emit_f8(3)
     emit_f8(3, lds_scales=True)     # scales through LDS (one DMA piece per wave and step): the long-K launches
