@@ -869,9 +869,10 @@ def main():
             enc_peak = MFMA_FP8_PEAK_TFLOPS if args.precision == "fp8" else MFMA_BF16_PEAK_TFLOPS
             roofline["encoder_gemms"] = {"achieved": round(enc_tf, 1), "peak": enc_peak, "frac": round(enc_tf / enc_peak, 4),
                                          "ms_per_forward": round(enc_ms, 4)}
-        # the single dominant instantiation, exactly the row rocprofv3 prints as gemmb_bf16_kernel<0, 1, 0, 0, 2, 8, true, 0, 3>: the
-        # hand-scheduled 256x256 kernel on eight waves with the GELU epilogue (csrc/gemm_asm.hip, tile 95) = conv1..conv5 +
-        # 9 x FFN1, persistent with the next tile's first K step requested before the epilogue
+        # the single dominant instantiation, the rows rocprofv3 prints as gemmc_bf16_kernel<0, 1, 0, *, 4> (csrc/gemm_asm16.hip, tile 47): the
+        # hand-scheduled 256x256 kernel on eight waves with the GELU epilogue, K loop on v_mfma_f32_16x16x32 = conv1..conv5 + 9 x FFN1,
+        # persistent with the next tile's first K step requested before the epilogue (rounds 3-6a: gemmb_bf16_kernel<0, 1, 0, 0, 2, 8, true, 0, 3>,
+        # the same tile on v_mfma_f32_32x32x16: --opt 13=-1)
         if clip_samples == CLIP_SAMPLES and B == BATCH_PER_GPU and args.precision == "bf16" and args.gemm_tile < 0 and not args.opt:
             big = ["gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_ffn1"]
             n_big = 5 + 9
@@ -879,8 +880,8 @@ def main():
             fl_big = sum(fl[k] for k in big)
             if ms_big > 0:
                 roofline["dominant_instantiation"] = {
-                    "kernel": "gemmb_bf16_kernel<0, 1, 0, 0, 2, 8, true, 0, 3> (256x256 tile, 8 waves x 128x64, inline-asm K loop over 128-byte LDS rows, "
-                              "GELU + bf16 epilogue, persistent)", "launches_per_forward": n_big,
+                    "kernel": "gemmc_bf16_kernel<0, 1, 0, *, 4> (tile 47: 256x256, 8 waves x 128x64, generated K loop on v_mfma_f32_16x16x32 over 128-byte LDS rows, "
+                              "GELU + bf16 epilogue, persistent; conv1-4 in the 3-tap K order)", "launches_per_forward": n_big,
                     "avg_launch_ms": round(ms_big / n_big, 4), "achieved": round(fl_big / (ms_big * 1e-3) / 1e12, 1),
                     "frac": round(fl_big / (ms_big * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
         # the HBM-bound end of the path (north_star: "achieved HBM GB/s on the conv frontend"): conv0 + GroupNorm + GELU

@@ -196,6 +196,12 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      rounds are handled by the 192-row tiles below; this stays as a test vehicle
  *   SYLBER_OPT_GEMM_H192               0 (default): the cost model may pick the 192-row siblings of the hand-scheduled tiles (ids 51 = 192x192, 57 = 192x256:
  *                                      a second tile HEIGHT, for launches whose 256-row tile count leaves a partial last round); -1: 256-row tiles only (A/B)
+ *   SYLBER_OPT_GEMM_MFMA16             0 (default): the GEMMs with 16-bit outputs (conv1-5, FFN1: csrc/gemm_bf16.hip EPI_BF16) run on the v_mfma_f32_16x16x32 family of
+ *                                      kernels (csrc/gemm_asm16.hip, tile ids 13 / 14 / 46 / 47: the instruction shape that is cheapest per FLOP under the package power
+ *                                      cap, profiles/r06_mfma16_loop.md); a forced SYLBER_OPT_GEMM_TILE id is mapped to the member of the same shape class on these
+ *                                      launches.  -1: those launches on the 32x32x16 kernels of the earlier rounds (A/B switch).  The two families group an output
+ *                                      element's fp32 sum over K differently (32-k against 16-k blocks): results agree to fp32 rounding of the accumulator, not bit
+ *                                      for bit -- WITHIN either setting results do not depend on the batch shape or the tile.
  *   SYLBER_OPT_GEMM_MODEL              which tiles the GEMM launches of this handle get (csrc/gemm_bf16.hip launch_f).  0 (default): the handle OWNS the chip -- one batch in
  *                                      flight, as in a synchronous Segmenter.__call__: a launch is charged its partial last round (measured per kernel
  *                                      family) and may use the 192-row tiles; 5: the handle SHARES the chip with another in-flight batch (bench.py's
@@ -210,7 +216,7 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      format's saturation value (+-65504: the fp16 modes clamp on conversion, they never produce infinities) and the
  *                                      largest magnitude seen; read with sylber_get_fp16_audit.  0 (default): off, nothing is launched. */
 enum { SYLBER_OPT_GEMM_TILE = 1, SYLBER_OPT_ATTN_QUERIES_PER_WAVE = 2, SYLBER_OPT_GEMM_PERSISTENT = 3, SYLBER_OPT_FUSE_OUTPROJ_LN = 4,
-       SYLBER_OPT_CONV0_VALU = 5, SYLBER_OPT_RESLN_PREFETCH = 6, SYLBER_OPT_FP8_ATTENTION = 7, SYLBER_OPT_GEMM_TAIL = 8, SYLBER_OPT_SEGMENT = 9, SYLBER_OPT_FP16_AUDIT = 10, SYLBER_OPT_GEMM_H192 = 11, SYLBER_OPT_GEMM_MODEL = 12 };
+       SYLBER_OPT_CONV0_VALU = 5, SYLBER_OPT_RESLN_PREFETCH = 6, SYLBER_OPT_FP8_ATTENTION = 7, SYLBER_OPT_GEMM_TAIL = 8, SYLBER_OPT_SEGMENT = 9, SYLBER_OPT_FP16_AUDIT = 10, SYLBER_OPT_GEMM_H192 = 11, SYLBER_OPT_GEMM_MODEL = 12, SYLBER_OPT_GEMM_MFMA16 = 13 };
 int sylber_set_option(sylber_t h, int32_t key, int32_t value);
 /* the audit's counters since SYLBER_OPT_FP16_AUDIT was last set (synchronises the device): names[i] (static strings: conv0 .. conv6, ln512,
  * proj_xpad, layernorm, q, k, v, context, ffn1), saturated[i] values clamped at +-65504, max_abs[i] largest magnitude; returns the number of

@@ -92,6 +92,7 @@ struct sylber_ctx {
     unsigned* audit_dev = nullptr;                                 // [AUDIT_STAGES][2]: saturated count, max |x| as half bits
     int opt_segment = 0;                                           // boundary detection: 0 wide (all CUs), -1 one workgroup per utterance
     int opt_gemm_model = 0;                                        // 5: round-5 tile cost model (A/B switch)
+    int opt_gemm_mfma16 = 0;                                       // -1: the 16-bit-output GEMMs on the 32x32x16 kernels (A/B switch; GemmArgs::tune_mfma16)
     int opt_gemm_h192 = 0;                                         // -1: no 192-row tiles in the cost model (A/B switch)
     int opt_gemm_tail = 0;                                         // row split of multi-round GEMM launches: 0 auto, -1 never, k + 1 = tail tile id k
     int opt_attn8 = 0;                                             // SYLBER_FP8: attention core on MXFP8 operands (0 / 1 on, -1 off)
@@ -310,6 +311,7 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
         case SYLBER_OPT_SEGMENT: c->opt_segment = value < 0 ? -1 : 0; break;
         case SYLBER_OPT_GEMM_MODEL: c->opt_gemm_model = value == 5 ? 5 : (value == 2 ? 2 : 0); break;
         case SYLBER_OPT_GEMM_H192: c->opt_gemm_h192 = value < 0 ? -1 : 0; break;
+        case SYLBER_OPT_GEMM_MFMA16: c->opt_gemm_mfma16 = value < 0 ? -1 : 0; break;
         case SYLBER_OPT_GEMM_TAIL: c->opt_gemm_tail = value < 0 ? -1 : (value > 0 ? value + 1 : 0); break;   // k > 0: tail tile id k (stored id + 1)
         default: syl_set_error("sylber_set_option", "unknown option key"); return 1;
     }
@@ -549,7 +551,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         GemmArgs a = {};
         a.X = src; a.ldx = (long)CS[i] * 512; a.W = c->conv_w[i];
         a.M = B * p.R[i]; a.N = 512; a.K = CK[i] * 512; a.bias = nullptr; a.act = split ? ACT_GELU_ERF7 : ACT_GELU_FAST;
-        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.tune_tail = c->opt_gemm_tail; a.tune_h192 = c->opt_gemm_h192; a.tune_model = c->opt_gemm_model;  a.fmt = c->fmt_conv;
+        a.out0 = dst; a.ld0 = 512; a.tune_cfg = c->opt_gemm_cfg; a.tune_persist = c->opt_gemm_persist; a.tune_tail = c->opt_gemm_tail; a.tune_h192 = c->opt_gemm_h192; a.tune_mfma16 = c->opt_gemm_mfma16; a.tune_model = c->opt_gemm_model;  a.fmt = c->fmt_conv;
         a.x_lo = src_lo; a.w_lo = (long)512 * CK[i] * 512; a.out_lo = dst_lo;
         a.kpat = (CK[i] == 3 && c->fmt_conv != FMT_SPLIT) ? 1 : 0;      // chunk-major K order (weights packed to match at create)
         static const char* nm[7] = {"", "gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4", "gemm_conv5", "gemm_conv6"};
@@ -676,7 +678,7 @@ static int forward_launch(sylber_ctx* c, const Plan& p, const float* wav_dev, fl
         } else {
         GemmArgs f1 = {};
         f1.X = hbf; f1.ldx = 768; f1.W = d.w1; f1.M = M; f1.N = 3072; f1.K = 768; f1.bias = d.b1; f1.act = split ? ACT_GELU_ERF7 : ACT_GELU_FAST;
-        f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist; f1.tune_tail = c->opt_gemm_tail; f1.tune_h192 = c->opt_gemm_h192; f1.tune_model = c->opt_gemm_model;  f1.fmt = c->fmt;
+        f1.out0 = ffn; f1.ld0 = 3072; f1.tune_cfg = c->opt_gemm_cfg; f1.tune_persist = c->opt_gemm_persist; f1.tune_tail = c->opt_gemm_tail; f1.tune_h192 = c->opt_gemm_h192; f1.tune_mfma16 = c->opt_gemm_mfma16; f1.tune_model = c->opt_gemm_model;  f1.fmt = c->fmt;
         f1.x_lo = p.lo_hbf; f1.w_lo = (long)3072 * 768; f1.out_lo = p.lo_ffn;
         RUN("gemm_ffn1", launch_gemm_bf16(EPI_BF16, f1, s));
         if (aud_e && audit16(c, AUD_FFN1, ffn, M, 3072, 3072, s)) return 1;
@@ -874,6 +876,7 @@ struct TmpBuf {
 // `tile` argument of the op-level entry points: -1 = automatic, else tile id + 1000 x (workgroups per CU; 9 = one workgroup per tile)
 // + 100000 x t (tail policy of the launch, GemmArgs::tune_tail: t = 1 never split by rows, t >= 2 force a split with tail tile id t - 2)
 static void decode_tile(int tile, GemmArgs& g) {
+    if (tile >= 1000000) { g.tune_mfma16 = -1; tile -= 1000000; if (tile == 999) tile = -1; }   // tile + 1000000: the 16-bit-output role on the 32x32x16 kernels (GemmArgs::tune_mfma16); 1000999 = that with the automatic tile
     const int t = tile >= 100000 ? tile / 100000 : 0;
     if (tile >= 100000) tile %= 100000;
     g.tune_tail = t == 0 ? 0 : (t == 1 ? -1 : t - 1);
@@ -1250,6 +1253,8 @@ static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t
     act %= 10000;
     const int tail_code = act / 100;                      // act + 100 t: tail policy of the launch (GemmArgs::tune_tail)
     act %= 100;
+    const bool legacy16 = cfg >= 1000000;                 // cfg + 1000000: the 16-bit-output role on the 32x32x16 kernels (GemmArgs::tune_mfma16 = -1)
+    if (legacy16) cfg -= 1000000;
     const bool kpat = cfg >= 350000;                      // cfg + 400000: the 3-tap conv layers' chunk-major K order (K = 1536, ldx = 1024)
     if (kpat) cfg -= 400000;
     const bool cold = cfg >= 150000;                      // cfg + 200000: operands flushed out of the caches before every launch
@@ -1280,6 +1285,7 @@ static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t
     g.tune_cfg = cfg < 0 ? 0 : (cfg % 1000) + 1;
     g.tune_persist = cfg >= 9000 ? -1 : (cfg >= 1000 ? cfg / 1000 : 0);    // cfg = persist * 1000 + tile (9000 + tile: persist = -1)
     g.tune_h192 = no_h192 ? -1 : 0; g.tune_model = no_h192 ? 5 : 0;
+    g.tune_mfma16 = legacy16 ? -1 : 0;
     g.tune_tail = tail_code == 0 ? 0 : (tail_code == 1 ? -1 : tail_code - 1);   // act + 100 t: t = 1 never split, t >= 2 force tail tile id t - 2
     TmpBuf trb;
     if (g_gemm_trace_out) {
@@ -1330,7 +1336,8 @@ static int gemm_bench_impl(int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t
 // model = SYLBER_OPT_GEMM_MODEL (0: the handle owns the chip, 5: shares it), kpat = 1 for the 3-tap conv K order
 extern "C" int sylber_debug_gemm_pick(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t act, int32_t fmt, int32_t model, int32_t kpat) {
     GemmArgs g = {};
-    g.M = M; g.N = N; g.K = K; g.act = act; g.fmt = fmt; g.tune_model = model; g.kpat = kpat;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.fmt = fmt; g.tune_model = model % 100; g.kpat = kpat;
+    g.tune_mfma16 = model >= 100 ? -1 : 0;               // model + 100: the 16-bit-output role on the 32x32x16 kernels
     return gemm_pick_tile(epi, g);
 }
 

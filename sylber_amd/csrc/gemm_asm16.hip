@@ -74,10 +74,13 @@ __device__ __forceinline__ void epilogue_rows32_m16_f32(const GemmArgs& a, const
         }
 }
 
-template <int EPI, int ACT, int FMT, bool TAP>
+// FMV = 32-row blocks per wave: 4 = tile 47 (256x256), 3 = tile 46 (192x256: the sibling tile 57 is to tile 97, for launches whose 256-row tile
+// count leaves a partial last round; gemm_asm.hip)
+template <int EPI, int ACT, int FMT, bool TAP, int FMV = 4>
 __global__ __launch_bounds__(512, 2) void gemmc_bf16_kernel(const GemmArgs a) {
-    static_assert(EPI == EPI_BF16 || EPI == EPI_F32, "tile 47: 16-bit rows (staged) or fp32 rows (direct)");
-    constexpr int FM = 4, FN = 2, NW = 8, WN = 4, BM = 256, BN = 256, RB = 128;
+    static_assert(EPI == EPI_BF16 || EPI == EPI_F32, "tiles 46 / 47: 16-bit rows (staged) or fp32 rows (direct)");
+    static_assert(FMV == 4 || (FMV == 3 && !TAP), "192-row tile: linear K order only");
+    constexpr int FM = FMV, FN = 2, NW = 8, WN = 4, BM = 64 * FM, BN = 256, RB = 128;
     constexpr int GX = 2 * FM, GW = 2 * FN;                  // 16-row X fragments / 16-column W fragments per wave
     constexpr int XT = BM * RB, WS = BN * RB;
     constexpr int XRING = 3 * XT;
@@ -163,7 +166,9 @@ __global__ __launch_bounds__(512, 2) void gemmc_bf16_kernel(const GemmArgs a) {
             if constexpr (TAP) kofx = tap3_offset(3 * 128);
             if constexpr (FMT == FMT_F16) {
 #define MF "v_mfma_f32_16x16x32_f16"
-                if constexpr (TAP) {
+                if constexpr (FMV == 3) {
+#include "gemm_asm_y3_m3_w8.inc"
+                } else if constexpr (TAP) {
 #include "gemm_asm_y3_w8_t.inc"
                 } else {
 #include "gemm_asm_y3_w8.inc"
@@ -171,7 +176,9 @@ __global__ __launch_bounds__(512, 2) void gemmc_bf16_kernel(const GemmArgs a) {
 #undef MF
             } else {
 #define MF "v_mfma_f32_16x16x32_bf16"
-                if constexpr (TAP) {
+                if constexpr (FMV == 3) {
+#include "gemm_asm_y3_m3_w8.inc"
+                } else if constexpr (TAP) {
 #include "gemm_asm_y3_w8_t.inc"
                 } else {
 #include "gemm_asm_y3_w8.inc"
@@ -225,12 +232,13 @@ __global__ __launch_bounds__(512, 2) void gemmc_bf16_kernel(const GemmArgs a) {
     }
 }
 
-template <int EPI, int ACT, int FMT, bool TAP>
+template <int EPI, int ACT, int FMT, bool TAP, int FMV = 4>
 static int launch_c(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = (3 * 256 + 2 * 256) * 128;
-    const int tiles = ((a.M - a.m_begin + 255) / 256) * ((a.N + 255) / 256);
+    constexpr int BM = 64 * FMV;
+    constexpr int LDS = (3 * BM + 2 * 256) * 128;
+    const int tiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + 255) / 256);
     static PerDeviceOnce attr_once;
-    auto kern = gemmc_bf16_kernel<EPI, ACT, FMT, TAP>;
+    auto kern = gemmc_bf16_kernel<EPI, ACT, FMT, TAP, FMV>;
     if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
@@ -241,22 +249,222 @@ static int launch_c(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-bool gemm_asm16_has_tile(int epi, const GemmArgs& a) {
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The small tiles of the 16x16x32 family, hipcc-scheduled: gemm_bf16_kernel's scheme (gemm_bf16.hip: four waves 2 x 2, K step 64 = 128-byte LDS
+// rows, two-slot ring, TWO workgroups per CU, buffer-descriptor LDS-DMA with the chunk swizzle on the source address) with 16-row fragments:
+// tile ids 13 = 128x128, 14 = 128x192 (what ids 3 / 4 are to the 32x32x16 kernels).  They serve the launches the big tiles cannot fill (small
+// batches, ragged tails) with the SAME fp32 chain per output element as tiles 46 / 47: slice 0 (k 0..31) then slice 1 (k 32..63) of every K
+// step, one 16x16x32 MFMA each, so a launch's bits do not depend on which member of the family the cost model picks (tests/test_gpu_ops.py).
+template <int FMT> struct MF16 {
+    static __device__ __forceinline__ f32x4_t mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct MF16<FMT_F16> {
+    static __device__ __forceinline__ f32x4_t mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <int N> __device__ __forceinline__ void wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define SCHED_FENCE_C() __builtin_amdgcn_sched_barrier(0)
+
+// register -> global epilogue of a wave tile of GX x GW accumulator quads (EPI_BF16: 16-bit rows, EPI_F32: fp32 rows)
+template <int GX, int GW, int EPI, int ACT, int FMT>
+__device__ __forceinline__ void epilogue_direct_m16(const GemmArgs& a, const f32x4_t (&acc)[GX][GW], int mrow0, int ncol0, int lane) {
+    const int t = lane & 15, qd = lane >> 4;
+    float4 bias[GW];
+    bool nok[GW];
+    int ncl[GW];
+#pragma unroll
+    for (int j = 0; j < GW; ++j) {
+        const int n = ncol0 + 16 * j + 4 * qd;
+        nok[j] = n < a.N;
+        ncl[j] = n < a.N - 4 ? n : a.N - 4;
+        bias[j] = a.bias ? *(const float4*)(a.bias + ncl[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < GX; ++i) {
+        const int m = mrow0 + 16 * i + t;
+        const bool mok = m < a.M;
+        const size_t ro = (size_t)(mok ? m : a.M - 1) * a.ld0;
+#pragma unroll
+        for (int j = 0; j < GW; ++j) {
+            float v0 = acc[i][j][0] + bias[j].x, v1 = acc[i][j][1] + bias[j].y, v2 = acc[i][j][2] + bias[j].z, v3 = acc[i][j][3] + bias[j].w;
+            apply_act4<ACT>(v0, v1, v2, v3);
+            if constexpr (EPI == EPI_BF16) {
+                uint2 pk; pk.x = H16<FMT>::pack2(v0, v1); pk.y = H16<FMT>::pack2(v2, v3);
+                if (mok && nok[j]) *(uint2*)((bf16_t*)a.out0 + ro + ncl[j]) = pk;
+            } else {
+                if (mok && nok[j]) *(float4*)((float*)a.out0 + ro + ncl[j]) = make_float4(v0, v1, v2, v3);
+            }
+        }
+    }
+}
+
+template <int FM, int FN, int EPI, int ACT, int FMT>
+__device__ __forceinline__ void gemm16_tile(const GemmArgs& a, const int tile_id, char* smem) {
+    constexpr int BM = 64 * FM, BN = 64 * FN, RB = 128;
+    constexpr int GX = 2 * FM, GW = 2 * FN;                  // 16-row fragments per wave (wave tile 32 FM x 32 FN)
+    constexpr int XT = BM * RB, WT = BN * RB, STAGE = XT + WT;
+    constexpr int NP = (BM + BN) / 8, NPW = NP / 4, XPW = BM / 8 / 4;
+    static_assert(NP % 4 == 0 && (BM / 8) % 4 == 0, "pieces must split evenly over the 4 waves");
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M - a.m_begin + BM - 1) / BM;
+    const int wg = xcd_remap(tile_id, tiles_m * tiles_n);
+    const int m0 = a.m_begin + (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+    const int srow = lane >> 3, spos = lane & 7;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (size_t)m0 * a.ldx), 0, (int)0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.W + (size_t)n0 * a.K), 0, (int)0xffffffffu, 0x00020000);
+    int voff[NPW], lds_off[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int p = wave + 4 * i;
+        const bool isx = i < XPW;
+        const int r = (isx ? p : p - BM / 8) * 8 + srow;
+        const int c = spos ^ ((r >> 1) & 7);
+        if (isx) { int xm = m0 + r; xm = xm < a.M ? xm : a.M - 1; voff[i] = (int)(((long)(xm - m0) * a.ldx + c * 8) * 2); }
+        else { int wr = n0 + r; wr = wr < a.N ? wr : a.N - 1; voff[i] = ((wr - n0) * a.K + c * 8) * 2; }
+        lds_off[i] = (isx ? 0 : XT) + (isx ? p : p - BM / 8) * 1024;
+    }
+    const int nt = a.K / 64;
+    auto dma = [&](int kt, int i, char* base) {
+        const bool isx = i < XPW;
+        glds16_c(isx ? rx : rw, voff[i], (a.kpat && isx) ? tap3_offset(kt * 128) : kt * 128, base + lds_off[i]);
+    };
+    auto stage = [&](int kt, int slot) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) dma(kt, i, smem + slot * STAGE);
+    };
+    const int frow = lane & 15, fq = lane >> 4, swz = (frow >> 1) & 7;
+    int koff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) koff[h] = ((4 * h + fq) ^ swz) << 4;
+    const int xrow_off = (wm * 32 * FM + frow) * RB, wrow_off = XT + (wn * 32 * FN + frow) * RB;
+
+    f32x4_t acc[GX][GW];
+#pragma unroll
+    for (int i = 0; i < GX; ++i)
+#pragma unroll
+        for (int j = 0; j < GW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t xf[2][GX], wf[2][GW];
+    auto read_frags = [&](const char* sb, int h, int buf) {
+#pragma unroll
+        for (int f = 0; f < GX; ++f) xf[buf][f] = *(const bf16x8_t*)(sb + xrow_off + f * 16 * RB + koff[h]);
+#pragma unroll
+        for (int f = 0; f < GW; ++f) wf[buf][f] = *(const bf16x8_t*)(sb + wrow_off + f * 16 * RB + koff[h]);
+    };
+    // MFMAs of X fragments [i0, i1) of one slice with LDS-DMA pieces [p0, p1) of k-tile kt (-> ring slot dslot) spread between them
+    auto mfmas_dma = [&](int buf, int i0, int i1, int kt, int dslot, int p0, int p1, bool on) {
+        const int NM = (i1 - i0) * GW, np = p1 - p0;
+        char* base = smem + dslot * STAGE;
+#pragma unroll
+        for (int i = 0; i < GX; ++i) {
+            if (i < i0 || i >= i1) continue;
+#pragma unroll
+            for (int j = 0; j < GW; ++j) {
+                const int n = (i - i0) * GW + j;
+                acc[i][j] = MF16<FMT>::mfma(wf[buf][j], xf[buf][i], acc[i][j]);
+#pragma unroll
+                for (int p = 0; p < NPW; ++p) {
+                    if (np > 0 && p >= p0 && p < p1 && ((p - p0 + 1) * NM + np - 1) / np - 1 == n) {
+                        SCHED_FENCE_C();
+                        if (on) dma(kt, p, base);
+                        SCHED_FENCE_C();
+                    }
+                }
+            }
+        }
+    };
+
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    if (nt > 1) wait_vmcnt_c<NPW>(); else wait_vmcnt_c<0>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(smem, 0, 0);
+    int slot = 0;
+    // pieces [0, D0) of tile t+2 are issued behind the barrier of tile t (under the second half of its slice 1), the rest under slice 0 of tile t+1
+    constexpr int D0 = (NPW * 2 + 4) / 5;
+    for (int t = 0; t < nt; ++t) {
+        const char* sb = smem + slot * STAGE;
+        const int nslot = slot ^ 1;
+        const bool has_next = t + 1 < nt, cont = t >= 1 && t + 1 < nt, dma2 = t + 2 < nt;
+        SCHED_FENCE_C();
+        read_frags(sb, 1, 1);
+        SCHED_FENCE_C();
+        mfmas_dma(0, 0, GX, t + 1, nslot, D0, NPW, cont);
+        mfmas_dma(1, 0, GX / 2, 0, 0, 0, 0, false);
+        SCHED_FENCE_C();
+        if (has_next) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_vmcnt_c<0>();
+            __builtin_amdgcn_s_barrier();
+            SCHED_FENCE_C();
+            read_frags(smem + nslot * STAGE, 0, 0);
+            SCHED_FENCE_C();
+        }
+        mfmas_dma(1, GX / 2, GX, t + 2, slot, 0, D0, dma2);
+        slot = nslot;
+    }
+    epilogue_direct_m16<GX, GW, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
+}
+
+template <int FM, int FN, int EPI, int ACT, int FMT>
+__global__ __launch_bounds__(256, 2) void gemm16_bf16_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    constexpr int BM = 64 * FM, BN = 64 * FN;
+    const int ntiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        gemm16_tile<FM, FN, EPI, ACT, FMT>(a, tile, smem);
+        if (tile + (int)gridDim.x < ntiles) __builtin_amdgcn_s_barrier();
+    }
+}
+
+template <int FM, int FN, int EPI, int ACT, int FMT>
+static int launch_s(const GemmArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    const int tiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    static PerDeviceOnce attr_once;
+    auto kern = gemm16_bf16_kernel<FM, FN, EPI, ACT, FMT>;
+    if (attr_once.need()) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    }
+    int grid = tiles;
+    const int per_cu = a.tune_persist > 0 ? a.tune_persist : (a.tune_persist == 0 ? 2 : 0);
+    if (per_cu > 0 && tiles > per_cu * 256) grid = per_cu * 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- the family's dispatch ------------------------------------------------------------------------------------------------------
+bool gemm_asm16_has_tile(int epi, const GemmArgs& a, int tile) {
+    if (tile != 13 && tile != 14 && tile != 46 && tile != 47) return false;
     if ((epi != EPI_BF16 && epi != EPI_F32) || (a.act != 0 && a.act != 1)) return false;
     if (a.fmt != FMT_BF16 && a.fmt != FMT_F16) return false;
     if (epi == EPI_F32 && (a.fmt != FMT_BF16 || a.kpat)) return false;
-    if (a.K % 128 != 0 || a.K < 256) return false;
+    if (a.K % 64 != 0 || a.K < 64) return false;
     if (a.kpat && a.K != 1536) return false;
+    if (tile == 13 || tile == 14) return true;
+    if (a.K % 128 != 0 || a.K < 256) return false;         // the generated loops: pairs of K steps, at least four
+    if (tile == 46 && a.kpat) return false;
     return true;
 }
 
+template <int EPI, int ACT, int FMT>
+static int launch_family(int tile, const GemmArgs& a, hipStream_t s) {
+    if (tile == 13) return launch_s<2, 2, EPI, ACT, FMT>(a, s);
+    if (tile == 14) return launch_s<2, 3, EPI, ACT, FMT>(a, s);
+    if (tile == 46) return launch_c<EPI, ACT, FMT, false, 3>(a, s);
+    if constexpr (EPI == EPI_BF16) { if (a.kpat) return launch_c<EPI, ACT, FMT, true>(a, s); }
+    return launch_c<EPI, ACT, FMT, false>(a, s);
+}
+
 int launch_gemm_asm16(int epi, const GemmArgs& a, hipStream_t s) {
-    if (!gemm_asm16_has_tile(epi, a)) { syl_set_error("launch_gemm_asm16", "tile 47: 16-bit / fp32 rows (plain / GELU), K % 128 == 0, K >= 256"); return 1; }
-    if (epi == EPI_F32) return a.act == 1 ? launch_c<EPI_F32, 1, FMT_BF16, false>(a, s) : launch_c<EPI_F32, 0, FMT_BF16, false>(a, s);
-    if (a.fmt == FMT_F16) {
-        if (a.kpat) return a.act == 1 ? launch_c<EPI_BF16, 1, FMT_F16, true>(a, s) : launch_c<EPI_BF16, 0, FMT_F16, true>(a, s);
-        return a.act == 1 ? launch_c<EPI_BF16, 1, FMT_F16, false>(a, s) : launch_c<EPI_BF16, 0, FMT_F16, false>(a, s);
-    }
-    if (a.kpat) return a.act == 1 ? launch_c<EPI_BF16, 1, FMT_BF16, true>(a, s) : launch_c<EPI_BF16, 0, FMT_BF16, true>(a, s);
-    return a.act == 1 ? launch_c<EPI_BF16, 1, FMT_BF16, false>(a, s) : launch_c<EPI_BF16, 0, FMT_BF16, false>(a, s);
+    const int tile = a.tune_cfg - 1;
+    if (!gemm_asm16_has_tile(epi, a, tile)) { syl_set_error("launch_gemm_asm16", "no 16x16x32 instantiation for this tile / epilogue / K"); return 1; }
+    if (epi == EPI_F32) return a.act == 1 ? launch_family<EPI_F32, 1, FMT_BF16>(tile, a, s) : launch_family<EPI_F32, 0, FMT_BF16>(tile, a, s);
+    if (a.fmt == FMT_F16) return a.act == 1 ? launch_family<EPI_BF16, 1, FMT_F16>(tile, a, s) : launch_family<EPI_BF16, 0, FMT_F16>(tile, a, s);
+    return a.act == 1 ? launch_family<EPI_BF16, 1, FMT_BF16>(tile, a, s) : launch_family<EPI_BF16, 0, FMT_BF16>(tile, a, s);
 }

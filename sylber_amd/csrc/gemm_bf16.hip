@@ -909,9 +909,13 @@ static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
             }
             return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
-        case 51: case 57: case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 86: case 87: case 88: case 89: case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 47: case 98:
+        case 13: case 14: case 46: case 47:
+            // the v_mfma_f32_16x16x32 family (gemm_asm16.hip): the 16-bit-output launches by default (launch_f), any instantiated epilogue when forced
+            if (gemm_asm16_has_tile(EPI, a, cfg)) { GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm16(EPI, b, s); }
+            break;
+        case 51: case 57: case 60: case 61: case 62: case 63: case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77: case 78: case 80: case 81: case 82: case 83: case 85: case 86: case 87: case 88: case 89: case 90: case 91: case 92: case 93: case 94: case 95: case 96: case 97: case 98:
             // hand-scheduled K loop; a forced tile without an instantiation for this epilogue falls back to 128x192 (sylber_hip.h)
-            if (gemm_asm_has_tile(EPI, a, cfg) || (cfg != 51 && cfg != 57 && cfg != 60 && cfg != 80 && cfg != 85 && cfg != 86 && cfg != 90 && cfg != 91 && cfg != 95 && cfg != 96 && cfg != 97 && cfg != 47 && gemm_asm_applicable(EPI, a))) {
+            if (gemm_asm_has_tile(EPI, a, cfg) || (cfg != 51 && cfg != 57 && cfg != 60 && cfg != 80 && cfg != 85 && cfg != 86 && cfg != 90 && cfg != 91 && cfg != 95 && cfg != 96 && cfg != 97 && gemm_asm_applicable(EPI, a))) {
                 GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm(EPI, b, s);
             }
             break;
@@ -945,7 +949,7 @@ struct TileCfg { int id, bm, bn, per_cu; double eff, pr0; };
 struct TileModel {
     static constexpr int NCFG = 9;
     TileCfg cfgs[NCFG];
-    bool asm_ok, r5;
+    bool asm_ok, r5, m16;
     int EPI;
     const GemmArgs* a;
     TileModel(int EPI_, int FMT, const GemmArgs& a_) : EPI(EPI_), a(&a_) {
@@ -988,12 +992,39 @@ struct TileModel {
                                 {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27, pa}, {86, 256, 128, 1, 1.10, pa},
                                 {51, 192, 192, 1, (long_k ? 1.10 : 1.04) * GEMM_H192_EFF, pa}, {57, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa}};
         for (int i = 0; i < NCFG; ++i) cfgs[i] = init[i];
+        // The 16-bit-output GEMMs (EPI_BF16, plain or GELU: conv1-5 and FFN1, 46 % of the 32 x 10 s forward) run on the v_mfma_f32_16x16x32 FAMILY
+        // (gemm_asm16.hip; same-box +2.7 ... +7.2 % per launch, profiles/r06_mfma16_loop.md): 13 / 14 = the two-per-CU 128x128 / 128x192 kernels, 47 =
+        // tile 97's geometry, 46 = its 192-row sibling.  The family adds 32-k blocks to an element's fp32 chain where the 32x32x16 kernels add 16-k
+        // blocks, so the ROLE moves as a whole: every tile a batch shape can pick for these launches is a member, and results stay independent of
+        // the batch shape.  tune_mfma16 = -1 (SYLBER_OPT_GEMM_MFMA16) puts the role back on the 32x32x16 kernels.
+        m16 = EPI == EPI_BF16 && FMT != FMT_SPLIT && (a.act == 0 || a.act == 1) && a.tune_mfma16 >= 0 && gemm_asm16_has_tile(EPI, a, 14);
+        if (m16) {
+            const TileCfg fam[4] = {{13, 128, 128, 2, r5 ? 0.93 : 0.95, p2}, {14, 128, 192, 2, 1.00, p2}, {47, 256, 256, 1, long_k ? 1.32 : 1.27, pa},
+                                    {46, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa}};
+            for (int i = 0; i < NCFG; ++i) cfgs[i] = i < 4 ? fam[i] : TileCfg{-1, 256, 256, 1, 1.0, 1.0};
+        }
+    }
+    // the member of the 16x16x32 family that stands in for a FORCED tile id (SYLBER_OPT_GEMM_TILE is per handle: the parity tests force one id on
+    // every launch of a forward and expect the same bits from each; on the role's launches every id maps to a member of the same shape class)
+    int family_member(int cfg) const {
+        const GemmArgs& a = *this->a;
+        int m;
+        switch (cfg) {
+            case 13: case 14: case 46: case 47: m = cfg; break;
+            case 3: m = 13; break;
+            case 51: case 57: m = 46; break;
+            case 10: case 30: case 40: case 41: case 60: case 80: case 85: case 95: case 97: case 98: m = 47; break;
+            default: m = 14; break;
+        }
+        return gemm_asm16_has_tile(EPI, a, m) ? m : 14;
     }
     double cost_of(int i, long rows) const {
         const GemmArgs& a = *this->a;
         const TileCfg& c = cfgs[i];
-        if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, c.id))) return 1e300;   // only tiles that exist for this epilogue / format
-        if ((c.id == 51 || c.id == 57) && (a.tune_h192 < 0 || r5)) return 1e300;
+        if (c.id < 0) return 1e300;
+        if (m16) { if (!gemm_asm16_has_tile(EPI, a, c.id)) return 1e300; }
+        else if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, c.id))) return 1e300;   // only tiles that exist for this epilogue / format
+        if ((c.id == 51 || c.id == 57 || c.id == 46) && (a.tune_h192 < 0 || r5)) return 1e300;
         const long tm = (rows + c.bm - 1) / c.bm, tn = (a.N + c.bn - 1) / c.bn;
         if (c.id == 86 && tm * tn < 192) return 1e300;      // (measured for launches that fill the chip; small batches keep their tiles)
         const long slots = 256L * c.per_cu, tiles = tm * tn;
@@ -1036,7 +1067,7 @@ static int launch_f(const GemmArgs& a, hipStream_t s) {
     double whole_cost;
     const int best = pick(rows, &whole_cost);
     int cfg = cfgs[best].id;
-    if (a.tune_cfg > 0) cfg = a.tune_cfg - 1;            // per-call override (sylber_set_option / parity tests)
+    if (a.tune_cfg > 0) cfg = tm_.m16 ? tm_.family_member(a.tune_cfg - 1) : a.tune_cfg - 1;   // per-call override (sylber_set_option / parity tests)
     // ---- row split: rows of the full rounds on the chosen tile, the rest re-tiled.  FORCED ONLY (tune_tail > 0): measured (profiles/r06_tail_policy.md),
     // a smaller tile alone on its CU runs its K loop at the same wall time per step as a big one (a lone 128x192x3072 tile: 66 us; two
     // co-resident: 80 us), so re-tiling the tail buys nothing and the second launch costs 3-5 us; with two batches in flight it is a loss

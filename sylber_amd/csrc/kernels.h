@@ -55,6 +55,8 @@ struct GemmArgs {
                                   // row indices stay absolute everywhere (operands, epilogues, the row -> (utterance, frame) maps)
     int tune_model;               // 5: the round-5 cost model of launch_f (A/B switch); 0: the current one
     int tune_h192;                // -1: the cost model leaves the 192-row tiles (51 / 57) out (A/B switch)
+    int tune_mfma16;              // 0 (default): the 16-bit-output GEMMs (EPI_BF16: conv1-5, FFN1) run on the v_mfma_f32_16x16x32 family (tiles 13 / 14 / 46 / 47,
+                                  // gemm_asm16.hip); -1: on the 32x32x16 kernels of rounds 1-6a (A/B switch; the two families group an element's fp32 chain differently)
     int tune_tail;                // tail policy of multi-round launches: 0 automatic, -1 never split, k > 0 = force a split with tail tile id k - 1
 };
 
@@ -69,7 +71,7 @@ bool gemm_asm_applicable(int epi, const GemmArgs& a);
 bool gemm_asm_has_tile(int epi, const GemmArgs& a, int tile);
 int launch_gemm_asm(int epi, const GemmArgs& a, hipStream_t s);
 // tile 47 (gemm_asm16.hip): tile 97's geometry on v_mfma_f32_16x16x32; forced only (its own fp32 grouping over K)
-bool gemm_asm16_has_tile(int epi, const GemmArgs& a);
+bool gemm_asm16_has_tile(int epi, const GemmArgs& a, int tile);
 int launch_gemm_asm16(int epi, const GemmArgs& a, hipStream_t s);
 
 // MXFP8 GEMM (gemm_mxfp8.hip): e4m3 operands [rows][K] with one E8M0 scale per 32 elements along K stored

@@ -731,7 +731,7 @@ def emit_y3(fn=2, nw=8, tap=False, fm=4, gb=3):
     ins += ['[rx] "s"(rx)', '[rw] "s"(rw)', '[lbase] "s"(lbase)', '[cneg] "s"(cneg)']
     if tap:
         ins += ['[c2048] "s"(c2048)', '[cm1024] "s"(cm1024)', '[cm896] "s"(cm896)']
-    name = "gemm_asm_y3" + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + ("_t" if tap else "") + ".inc"
+    name = "gemm_asm_y3" + ("" if fm == 4 else f"_m{fm}") + ("" if nw == 4 else f"_w{nw}") + ("" if fn == (4 if nw == 4 else 2) else f"_n{fn}") + ("_t" if tap else "") + ".inc"
     dst = os.path.join(OUTDIR, name)
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_gemm_asm.py (Y3: the X3 ring on 16x16x32 MFMAs) -- do not edit; the schedule is documented there.\n")
@@ -977,6 +977,7 @@ def emit_product():
         emit_x3(3, 4, pre_e=7, pre_cols=cols)          # K >= 1152 (FFN2, K = 3072: 48 steps, the last 17 unrolled)
     emit_y3(2, 8)                    # tile 47: tile 97's geometry on 16x16x32 MFMAs (forced only: its own fp32 grouping)
     emit_y3(2, 8, tap=True)
+    emit_y3(2, 8, fm=3)              # tile 46: its 192-row sibling
     emit_f8(4)
     emit_f8(3)
     emit_f8(3, lds_scales=True)     # scales through LDS (one DMA piece per wave and step): the long-K launches

@@ -1,4 +1,6 @@
-"""Tile 97 (v_mfma_f32_32x32x16) against tile 47 (the same tile geometry on v_mfma_f32_16x16x32), same box, alternating (development aid).
+"""The 32x32x16 kernels against their siblings of the v_mfma_f32_16x16x32 family (csrc/gemm_asm16.hip), same box, alternating (development aid):
+tile 97 vs 47 (256x256, eight waves, generated loops), 57 vs 46 (192x256), 3 vs 13 and 4 vs 14 (hipcc-scheduled 128x128 / 128x192, two per CU).
+cfg + 1000000 = the launch on the 32x32x16 kernels (GemmArgs::tune_mfma16 = -1): without it a 16-bit-output launch maps any forced id into the family.
 
 The shapes are the launches tile 97 serves in the forward (conv1-5 in the 3-tap K order, FFN1) plus the 4096^3 yardstick; operands random, hot.
 Output: one markdown table row per shape (profiles/r06_mfma16_loop.md)."""
@@ -21,6 +23,17 @@ SHAPES = [  # name, M, N, K, ldx, epi, act, kpat
     ("4096^3 plain", 4096, 4096, 4096, 4096, 0, 0, False),
     ("8192x8192x4096 plain", 8192, 8192, 4096, 4096, 0, 0, False),
 ]
+PAIRS = [(97, 47)]
+SMALL = [  # the small tiles on the launches of small batches, and the 192-row siblings where a 256-row tile count leaves a partial round
+    ("FFN1 1x10s", 512, 3072, 768, 768, 0, 1, False, (3, 13)),
+    ("FFN1 1x10s", 512, 3072, 768, 768, 0, 1, False, (4, 14)),
+    ("FFN1 4x10s", 2048, 3072, 768, 768, 0, 1, False, (3, 13)),
+    ("FFN1 4x10s", 2048, 3072, 768, 768, 0, 1, False, (4, 14)),
+    ("conv6 32x10s", 16384, 512, 1024, 1024, 0, 1, False, (3, 13)),
+    ("conv4 1x10s (3-tap)", 2048, 512, 1536, 1024, 0, 1, True, (4, 14)),
+    ("FFN1 24x10s", 24 * 512, 3072, 768, 768, 0, 1, False, (57, 46)),
+    ("conv5 24x10s", 24 * 1024, 512, 1024, 1024, 0, 1, False, (57, 46)),
+]
 
 
 def run(m, n, k, ldx, epi, act, cfg):
@@ -29,14 +42,15 @@ def run(m, n, k, ldx, epi, act, cfg):
     return ms.value * 1e3
 
 
-print("| launch | M x N x K | tile 97 us (32x32x16) | tile 47 us (16x16x32) | TF 97 | TF 47 | 47 vs 97 |")
-print("|---|---|---:|---:|---:|---:|---:|")
-for name, m, n, k, ldx, epi, act, kpat in SHAPES:
-    t = {97: [], 47: []}
+print("| launch | M x N x K | tiles | 32x32x16 us | 16x16x32 us | TF | TF | gain |")
+print("|---|---|---|---:|---:|---:|---:|---:|")
+for row in [r + ((97, 47),) for r in SHAPES] + SMALL:
+    name, m, n, k, ldx, epi, act, kpat, (old, new) = row
+    t = {old: [], new: []}
     for _ in range(REPS):
-        for tile in (97, 47):
-            t[tile].append(run(m, n, k, ldx, epi, act, tile + (400000 if kpat else 0)))
-    a, b = sorted(t[97])[len(t[97]) // 2], sorted(t[47])[len(t[47]) // 2]
+        for tile in (old, new):
+            t[tile].append(run(m, n, k, ldx, epi, act, tile + (400000 if kpat else 0) + (1000000 if tile == old else 0)))
+    a, b = sorted(t[old])[len(t[old]) // 2], sorted(t[new])[len(t[new]) // 2]
     fl = 2.0 * m * n * k
-    print("| %s | %d x %d x %d | %.1f (%s) | %.1f (%s) | %.0f | %.0f | %+.1f %% |" % (
-        name, m, n, k, a, " ".join("%.1f" % v for v in t[97]), b, " ".join("%.1f" % v for v in t[47]), fl / a / 1e6, fl / b / 1e6, (a / b - 1) * 100), flush=True)
+    print("| %s | %d x %d x %d | %d vs %d | %.1f (%s) | %.1f (%s) | %.0f | %.0f | %+.1f %% |" % (
+        name, m, n, k, old, new, a, " ".join("%.1f" % v for v in t[old]), b, " ".join("%.1f" % v for v in t[new]), fl / a / 1e6, fl / b / 1e6, (a / b - 1) * 100), flush=True)
