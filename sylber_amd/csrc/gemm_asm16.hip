@@ -14,6 +14,7 @@
 // output columns 4 q + e (e < 4) of the W fragment.  A wave's 128 x 64 tile = 8 X fragments x 4 W fragments = 32 accumulator quads.
 #include "kernels.h"
 #include "gemm_epilogue.h"
+#include <type_traits>
 
 typedef __attribute__((address_space(3))) void* lds_vptr_c;
 typedef int i32x4c_t __attribute__((ext_vector_type(4)));
@@ -385,10 +386,13 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, const int tile_id
     int slot = 0;
     // pieces [0, D0) of tile t+2 are issued behind the barrier of tile t (under the second half of its slice 1), the rest under slice 0 of tile t+1
     constexpr int D0 = (NPW * 2 + 4) / 5;
-    for (int t = 0; t < nt; ++t) {
+    // one K tile.  STEADY (1 <= t <= nt - 3): every "does tile t+1 / t+2 exist" test is true, so the loop that runs nearly all tiles carries no branch
+    // around its LDS-DMA instructions (as gemm_bf16_tile); the first and the last two tiles take the general form
+    auto ktile = [&](auto steady, int t) {
+        constexpr bool STEADY = decltype(steady)::value;
         const char* sb = smem + slot * STAGE;
         const int nslot = slot ^ 1;
-        const bool has_next = t + 1 < nt, cont = t >= 1 && t + 1 < nt, dma2 = t + 2 < nt;
+        const bool has_next = STEADY || t + 1 < nt, cont = STEADY || (t >= 1 && t + 1 < nt), dma2 = STEADY || t + 2 < nt;
         SCHED_FENCE_C();
         read_frags(sb, 1, 1);
         SCHED_FENCE_C();
@@ -405,6 +409,12 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, const int tile_id
         }
         mfmas_dma(1, GX / 2, GX, t + 2, slot, 0, D0, dma2);
         slot = nslot;
+    };
+    {
+        int t = 0;
+        if (nt > 0) ktile(std::false_type{}, t++);
+        for (; t < nt - 2; ++t) ktile(std::true_type{}, t);
+        for (; t < nt; ++t) ktile(std::false_type{}, t);
     }
     epilogue_direct_m16<GX, GW, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
 }

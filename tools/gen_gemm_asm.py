@@ -629,8 +629,8 @@ def y3_step(rq, par, tail_w, x_next, head, vm, nxt=True, first=False):
                 after[1 + j].append(("rw", 1, j, par))
             for i in range(GX):
                 after[i * GW + GW - 1].append(("rx", i, 1))
-            pos = 2
-            stride = 4 if 2 + 4 * (len(queue) - 1) < n_mf else 2
+            pos = Y3["dpos"]
+            stride = Y3["dstride"] if pos + Y3["dstride"] * (len(queue) - 1) < n_mf else 2
             while queue:
                 assert pos < n_mf
                 a, b = queue.pop(0)
@@ -657,7 +657,7 @@ def y3_step(rq, par, tail_w, x_next, head, vm, nxt=True, first=False):
                 for i in range(GB + 1, GX):
                     after[i * GW + GW - 1].append(("rx", i, 0))
             if head:
-                pos = bpos + 2
+                pos = bpos + Y3["hpos"]
                 for p_ in range(nh):
                     assert pos < n_mf
                     a, b = y3_dma_w(nxp + p_, par)
@@ -689,6 +689,12 @@ def y3_step(rq, par, tail_w, x_next, head, vm, nxt=True, first=False):
 
 
 def emit_y3(fn=2, nw=8, tap=False, fm=4, gb=3):
+    # schedule knobs for same-box A/B builds (SYLBER_BUILD_VARIANT; defaults = the shipping schedule): Y3_GB = X fragment behind whose MFMAs the
+    # barrier of slice 1 sits, Y3_DSTRIDE / Y3_DPOS = spacing / first position of slice 0's LDS-DMA pieces, Y3_HPOS = first W piece behind the barrier
+    gb = int(os.environ.get("Y3_GB", gb))
+    Y3["dstride"] = int(os.environ.get("Y3_DSTRIDE", 4))
+    Y3["dpos"] = int(os.environ.get("Y3_DPOS", 2))
+    Y3["hpos"] = int(os.environ.get("Y3_HPOS", 2))
     bn = 64 * fn if nw == 4 else 128 * fn
     Y3.update({"fn": fn, "nw": nw, "bn": bn, "tap": tap, "fm": fm, "xt": 64 * fm * 128, "gb": gb})
     GX, GW = 2 * fm, 2 * fn
