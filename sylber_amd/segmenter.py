@@ -331,6 +331,13 @@ class Segmenter:
         self.output_memory = kwargs.get("output_memory", "pinned")
         if self.output_memory not in ("pinned", "pageable"):
             raise ValueError("output_memory must be 'pinned' or 'pageable'")
+        # Round 6: a LARGE batch of host tensors is cut into `call_split` sub-batches that go through the machinery of ``stream`` inside the one
+        # synchronous call: the upload of part 2 runs under the forward of part 1 and the download of part 1 under the forward of part 2, so the
+        # call pays the PCIe time of ONE part at each end instead of the whole batch's (32 x 10 s: 7.4 -> see INTEGRATION.md).  Every part is padded
+        # to the WHOLE batch's longest clip (the reference pads to the batch max, sylber.py:93-118, and returns the padded frames), and an
+        # utterance's results do not depend on the batch it is computed in, so the call returns exactly what the unsplit call returns.  0 / 1: off.
+        self._call_split = max(0, int(kwargs.get("call_split", 2)))
+        # (a split call leases one page-locked block per part: `max_pinned_batches` counts blocks)
         self.out_pool = PinnedOutputPool(max_leased=int(kwargs.get("max_pinned_batches", 4)))
         # host padding of tensor inputs (encode_batch).  tools/pad_probe.py on the 256-cpu boxes: the 20 MB copy of a 32 x 10 s batch into the
         # page-locked staging buffer takes 0.49 ms on one thread, 0.36-0.44 on two, MORE on four / eight / sixteen (0.58 / 0.93 / 1.25: waking
@@ -513,6 +520,9 @@ class Segmenter:
         mark("enter")
         gmark("enter")
         batch_wavs, is_batch = self._collect(wav_file, wav)
+        parts = self._split_plan(batch_wavs) if (is_batch and tr is None and gtr is None) else None
+        if parts is not None:
+            return self._call_in_parts(parts, in_second)
         hidden, _ = self.encode_batch(batch_wavs)
         gmark("forward done")
         mark("padded, H2D and forward issued")
@@ -600,6 +610,43 @@ class Segmenter:
         mark("dicts built")
         return outputs if is_batch else outputs[0]
 
+    # -- one synchronous call on a large host batch, pipelined over sub-batches (round 6) -----------------
+    def _split_plan(self, batch_wavs):
+        """sub-batches (lists of the caller's tensors, in order) or None: only host batches large enough that a part still fills the chip
+        (at least 8 rows and ~65 s of padded audio per part)"""
+        n = self._call_split
+        if n < 2 or len(batch_wavs) < 2:
+            return None
+        rows, lmax = 0, 0
+        for w in batch_wavs:
+            if not torch.is_tensor(w) or w.dim() != 2 or w.is_cuda:
+                return None
+            rows += int(w.shape[0])
+            lmax = max(lmax, int(w.shape[1]))
+        n = min(n, rows // 8, (rows * lmax) >> 20)
+        if n < 2:
+            return None
+        parts, cur, acc, k = [], [], 0, 1
+        for w in batch_wavs:
+            cur.append(w)
+            acc += int(w.shape[0])
+            if acc * n >= rows * k and k < n:
+                parts.append(cur)
+                cur, k = [], k + 1
+        if cur:
+            parts.append(cur)
+        return parts if len(parts) >= 2 else None
+
+    def _call_in_parts(self, parts, in_second):
+        self._force_lmax = max(int(w.shape[1]) for p in parts for w in p)
+        outputs = []
+        try:
+            for res in self.stream(parts, in_second=in_second):
+                outputs.extend(res)
+        finally:
+            self._force_lmax = 0
+        return outputs
+
     # -- a stream of batches: the PCIe-inclusive path at (nearly) the resident rate -----------------------
     def stream(self, batches, in_second=True):
         """Generator over an iterable of batches (each what ``__call__`` takes as ``wav=``: a list of host ``[channels, N]`` tensors).
@@ -639,7 +686,7 @@ class Segmenter:
             rows, lengths = self._rows(batch_wavs if isinstance(batch_wavs, (list, tuple)) else [batch_wavs])
             if any(r.is_cuda for r in rows):
                 raise ValueError("Segmenter.stream takes host tensors (device batches have nothing to overlap: use __call__)")
-            lmax = max(lengths)
+            lmax = max(max(lengths), int(self.__dict__.get("_force_lmax") or 0))      # (a split __call__ pads every part to the whole batch's max)
             stage, slot = self._stage_buffer((len(rows), lmax))
             stage_np = stage.numpy()
 

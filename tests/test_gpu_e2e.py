@@ -308,6 +308,45 @@ def test_stream_of_batches_equals_calls(sd):
     assert all(np.array_equal(a["segments"], b["segments"] / 50.0) for a, b in zip(sec[0], ref[0]))
 
 
+def test_call_split_returns_the_unsplit_call(sd):
+    """round 6: a large host batch is cut into `call_split` sub-batches pipelined INSIDE one synchronous __call__ (upload of part 2 under the forward
+    of part 1, download of part 1 under the forward of part 2).  Every part is padded to the whole batch's longest clip (sylber.py:93-118 pads to
+    the batch max and returns the padded frames) and an utterance's results do not depend on the batch it is computed in, so the call returns the
+    bits of the unsplit call: ragged lengths, a stereo item (two rows), 2 / 3 / 4 parts, both output memories, the opt-in output subset; small
+    batches, device tensors and a single tensor are not split"""
+    from sylber_amd import Segmenter
+    rng = np.random.default_rng(33)
+    wavs = [syllable_wave(int(rng.integers(100000, 128000)), 500 + i) for i in range(23)]
+    wavs.insert(5, torch.cat([syllable_wave(120000, 601), syllable_wave(120000, 602)], 0))      # [2, N]: two rows of the batch
+    wavs[11] = syllable_wave(131072, 603)                                                         # the batch max
+    ref_seg = Segmenter(model_ckpt=sd, call_split=0)
+    assert ref_seg._split_plan(wavs) is None
+    ref = ref_seg(wav=wavs, in_second=False)
+    assert len(ref) == 25 and all(o["hidden_states"].shape == ref[0]["hidden_states"].shape for o in ref)
+    for n, mode in ((2, "pinned"), (3, "pinned"), (4, "pageable")):
+        S = Segmenter(model_ckpt=sd, call_split=n, output_memory=mode)
+        plan = S._split_plan(wavs)
+        assert plan is not None and len(plan) == min(n, 3) and sum(len(p) for p in plan) == len(wavs)      # (25 rows: at most 3 parts of 8+ rows)
+        for _ in range(2):
+            got = S(wav=wavs, in_second=False)
+            assert len(got) == len(ref)
+            for g, e in zip(got, ref):
+                _check_contract(g, False)
+                assert np.array_equal(g["hidden_states"], e["hidden_states"]) and np.array_equal(g["segments"], e["segments"])
+                assert np.array_equal(g["segment_features"], e["segment_features"], equal_nan=True)
+        sec = S(wav=wavs, in_second=True)
+        assert all(np.array_equal(a["segments"], b["segments"] / 50.0) for a, b in zip(sec, ref))
+    S = Segmenter(model_ckpt=sd, call_split=2, outputs=("segments", "segment_features"))
+    got = S(wav=wavs, in_second=False)
+    assert all(set(g) == {"segments", "segment_features"} and np.array_equal(g["segments"], e["segments"]) and
+               np.array_equal(g["segment_features"], e["segment_features"], equal_nan=True) for g, e in zip(got, ref))
+    # not split: few rows, little audio, device tensors, a bare tensor
+    assert S._split_plan(wavs[:6]) is None and S._split_plan([w[:, :8000] for w in wavs]) is None
+    assert S._split_plan([w.cuda() for w in wavs]) is None
+    one = S(wav=wavs[0], in_second=False)
+    assert isinstance(one, dict) and np.array_equal(one["segments"], Segmenter(model_ckpt=sd, call_split=0)(wav=wavs[0], in_second=False)["segments"])
+
+
 def test_outputs_opt_in_skips_hidden_states(sd):
     """round 6: `outputs=` chooses which keys of the reference's dict (sylber.py:134-138) a call returns.  The default is the reference's
     contract (all three); without "hidden_states" the 49 MB D2H of a 32 x 10 s batch and its page-locked block are skipped, without

@@ -19,6 +19,10 @@ python bench.py --ragged --no-cpu-baseline --no-api --no-other-configs > $OUT/be
 python bench.py --exchange-selftest --no-cpu-baseline --no-api 2> $OUT/bench_selftest.err | tail -1 > $OUT/bench_exchange_selftest.json
 python tools/attn_bench.py > $OUT/attn_bench.txt 2>&1
 python tools/gemm_bench.py -1,4,91,97 > $OUT/gemm_bench.txt 2>&1
+# round 6, second collection: the 16x16x32 family against the 32x32x16 kernels and against the vendor library on THIS box
+python tools/blaslt_yardstick.py > $OUT/yardstick_hipblaslt.md 2>&1
+python tools/mfma16_ab.py 3 > $OUT/mfma16_ab.md 2>&1
+bash tools/mfma16_forward_ab.sh 2 > $OUT/mfma16_forward_ab.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-other-configs > $OUT/trace_pipelined.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sequential -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-other-configs --no-overlap > $OUT/trace_sequential.log 2>&1

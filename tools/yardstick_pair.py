@@ -38,8 +38,11 @@ def timed(fn, iters):
 
 t_v = timed(lambda: torch.matmul(x, w.t(), out=out), 40)
 lib = _lib.load()
-ms = ctypes.c_float()
+ms, ms32 = ctypes.c_float(), ctypes.c_float()
+# the automatic tile of a 16-bit-output launch is a member of the v_mfma_f32_16x16x32 family (tile 47 at these shapes); cfg 1000097 = tile 97, the
+# same geometry on v_mfma_f32_32x32x16 (rounds 3-6a): the three kernels of profiles/r06_yardstick_pmc.md
 _lib.check(lib.sylber_debug_gemm_bench(m, n, k, k, 0, 0, -1, 40, ctypes.byref(ms)), "gemm_bench")
+_lib.check(lib.sylber_debug_gemm_bench(m, n, k, k, 0, 0, 1000097, 40, ctypes.byref(ms32)), "gemm_bench")
 fl = 2.0 * m * n * k
-print("%s M=%d N=%d K=%d | hipBLASLt %.1f us %.0f TF | this library %.1f us %.0f TF | ratio %.3f" % (
-    name, m, n, k, t_v * 1e3, fl / t_v / 1e9, ms.value * 1e3, fl / ms.value / 1e9, t_v / ms.value))
+print("%s M=%d N=%d K=%d | hipBLASLt %.1f us %.0f TF | this library (16x16x32 family) %.1f us %.0f TF | tile 97 (32x32x16) %.1f us %.0f TF | vendor / ours %.3f" % (
+    name, m, n, k, t_v * 1e3, fl / t_v / 1e9, ms.value * 1e3, fl / ms.value / 1e9, ms32.value * 1e3, fl / ms32.value / 1e9, t_v / ms.value))
