@@ -941,32 +941,17 @@ def main():
             t_lean.append(time.perf_counter() - t0)
         dt_lean = statistics.median(t_lean)
         del lean
-        # the default call computes a large batch in `call_split` pipelined parts (round 6); the same call in ONE part, as rounds 1-6a made it
-        one = Segmenter(model_ckpt=sd, device=str(dev), precision=args.precision, call_split=0)
-        for _ in range(2):
-            one(wav=host_wavs, in_second=True)
-        t_one = []
-        for _ in range(n_api):
-            t0 = time.perf_counter()
-            one(wav=host_wavs, in_second=True)
-            t_one.append(time.perf_counter() - t0)
-        dt_one = statistics.median(t_one)
-        del one
         api = {"value": round(B * clip_seconds / dt, 1), "unit": "audio-sec/s", "ms_per_call": round(dt * 1e3, 2),
                "without_hidden_states": {"value": round(B * clip_seconds / dt_lean, 1), "unit": "audio-sec/s", "ms_per_call": round(dt_lean * 1e3, 2),
                                          "what": "the same call with Segmenter(outputs=('segments', 'segment_features')): opt-in, the default returns the reference's three keys"},
-               "call_split": seg_api._call_split,
-               "in_one_part": {"value": round(B * clip_seconds / dt_one, 1), "unit": "audio-sec/s", "ms_per_call": round(dt_one * 1e3, 2),
-                               "what": "Segmenter(call_split=0): the batch as ONE forward (rounds 1-6a); the default cuts a large host batch into call_split parts "
-                                       "pipelined inside the call (upload / download of one part under the forward of the other), same returned bits"},
                "stream": {"value": round(B * clip_seconds / dt_stream, 1), "unit": "audio-sec/s", "ms_per_batch": round(dt_stream * 1e3, 2),
                           "what": "Segmenter.stream over %d such batches (host tensors in, numpy dicts out): copies and host work of "
                                   "neighbouring batches overlap the forward" % n_stream},
                "ms_min": round(min(t_api) * 1e3, 2), "ms_median": round(dt * 1e3, 2), "ms_max": round(max(t_api) * 1e3, 2),
                "calls": n_api, "pinned_allocations_during_timing": seg_api.out_pool.allocations - allocs0,
-               "what": "Segmenter.__call__(wav=[%d host tensors]) -> list of numpy dicts: padding into a pinned staging ring + H2D, forward + "
-                       "segmentation, D2H of hidden states / segments / features into leased page-locked blocks (PinnedOutputPool), per-utterance "
-                       "slicing -- in call_split pipelined parts; %d back-to-back calls" % (B, n_api)}
+               "what": "Segmenter.__call__(wav=[%d host tensors]) -> list of numpy dicts: one batched H2D from a pinned staging "
+                       "ring, forward + segmentation, D2H of hidden states / segments / features into a leased page-locked "
+                       "block (PinnedOutputPool), per-utterance slicing; %d back-to-back calls" % (B, n_api)}
         del seg_api
 
     cpu = None

@@ -331,12 +331,12 @@ class Segmenter:
         self.output_memory = kwargs.get("output_memory", "pinned")
         if self.output_memory not in ("pinned", "pageable"):
             raise ValueError("output_memory must be 'pinned' or 'pageable'")
-        # Round 6: a LARGE batch of host tensors is cut into `call_split` sub-batches that go through the machinery of ``stream`` inside the one
-        # synchronous call: the upload of part 2 runs under the forward of part 1 and the download of part 1 under the forward of part 2, so the
-        # call pays the PCIe time of ONE part at each end instead of the whole batch's (32 x 10 s: 7.4 -> see INTEGRATION.md).  Every part is padded
-        # to the WHOLE batch's longest clip (the reference pads to the batch max, sylber.py:93-118, and returns the padded frames), and an
-        # utterance's results do not depend on the batch it is computed in, so the call returns exactly what the unsplit call returns.  0 / 1: off.
-        self._call_split = max(0, int(kwargs.get("call_split", 2)))
+        # Round 6 (measured, OFF by default): `call_split = n >= 2` cuts a large batch of host tensors into n sub-batches that go through the machinery of
+        # ``stream`` inside the one synchronous call (upload of part 2 under the forward of part 1, download of part 1 under the forward of part 2; every
+        # part padded to the WHOLE batch's longest clip, so the call returns exactly the unsplit call's bits).  It is SLOWER on every shape tried
+        # (32 x 10 s: 7.4 -> 8.2 ms with two parts, 9.7 with three; 16 x 10 s 4.5 -> 5.5; 8 x 60 s equal): a half batch's forward is not half a forward, and
+        # the download of one part runs as a shader copy beside the 160-KiB-LDS GEMM workgroups of the other part's forward (tools/api_split_ab.py).
+        self._call_split = max(0, int(kwargs.get("call_split", 0)))
         # (a split call leases one page-locked block per part: `max_pinned_batches` counts blocks)
         self.out_pool = PinnedOutputPool(max_leased=int(kwargs.get("max_pinned_batches", 4)))
         # host padding of tensor inputs (encode_batch).  tools/pad_probe.py on the 256-cpu boxes: the 20 MB copy of a 32 x 10 s batch into the

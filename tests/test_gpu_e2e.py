@@ -309,8 +309,8 @@ def test_stream_of_batches_equals_calls(sd):
 
 
 def test_call_split_returns_the_unsplit_call(sd):
-    """round 6: a large host batch is cut into `call_split` sub-batches pipelined INSIDE one synchronous __call__ (upload of part 2 under the forward
-    of part 1, download of part 1 under the forward of part 2).  Every part is padded to the whole batch's longest clip (sylber.py:93-118 pads to
+    """round 6 (an option, off by default: measured slower, tools/api_split_ab.py): `call_split = n` cuts a large host batch into n sub-batches pipelined
+    INSIDE one synchronous __call__ (upload of part 2 under the forward of part 1, download of part 1 under the forward of part 2).  Every part is padded to the whole batch's longest clip (sylber.py:93-118 pads to
     the batch max and returns the padded frames) and an utterance's results do not depend on the batch it is computed in, so the call returns the
     bits of the unsplit call: ragged lengths, a stereo item (two rows), 2 / 3 / 4 parts, both output memories, the opt-in output subset; small
     batches, device tensors and a single tensor are not split"""
