@@ -309,7 +309,7 @@ extern "C" int sylber_set_option(sylber_t c, int32_t key, int32_t value) {
             break;
         }
         case SYLBER_OPT_SEGMENT: c->opt_segment = value < 0 ? -1 : 0; break;
-        case SYLBER_OPT_GEMM_MODEL: c->opt_gemm_model = value == 5 ? 5 : (value == 2 ? 2 : 0); break;
+        case SYLBER_OPT_GEMM_MODEL: c->opt_gemm_model = value == 5 ? 5 : (value == 2 ? 2 : (value == 6 ? 6 : 0)); break;   // (6 = 0 without the lone-round rule: A/B)
         case SYLBER_OPT_GEMM_H192: c->opt_gemm_h192 = value < 0 ? -1 : 0; break;
         case SYLBER_OPT_GEMM_MFMA16: c->opt_gemm_mfma16 = value < 0 ? -1 : 0; break;
         case SYLBER_OPT_GEMM_TAIL: c->opt_gemm_tail = value < 0 ? -1 : (value > 0 ? value + 1 : 0); break;   // k > 0: tail tile id k (stored id + 1)

@@ -300,16 +300,21 @@ __device__ __forceinline__ void epilogue_direct_m16(const GemmArgs& a, const f32
     }
 }
 
-template <int FM, int FN, int EPI, int ACT, int FMT>
+// NW = 4: waves 2 x 2, wave tile 32 FM x 32 FN (tiles 13 / 14).  NW = 8 (tiles 15 / 16, round 6): waves 2 x 4, wave tile 32 FM x 16 FN -- the SAME tile and the
+// same chain order on twice the waves: a workgroup that is ALONE on its CU (small batches: fewer tiles than CUs) is bound by what ONE wave per SIMD has to issue per
+// K step -- eight LDS-DMA pieces at 100+ issue cycles each beside 32 sixteen-cycle MFMAs and 16 fragment reads (~2 200 cycles per K step measured against 512 of
+// MFMA time); eight waves halve every per-wave count and put two waves on each SIMD
+template <int FM, int FN, int EPI, int ACT, int FMT, int NW = 4>
 __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, const int tile_id, char* smem) {
     constexpr int BM = 64 * FM, BN = 64 * FN, RB = 128;
-    constexpr int GX = 2 * FM, GW = 2 * FN;                  // 16-row fragments per wave (wave tile 32 FM x 32 FN)
+    constexpr int WNN = NW / 2;                              // waves along n
+    constexpr int GX = 2 * FM, GW = 4 * FN / WNN;            // 16-row fragments per wave (wave tile 32 FM x (64 FN / WNN))
     constexpr int XT = BM * RB, WT = BN * RB, STAGE = XT + WT;
-    constexpr int NP = (BM + BN) / 8, NPW = NP / 4, XPW = BM / 8 / 4;
-    static_assert(NP % 4 == 0 && (BM / 8) % 4 == 0, "pieces must split evenly over the 4 waves");
+    constexpr int NP = (BM + BN) / 8, NPW = NP / NW, XPW = BM / 8 / NW;
+    static_assert(NP % NW == 0 && (BM / 8) % NW == 0 && (4 * FN) % WNN == 0, "pieces / fragments must split evenly over the waves");
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNN, wn = wave % WNN;
     const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M - a.m_begin + BM - 1) / BM;
     const int wg = xcd_remap(tile_id, tiles_m * tiles_n);
     const int m0 = a.m_begin + (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
@@ -320,7 +325,7 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, const int tile_id
     int voff[NPW], lds_off[NPW];
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-        const int p = wave + 4 * i;
+        const int p = wave + NW * i;
         const bool isx = i < XPW;
         const int r = (isx ? p : p - BM / 8) * 8 + srow;
         const int c = spos ^ ((r >> 1) & 7);
@@ -341,7 +346,7 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, const int tile_id
     int koff[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) koff[h] = ((4 * h + fq) ^ swz) << 4;
-    const int xrow_off = (wm * 32 * FM + frow) * RB, wrow_off = XT + (wn * 32 * FN + frow) * RB;
+    const int xrow_off = (wm * 32 * FM + frow) * RB, wrow_off = XT + (wn * 16 * GW + frow) * RB;
 
     f32x4_t acc[GX][GW];
 #pragma unroll
@@ -416,47 +421,47 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, const int tile_id
         for (; t < nt - 2; ++t) ktile(std::true_type{}, t);
         for (; t < nt; ++t) ktile(std::false_type{}, t);
     }
-    epilogue_direct_m16<GX, GW, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, lane);
+    epilogue_direct_m16<GX, GW, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 16 * GW, lane);
 }
 
-template <int FM, int FN, int EPI, int ACT, int FMT>
-__global__ __launch_bounds__(256, 2) void gemm16_bf16_kernel(const GemmArgs a) {
+template <int FM, int FN, int EPI, int ACT, int FMT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void gemm16_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int BM = 64 * FM, BN = 64 * FN;
     const int ntiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        gemm16_tile<FM, FN, EPI, ACT, FMT>(a, tile, smem);
+        gemm16_tile<FM, FN, EPI, ACT, FMT, NW>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) __builtin_amdgcn_s_barrier();
     }
 }
 
-template <int FM, int FN, int EPI, int ACT, int FMT>
+template <int FM, int FN, int EPI, int ACT, int FMT, int NW = 4>
 static int launch_s(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * FM, BN = 64 * FN;
     constexpr int LDS = 2 * (BM + BN) * 128;
     const int tiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static PerDeviceOnce attr_once;
-    auto kern = gemm16_bf16_kernel<FM, FN, EPI, ACT, FMT>;
+    auto kern = gemm16_bf16_kernel<FM, FN, EPI, ACT, FMT, NW>;
     if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
     int grid = tiles;
     const int per_cu = a.tune_persist > 0 ? a.tune_persist : (a.tune_persist == 0 ? 2 : 0);
     if (per_cu > 0 && tiles > per_cu * 256) grid = per_cu * 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // ---- the family's dispatch ------------------------------------------------------------------------------------------------------
 bool gemm_asm16_has_tile(int epi, const GemmArgs& a, int tile) {
-    if (tile != 13 && tile != 14 && tile != 46 && tile != 47) return false;
+    if (tile != 13 && tile != 14 && tile != 15 && tile != 16 && tile != 46 && tile != 47) return false;
     if ((epi != EPI_BF16 && epi != EPI_F32) || (a.act != 0 && a.act != 1)) return false;
     if (a.fmt != FMT_BF16 && a.fmt != FMT_F16) return false;
     if (epi == EPI_F32 && (a.fmt != FMT_BF16 || a.kpat)) return false;
     if (a.K % 64 != 0 || a.K < 64) return false;
     if (a.kpat && a.K != 1536) return false;
-    if (tile == 13 || tile == 14) return true;
+    if (tile == 13 || tile == 14 || tile == 15 || tile == 16) return true;
     if (a.K % 128 != 0 || a.K < 256) return false;         // the generated loops: pairs of K steps, at least four
     if (tile == 46 && a.kpat) return false;
     return true;
@@ -466,6 +471,8 @@ template <int EPI, int ACT, int FMT>
 static int launch_family(int tile, const GemmArgs& a, hipStream_t s) {
     if (tile == 13) return launch_s<2, 2, EPI, ACT, FMT>(a, s);
     if (tile == 14) return launch_s<2, 3, EPI, ACT, FMT>(a, s);
+    if (tile == 15) return launch_s<2, 2, EPI, ACT, FMT, 8>(a, s);
+    if (tile == 16) return launch_s<2, 3, EPI, ACT, FMT, 8>(a, s);
     if (tile == 46) return launch_c<EPI, ACT, FMT, false, 3>(a, s);
     if constexpr (EPI == EPI_BF16) { if (a.kpat) return launch_c<EPI, ACT, FMT, true>(a, s); }
     return launch_c<EPI, ACT, FMT, false>(a, s);

@@ -50,20 +50,25 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // sits only where the kernel waits lgkmcnt(0) anyway or has no LDS read in flight
 #define TSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 
-template <int FM, int FN, int BK, int NSTAGE, bool PRIO, int EPI, int ACT, int FMT>
+// WM x WN = the wave grid.  2 x 2 (four waves, wave tile 32 FM x 32 FN): tile ids 0 / 3 / 4.  4 x 2 (EIGHT waves, round 6: ids 5 = 128x128 with FM = 1, FN = 2 and
+// 6 = 128x192 with FM = 1, FN = 3): the same tiles on twice the waves.  A workgroup that is alone on its CU -- every launch of a small batch -- is bound by what one
+// wave per SIMD has to ISSUE per K step (eight LDS-DMA pieces at 100+ issue cycles each, 16 fragment reads, 16 MFMAs: ~2 200 cycles against 512 of MFMA time);
+// eight waves halve every per-wave count and put two waves on each SIMD (profiles/r06_small_tiles.md).  Same chain order per output element: bit-identical.
+template <int FM, int FN, int BK, int NSTAGE, bool PRIO, int EPI, int ACT, int FMT, int WM = 2, int WN = 2>
 __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile_id, char* smem) {
-    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int NWV = WM * WN;
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int RB = BK * 2;               // bytes per LDS row (128 or 64)
     constexpr int CPR = RB / 16;             // 16-B chunks per row
     constexpr int RPP = 1024 / RB;           // rows per 1-KiB staging piece (one wave instruction)
     constexpr int KK = BK / 16;              // MFMA k-substeps per stage
     constexpr int XT = BM * RB, WT = BN * RB, STAGE = XT + WT;
     constexpr int NP = (BM + BN) / RPP;      // 1-KiB pieces per stage
-    constexpr int NPW = NP / 4;              // pieces per wave
-    static_assert(NP % 4 == 0, "tile must split evenly over 4 waves");
+    constexpr int NPW = NP / NWV;            // pieces per wave
+    static_assert(NP % NWV == 0, "tile must split evenly over the waves");
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int tiles_n = (a.N + BN - 1) / BN;
     const int tiles_m = (a.M - a.m_begin + BM - 1) / BM;
@@ -78,12 +83,12 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     int lds_off[NPW];
     // pieces wave + 4 i with i < XPW are X rows for EVERY wave (the X pieces split evenly over the waves): which operand
     // a piece belongs to is a compile-time property of i, so its descriptor is too
-    static_assert((BM / RPP) % 4 == 0, "X pieces must split evenly over the 4 waves");
-    constexpr int XPW = BM / RPP / 4;
+    static_assert((BM / RPP) % NWV == 0, "X pieces must split evenly over the waves");
+    constexpr int XPW = BM / RPP / NWV;
     const int pl_x = (int)(unsigned)(a.x_lo * 2), pl_w = (int)(unsigned)(a.w_lo * 2);   // FMT_SPLIT: lo-plane byte offsets
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-        const int p = wave + 4 * i;
+        const int p = wave + NWV * i;
         const bool isx_i = i < XPW;
         const int r = (isx_i ? p : p - BM / RPP) * RPP + srow;   // tile-local row
         // source chunk landing at LDS position spos (bank swizzle through the source address)
@@ -241,7 +246,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
     if constexpr (EPI == EPI_QK || EPI == EPI_PROJ) {
         // measured A/B (MI355X): the LDS-staged, line-coalesced epilogue wins for the scattered head-major /
         // dual-output epilogues (+7 % qk, +40 % proj) and is neutral-to-slightly-negative for the others
-        static_assert(4 * StagedEpi<FN, EPI>::BYTES <= NSTAGE * STAGE, "epilogue staging must fit the ring");
+        static_assert(NWV * StagedEpi<FN, EPI>::BYTES <= NSTAGE * STAGE, "epilogue staging must fit the ring");
         __builtin_amdgcn_s_barrier();                 // every wave is done reading operand tiles
         char* my = smem + wave * StagedEpi<FN, EPI>::BYTES;
         epilogue_staged<FM, FN, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 32 * FN, my, lane);
@@ -255,25 +260,25 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const int tile
 // in-flight batch (a different kernel, in a different phase) can take the second one: its K loop then runs
 // under this launch's HBM-bound epilogue and vice versa, instead of two workgroups of the SAME launch hitting
 // their epilogues together.
-template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT, int FMT>
-__global__ __launch_bounds__(256, MINB) void gemm_bf16_kernel(const GemmArgs a) {
+template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT, int FMT, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
-    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     const int ntiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        gemm_bf16_tile<FM, FN, BK, NSTAGE, PRIO, EPI, ACT, FMT>(a, tile, smem);
+        gemm_bf16_tile<FM, FN, BK, NSTAGE, PRIO, EPI, ACT, FMT, WM, WN>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) __builtin_amdgcn_s_barrier();   // LDS (operand ring / epilogue staging) is reused
     }
 }
 
-template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT, int FMT>
+template <int FM, int FN, int BK, int NSTAGE, int MINB, bool PRIO, int EPI, int ACT, int FMT, int WM = 2, int WN = 2>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
-    constexpr int BM = 64 * FM, BN = 64 * FN;
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDS = NSTAGE * (BM + BN) * BK * 2;
     if (a.K % BK != 0) { syl_set_error("launch_gemm_bf16", "K must be a multiple of the K step"); return 1; }
     const int tiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static PerDeviceOnce attr_once;
-    auto kern = gemm_bf16_kernel<FM, FN, BK, NSTAGE, MINB, PRIO, EPI, ACT, FMT>;
+    auto kern = gemm_bf16_kernel<FM, FN, BK, NSTAGE, MINB, PRIO, EPI, ACT, FMT, WM, WN>;
     if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
@@ -282,7 +287,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     int grid = tiles;
     const int per_cu = a.tune_persist > 0 ? a.tune_persist : (a.tune_persist == 0 ? MINB : 0);
     if (per_cu > 0 && tiles > per_cu * 256) grid = per_cu * 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -872,6 +877,11 @@ static int launch_cfg8p(const GemmArgs& a, hipStream_t s) {
 #ifndef GEMM_SOLO_EFF
 #define GEMM_SOLO_EFF 0.60          // a 2-per-CU tile alone on its CU, relative to its rated efficiency (measured: a lone 128x192x3072 tile 66 us, two co-resident 80 us)
 #endif
+#ifndef GEMM_LONE_ROUND
+#define GEMM_LONE_ROUND 0.90        // a launch of FEWER tiles than CUs on the one-per-CU persistent tiles: every tile runs alone on its CU for about a full round's time, however few
+                                    // there are (B = 1: FFN1 as 36 tiles of 192x256 = 19.5-21 us against 10.3 us on 96 tiles of 128x128; profiles/r06_small_tiles.md) -- the
+                                    // partial-round rule below (fitted to launches of one round and more) priced it at 0.48 and sent every GEMM of a single-clip call to the big tiles
+#endif
 #ifndef GEMM_SPLIT_US
 #define GEMM_SPLIT_US 4.0           // what the second launch of a split costs (dispatch gap + a second prologue)
 #endif
@@ -901,6 +911,13 @@ static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
     switch (cfg) {
         case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT, FMT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
         case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);   // 128x128, 2 WG/CU
+        // (the projection's dual-output fp32 staging does not fit eight private regions into the two-slot ring: it keeps the four-wave forms)
+        case 5:
+            if constexpr (EPI == EPI_PROJ) return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);
+            else return launch_cfg<1, 2, 64, 2, 2, false, EPI, ACT, FMT, 4, 2>(a, s);   // 128x128 on EIGHT waves (4 x 2, wave tile 32x64), 2 WG/CU
+        case 6:
+            if constexpr (EPI == EPI_PROJ) return launch_cfg<2, 3, 64, 2, 2, false, EPI, ACT, FMT>(a, s);
+            else return launch_cfg<1, 3, 64, 2, 2, false, EPI, ACT, FMT, 4, 2>(a, s);   // 128x192 on eight waves (wave tile 32x96), 2 WG/CU
         case 10:
             if constexpr (EPI == EPI_BF16) {
                 // whole tiles, more than one round, at least 3 K steps: the persistent kernel with cross-tile prefetch
@@ -909,7 +926,7 @@ static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
             }
             return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
-        case 13: case 14: case 46: case 47:
+        case 13: case 14: case 15: case 16: case 46: case 47:
             // the v_mfma_f32_16x16x32 family (gemm_asm16.hip): the 16-bit-output launches by default (launch_f), any instantiated epilogue when forced
             if (gemm_asm16_has_tile(EPI, a, cfg)) { GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm16(EPI, b, s); }
             break;
@@ -997,10 +1014,12 @@ struct TileModel {
         // tile 97's geometry, 46 = its 192-row sibling.  The family adds 32-k blocks to an element's fp32 chain where the 32x32x16 kernels add 16-k
         // blocks, so the ROLE moves as a whole: every tile a batch shape can pick for these launches is a member, and results stay independent of
         // the batch shape.  tune_mfma16 = -1 (SYLBER_OPT_GEMM_MFMA16) puts the role back on the 32x32x16 kernels.
-        m16 = EPI == EPI_BF16 && FMT != FMT_SPLIT && (a.act == 0 || a.act == 1) && a.tune_mfma16 >= 0 && gemm_asm16_has_tile(EPI, a, 14);
+        m16 = EPI == EPI_BF16 && FMT != FMT_SPLIT && (a.act == 0 || a.act == 1) && a.tune_mfma16 >= 0 && gemm_asm16_has_tile(EPI, a, 15);
         if (m16) {
-            // (14 rated below 13: on the role's shapes -- N = 512 / 3072, both whole in 128 and 192 columns -- the 128x128 kernel measured 8-25 % faster wherever a small tile is the pick)
-            const TileCfg fam[4] = {{13, 128, 128, 2, r5 ? 0.93 : 0.95, p2}, {14, 128, 192, 2, 0.88, p2}, {47, 256, 256, 1, long_k ? 1.32 : 1.27, pa},
+            // small tiles: 15 = the 128x128 tile on EIGHT waves (+3 ... +21 % over its four-wave form 13 on every shape of the role: a 16-cycle-MFMA loop is bound by
+            // what one wave has to issue, profiles/r06_small_tiles.md); 14 = 128x192 on four waves, rated below it (it wins only where 512 of its tiles are exactly
+            // one round: 8 clips).  13 and 16 (128x192 on eight waves: 136 VGPRs, one workgroup per CU) stay forced-only members.
+            const TileCfg fam[4] = {{15, 128, 128, 2, 1.00, p2}, {14, 128, 192, 2, 0.88, p2}, {47, 256, 256, 1, long_k ? 1.32 : 1.27, pa},
                                     {46, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa}};
             for (int i = 0; i < NCFG; ++i) cfgs[i] = i < 4 ? fam[i] : TileCfg{-1, 256, 256, 1, 1.0, 1.0};
         }
@@ -1011,13 +1030,15 @@ struct TileModel {
         const GemmArgs& a = *this->a;
         int m;
         switch (cfg) {
-            case 13: case 14: case 46: case 47: m = cfg; break;
-            case 3: m = 13; break;
+            case 13: case 14: case 15: case 16: case 46: case 47: m = cfg; break;
+            case 3: case 5: m = 15; break;
+            case 6: m = 16; break;
             case 51: case 57: m = 46; break;
             case 10: case 30: case 40: case 41: case 60: case 80: case 85: case 95: case 97: case 98: m = 47; break;
-            default: m = 14; break;
+            case 4: case 11: case 90: case 91: case 96: case 0: case 86: m = 14; break;
+            default: m = 15; break;
         }
-        return gemm_asm16_has_tile(EPI, a, m) ? m : 14;
+        return gemm_asm16_has_tile(EPI, a, m) ? m : 15;
     }
     double cost_of(int i, long rows) const {
         const GemmArgs& a = *this->a;
@@ -1036,6 +1057,7 @@ struct TileModel {
             // its prologue / epilogue), GEMM_SOLO_EFF of the paired rate
             if (!r5 && c.per_cu == 2 && full == 0 && rem <= 256) rounds = 0.5 / GEMM_SOLO_EFF;
             else rounds += c.pr0 + (1.0 - c.pr0) * (double)rem / (double)slots;
+            if (full == 0 && c.per_cu == 1 && a.tune_model != 6 && rounds < GEMM_LONE_ROUND) rounds = GEMM_LONE_ROUND;   // (tune_model 6 = model 0 without this rule: A/B)
         }
         return rounds * c.per_cu * c.bm * c.bn / c.eff;
 

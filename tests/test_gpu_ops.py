@@ -91,7 +91,7 @@ def test_attention(lib, B, T, valid, qw):
     assert (o.cpu() - ref).pow(2).mean().sqrt().item() < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 3, 4, 10, 11, 40, 51, 57, 60, 80, 85, 90, 91, 95, 97])
+@pytest.mark.parametrize("cfg", [0, 3, 4, 5, 6, 10, 11, 40, 51, 57, 60, 80, 85, 90, 91, 95, 97])
 def test_linear_every_tile_config(lib, cfg):
     """every GEMM tile configuration (4-wave 2/3-slot rings, 8-wave staggered big tiles) gives the same
     result, including ragged M / N tails and a strided (overlapping-row) activation operand"""
@@ -129,7 +129,7 @@ def test_linear_split16(lib, cfg):
         assert err < 12 * (f32 - ref).abs().max().item() + 2e-6, (cfg, M, N, K)     # fp32 accumulation noise (a longer serial chain than the CPU's blocked sums)
 
 
-@pytest.mark.parametrize("cfg", [40, 51, 57, 60, 80, 85, 90, 91, 95, 97])
+@pytest.mark.parametrize("cfg", [3, 4, 5, 6, 40, 51, 57, 60, 80, 85, 90, 91, 95, 97])
 def test_gemm8_schedule_variants_bitwise(lib, cfg):
     """the K-loop schedule variants of the 8-wave kernel (where the LDS-DMA of step s+3 is issued) contract in the same
     order: bit-identical to the default schedule on a full-size launch, run to run (a hand-off race would show here)"""
@@ -218,10 +218,13 @@ def test_conv3_layer_every_tile(lib):
         xd = x.cuda()
         wc = w.contiguous()
         outs = {}
-        for tile in (9010, 97, 3, 4, 11, 40, 85, -1):
+        # (tile + 1000000 = the 32x32x16 kernels this test was written for: since round 6 a 16-bit-output launch maps a forced id into the 16x16x32
+        #  family, whose own sweep is test_mfma16_role_16bit_outputs; 1000999 = their automatic tile)
+        L = 1000000
+        for tile in (L + 9010, L + 97, L + 3, L + 4, L + 5, L + 6, L + 11, L + 40, L + 85, L + 999):
             y = torch.full((M, 512), -1, dtype=torch.int16, device="cuda")
             _lib.check(lib.sylber_op_conv3(_p(xd), ctypes.c_void_p(wc.data_ptr()), _p(y), R, M, tile, None), "op_conv3")
-            outs[tile] = y
+            outs[tile - L] = y
             assert torch.equal(y, outs[9010]), (M, tile)
         rows = torch.randint(0, M, (256,))
         got = outs[97][rows.cuda()].view(torch.bfloat16).float().cpu()
@@ -244,7 +247,7 @@ def test_mfma16_family(lib):
         b = torch.randn(N, generator=g)
         ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
         outs = {}
-        for cfg in (47, 97, 46, 13, 14, 47, 9047):
+        for cfg in (47, 97, 46, 13, 14, 15, 16, 47, 9047):
             if K < 256 and cfg in (46, 47, 97, 9047):
                 continue                                     # the generated loops need four K steps; the small tiles take any K % 64 == 0
             c = torch.full((M, N), float("nan"), device="cuda")
@@ -270,15 +273,15 @@ def test_mfma16_role_16bit_outputs(lib):
     outputs differ from the family's by at most one rounding step of the stored format on a small fraction of the elements"""
     from sylber_amd import _lib
     g = torch.Generator().manual_seed(48)
-    for (M, N, K) in [(16384, 3072, 768), (1000, 512, 1024), (24064, 3072, 768)]:
+    for (M, N, K) in [(16384, 3072, 768), (1000, 512, 1024), (24064, 3072, 768), (6437, 3072, 768), (256 * 90, 1024, 512)]:     # (persistent seams, whole and ragged)
         a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
         ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
         outs = {}
-        for tile in (-1, 47, 46, 13, 14, 97, 57, 3, 4, 10, 85, 91, 1000097, 1000004, 1000999):
+        for tile in (-1, 47, 46, 13, 14, 15, 16, 97, 57, 3, 4, 10, 85, 91, 1000097, 1000004, 1000999):
             c = torch.full((M, N), -1, dtype=torch.int16, device="cuda")
             _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 1, 0, tile, None), "op_linear16")
             outs[tile] = c
-        for tile in (47, 46, 13, 14, 97, 57, 3, 4, 10, 85, 91):
+        for tile in (47, 46, 13, 14, 15, 16, 97, 57, 3, 4, 10, 85, 91):
             assert torch.equal(outs[tile], outs[-1]), (tile, M, N, K)
         assert torch.equal(outs[1000097], outs[1000004]) and torch.equal(outs[1000097], outs[1000999]), (M, N, K)
         f, l = outs[-1].view(torch.bfloat16).float(), outs[1000097].view(torch.bfloat16).float()
@@ -294,7 +297,7 @@ def test_mfma16_role_16bit_outputs(lib):
         xd = x.cuda()
         wc = w.contiguous()
         ys = {}
-        for tile in (-1, 47, 13, 14, 1000097):
+        for tile in (-1, 47, 13, 14, 15, 16, 1000097):
             y = torch.full((M, 512), -1, dtype=torch.int16, device="cuda")
             _lib.check(lib.sylber_op_conv3(_p(xd), ctypes.c_void_p(wc.data_ptr()), _p(y), R, M, tile, None), "op_conv3")
             ys[tile] = y
@@ -309,7 +312,7 @@ def test_mfma16_role_16bit_outputs(lib):
         assert (got - ref).abs().max().item() < 2e-2 and (got - ref).pow(2).mean().sqrt().item() < 3e-3, M
 
 
-@pytest.mark.parametrize("tile", [4, 51, 90, 91, 96])
+@pytest.mark.parametrize("tile", [4, 5, 6, 51, 90, 91, 96])
 def test_residual_gemm_tiles(lib, tile):
     """the residual GEMM of an encoder block (out-projection K = 768, FFN2 K = 3072: EPI_F32_RESLN, in place) against torch, and
     bit for bit against the HIP-scheduled 128x192 kernel -- tile 91 with whole tiles runs the K loop that also prefetches the
@@ -344,10 +347,11 @@ def test_asm_tiles_persistent_seams(lib, tile):
         a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
         ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
         ref = torch.full((M, N), -1, dtype=torch.int16, device="cuda")
-        _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(ref), M, N, K, act, 0, 9010, None), "op_linear16")
+        # (+ 1000000: on the 32x32x16 kernels -- a 16-bit-output launch otherwise maps the forced id into the 16x16x32 family, test_mfma16_role_16bit_outputs)
+        _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(ref), M, N, K, act, 0, 1009010, None), "op_linear16")
         for _ in range(3):
             c = torch.full((M, N), -1, dtype=torch.int16, device="cuda")
-            _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, act, 0, tile, None), "op_linear16")
+            _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, act, 0, 1000000 + tile, None), "op_linear16")
             assert torch.equal(c, ref), (tile, M, N, K)
 
 

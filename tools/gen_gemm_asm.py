@@ -609,7 +609,7 @@ def y3_step(rq, par, tail_w, x_next, head, vm, nxt=True, first=False):
     n_mf = GX * GW
     XT = Y3["xt"]
     L = [q(f"; ---- Y3 step parity {par}: tail_w {int(tail_w)} x_next {int(x_next)} head {int(head)} vmcnt {vm}")]
-    nh = min(nwp - 1, (n_mf - (GB + 1) * GW) // 4)           # W pieces issued behind the barrier (one per four MFMAs)
+    nh = min(nwp - Y3.get("wtail", 1), (n_mf - (GB + 1) * GW - Y3.get("hpos", 2) + 3) // 4)   # W pieces issued behind the barrier (one per four MFMAs); the rest in the next step's slice 0
     queue = []
     if tail_w:
         queue += [y3_dma_w(i, par ^ 1) for i in range(nxp + nh, nxp + nwp)]
@@ -695,6 +695,7 @@ def emit_y3(fn=2, nw=8, tap=False, fm=4, gb=3):
     Y3["dstride"] = int(os.environ.get("Y3_DSTRIDE", 4))
     Y3["dpos"] = int(os.environ.get("Y3_DPOS", 2))
     Y3["hpos"] = int(os.environ.get("Y3_HPOS", 2))
+    Y3["wtail"] = int(os.environ.get("Y3_WTAIL", 1))          # W pieces of step j+1 left for slice 0 of step j (0: all of them behind the barrier of step j-1)
     bn = 64 * fn if nw == 4 else 128 * fn
     Y3.update({"fn": fn, "nw": nw, "bn": bn, "tap": tap, "fm": fm, "xt": 64 * fm * 128, "gb": gb})
     GX, GW = 2 * fm, 2 * fn
