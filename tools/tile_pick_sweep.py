@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--shapes", default="8x60,24x10,48x10,32x15,24x15,16x30,32x10")
     ap.add_argument("--tiles", default="-1,91,51,97,57,85,10,4,3")
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--convs", action="store_true", help="also the 3-tap conv layers (conv1-4)")
     args = ap.parse_args()
     import torch
     from sylber_amd import HubertEncoderHIP
@@ -23,6 +24,8 @@ def main():
     from sylber_amd.weights import synthetic_state_dict
     sd = synthetic_state_dict(0)
     keys = ("gemm_conv5", "gemm_conv6", "gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2")
+    if args.convs:
+        keys = ("gemm_conv1", "gemm_conv2", "gemm_conv3", "gemm_conv4") + keys
     tiles = [int(t) for t in args.tiles.split(",")]
     print("ms per forward of each launch group (sequential profile), one tile id forced on every GEMM launch that has it (`auto` = the cost model); "
           "`*` = the fastest forced tile of the column")
