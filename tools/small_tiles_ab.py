@@ -9,6 +9,8 @@ from sylber_amd import _lib
 
 lib = _lib.load()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+ALT = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else None      # other id quadruple for the 32x32x16 rows, e.g. 3,7,4,8 (three-slot rings)
+ALTF = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None     # the same for the family's FFN1 rows
 LAUNCHES = [("q,k,v", 2304, 768, 3, 0), ("out-proj", 768, 768, 6, 0), ("FFN2", 768, 3072, 6, 0), ("FFN1", 3072, 768, 0, 1)]
 
 
@@ -18,11 +20,11 @@ def run(m, n, k, epi, act, cfg):
     return ms.value * 1e3
 
 
-print("| launch | clips | M x N x K | 128x128: 4 waves us | 8 waves us | gain | 128x192: 4 waves us | 8 waves us | gain | best of the four |")
+print("| launch | clips | M x N x K | 128x128: first us | second us | gain | 128x192: first us | second us | gain | best of the four |")
 print("|---|---:|---|---:|---:|---:|---:|---:|---:|---|")
 for name, n, k, epi, act in LAUNCHES:
     fam = epi == 0
-    ids = (13, 15, 14, 16) if fam else (3, 5, 4, 6)
+    ids = (tuple(ALTF) if ALTF else (13, 15, 14, 16)) if fam else (tuple(ALT) if ALT else (3, 5, 4, 6))
     for clips in (1, 2, 4, 8, 16, 32):
         m = clips * 512
         t = {c: [] for c in ids}
