@@ -941,7 +941,19 @@ def main():
             t_lean.append(time.perf_counter() - t0)
         dt_lean = statistics.median(t_lean)
         del lean
+        # the reference's own example: ONE clip through the synchronous call (BASELINE configs[0]'s shape, on the GPU): latency, not throughput
+        for _ in range(3):
+            seg_api(wav=host_wavs[0], in_second=True)
+        t_one = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            seg_api(wav=host_wavs[0], in_second=True)
+            t_one.append(time.perf_counter() - t0)
+        dt_one = statistics.median(t_one)
         api = {"value": round(B * clip_seconds / dt, 1), "unit": "audio-sec/s", "ms_per_call": round(dt * 1e3, 2),
+               "single_clip": {"ms_per_call": round(dt_one * 1e3, 3), "ms_min": round(min(t_one) * 1e3, 3), "value": round(clip_seconds / dt_one, 1), "unit": "audio-sec/s",
+                               "what": "Segmenter.__call__(wav=one %g s host tensor) -> dict: the reference's README usage; every GEMM of it is a launch of fewer tiles than CUs "
+                                       "(small two-per-CU tiles, the 16-bit-output ones on eight waves; profiles/r06_small_tiles.md); 30 back-to-back calls" % clip_seconds},
                "without_hidden_states": {"value": round(B * clip_seconds / dt_lean, 1), "unit": "audio-sec/s", "ms_per_call": round(dt_lean * 1e3, 2),
                                          "what": "the same call with Segmenter(outputs=('segments', 'segment_features')): opt-in, the default returns the reference's three keys"},
                "stream": {"value": round(B * clip_seconds / dt_stream, 1), "unit": "audio-sec/s", "ms_per_batch": round(dt_stream * 1e3, 2),
@@ -992,12 +1004,16 @@ def main():
             import ctypes as _ct
             from sylber_amd import _lib as _l
             torch.cuda.synchronize(dev)
-            ms_ = _ct.c_float()
-            _l.check(_l.load().sylber_debug_gemm_bench(4096, 4096, 4096, 4096, 0, 0, -1, 30, _ct.byref(ms_)), "gemm_bench")
+            ms_, ms47_ = _ct.c_float(), _ct.c_float()
+            # the yardstick stays the kernel it has been since round 5 (tile 97: cfg + 1000000 keeps a 16-bit-output launch on the 32x32x16 kernels);
+            # the same launch on the tile the library picks by itself since round 6 (47: the same geometry on v_mfma_f32_16x16x32) is reported beside it
+            _l.check(_l.load().sylber_debug_gemm_bench(4096, 4096, 4096, 4096, 0, 0, 1000097, 30, _ct.byref(ms_)), "gemm_bench")
+            _l.check(_l.load().sylber_debug_gemm_bench(4096, 4096, 4096, 4096, 0, 0, -1, 30, _ct.byref(ms47_)), "gemm_bench")
             box_speed = {"gemm_4096_cubed_tflops": round(2.0 * 4096 ** 3 / (ms_.value * 1e-3) / 1e12, 1), "us_per_launch": round(ms_.value * 1e3, 1),
-                         "what": "30 back-to-back launches of this library's 4096^3 bf16 GEMM (plain 16-bit epilogue, hot operands, automatic tile) right "
-                                 "after the measurements above: the same kernel family as 55 % of the step, one fixed shape -- a per-box yardstick "
-                                 "(round-5/6 boxes: 1290-1345 TF)"}
+                         "automatic_tile_tflops": round(2.0 * 4096 ** 3 / (ms47_.value * 1e-3) / 1e12, 1),
+                         "what": "30 back-to-back launches of this library's 4096^3 bf16 GEMM on tile 97 (plain 16-bit epilogue, hot operands; the 32x32x16 "
+                                 "kernel of rounds 3-6a, kept as THE per-box yardstick: round-5/6 boxes read 1290-1345 TF) right after the measurements above; "
+                                 "automatic_tile_tflops = the same launch as the library runs it now (tile 47, v_mfma_f32_16x16x32)"}
         except Exception as e:  # noqa: BLE001
             box_speed = {"error": "%s: %s" % (type(e).__name__, e)}
 

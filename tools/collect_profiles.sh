@@ -23,6 +23,8 @@ python tools/gemm_bench.py -1,4,91,97 > $OUT/gemm_bench.txt 2>&1
 python tools/blaslt_yardstick.py > $OUT/yardstick_hipblaslt.md 2>&1
 python tools/mfma16_ab.py 3 > $OUT/mfma16_ab.md 2>&1
 bash tools/mfma16_forward_ab.sh 2 > $OUT/mfma16_forward_ab.txt 2>&1
+python tools/small_batch_ab.py > $OUT/small_batch_ab.md 2>&1
+python tools/small_tiles_ab.py 3 > $OUT/small_tiles_ab.md 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-other-configs > $OUT/trace_pipelined.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sequential -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-api --no-other-configs --no-overlap > $OUT/trace_sequential.log 2>&1
