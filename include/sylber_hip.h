@@ -169,7 +169,11 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      hand-scheduled K loops (csrc/gemm_asm.hip; a launch whose epilogue / K has no such
  *                                      instantiation falls back to 128x192): 80 = 256x256 4-wave, 90 = 256x192, 95 = 256x256
  *                                      8-wave, 85 / 91 / 97 = the same with a three-slot X ring, 51 / 57 = 91 / 97 on 192-row tiles, 86 = that ring on a 256x128 tile / four waves (91 also requests the fp32 residual rows of out-proj / FFN2 from
- *                                      inside its K loop when the launch has whole tiles; 96 = 91 without that), 60 = the 64-byte-row first cut)
+ *                                      inside its K loop when the launch has whole tiles; 96 = 91 without that), 60 = the 64-byte-row first cut;
+ *                                      round 6: 5 / 6 = 128x128 / 128x192 on EIGHT waves (same bits; measured no gain for these kernels, forced only);
+ *                                      the v_mfma_f32_16x16x32 family (csrc/gemm_asm16.hip; 16-bit-output and plain fp32 epilogues): 47 = tile 97's geometry, 46 = its 192-row
+ *                                      sibling, 13 / 14 = 128x128 / 128x192 hipcc-scheduled on four waves, 15 / 16 = the same on eight waves.  On a 16-bit-output launch
+ *                                      (conv1-5, FFN1) ANY forced id runs on the family member of the same shape class unless SYLBER_OPT_GEMM_MFMA16 = -1)
  *   SYLBER_OPT_ATTN_QUERIES_PER_WAVE   0 (default): the hand-scheduled key loop (csrc/attention.hip attention_asm_kernel, generated by
  *                                      tools/gen_attn_asm.py; bf16 / fp16 modes); 32 or 64: the compiler-scheduled kernels with that many
  *                                      queries per wave (its reference; split16 always runs the 32-query one)
@@ -208,6 +212,8 @@ int sylber_condition(sylber_mlp_t m, const float* hidden_dev, const int64_t* seg
  *                                      pipeline, ShardedSegmenter's two engines): the CUs a partial round leaves idle go to the other stream's
  *                                      kernels, whole-round accounting with the round-5 constants measured fastest there (8 x 60 s: 8.57 vs 8.78 ms
  *                                      per step; alone on the chip the same handle is 5 % slower with it).  Outputs are bit-identical either way.
+ *                                      (6 = 0 without the lone-round rule of round 6 -- a launch of fewer tiles than CUs on the one-per-CU persistent tiles costs a full round --
+ *                                      i.e. the tile choice of rounds 5-6a for small batches: A/B switch.)
  *   SYLBER_OPT_SEGMENT                 0 (default): sylber_segment as wide kernels -- frame norms, one workgroup per unbroken run of speech frames
  *                                      (independent instances of get_segment's two phases), compaction, pooling one wave per segment, all on all
  *                                      CUs; -1: one workgroup per utterance (rounds 1-5; bit-identical, A/B switch and reference)
