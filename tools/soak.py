@@ -1,6 +1,7 @@
 """soak: N pipelined steps (two handles, probed streams, boundary detection on side streams, as bench.py runs them) with EVERY
 step's hidden states, segment tables, counts and pooled features compared bit for bit against the first step's -- rare races
-(LDS-DMA hazards, stream ordering, workspace aliasing) would show up as a mismatch.   python tools/soak.py [steps] [precision]"""
+(LDS-DMA hazards, stream ordering, workspace aliasing) would show up as a mismatch.   python tools/soak.py [steps] [precision] [clips = 32]
+(24 clips: FFN1 / conv5 on the 192-row tile 46; 4 clips: the eight-wave small tiles)"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,7 @@ from sylber_amd.weights import synthetic_state_dict
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 sd = synthetic_state_dict(0)
-B, N = 32, 160000
+B, N = (int(sys.argv[3]) if len(sys.argv) > 3 else 32), 160000
 x = torch.cat([syllable_wave(N, 500 + i) for i in range(B)], 0).cuda()
 lens = [N - 3000 * (i % 5) for i in range(B)]
 encs = [HubertEncoderHIP(sd, precision=prec) for _ in range(2)]
