@@ -910,6 +910,11 @@ static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
     } else
     switch (cfg) {
         case 0: return launch_cfg<4, 2, 64, 3, 1, false, EPI, ACT, FMT>(a, s);   // 256x128, 3-slot ring, 1 WG/CU
+        // round 6: the launches of a call on one or two clips are chains of K steps on a few LONE workgroups (fewer tiles than CUs), each step waiting for LDS-DMA pieces
+        // issued half a step earlier.  64-row tiles put four times the workgroups on the idle CUs, and a THREE-slot ring lets a step's pieces be one and a half steps old:
+        // out-proj of one clip 12.5 -> 7.0 us, FFN2 25.5 -> 18.5, q,k,v 9.4 -> 7.9 (profiles/r06_small_tiles.md).  Same chain per output element: bit-identical.
+        case 1: return launch_cfg<1, 1, 64, 3, 2, false, EPI, ACT, FMT>(a, s);   // 64x64, three-slot ring, 2+ WG/CU
+        case 2: return launch_cfg<1, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);   // 64x128, two-slot ring
         case 3: return launch_cfg<2, 2, 64, 2, 2, false, EPI, ACT, FMT>(a, s);   // 128x128, 2 WG/CU
         // (the projection's dual-output fp32 staging does not fit eight private regions into the two-slot ring: it keeps the four-wave forms)
         case 5:
@@ -964,9 +969,9 @@ static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
 // configuration i over `rows` rows of launch `a`, for epilogue EPI and operand format FMT.
 struct TileCfg { int id, bm, bn, per_cu; double eff, pr0; };
 struct TileModel {
-    static constexpr int NCFG = 9;
+    static constexpr int NCFG = 11;
     TileCfg cfgs[NCFG];
-    bool asm_ok, r5, m16;
+    bool asm_ok, r5, m16, split;
     int EPI;
     const GemmArgs* a;
     TileModel(int EPI_, int FMT, const GemmArgs& a_) : EPI(EPI_), a(&a_) {
@@ -974,6 +979,7 @@ struct TileModel {
         // 80 / 90: the hand-scheduled 4-wave kernels (gemm_asm.hip).  Their K loop runs ~25 % above the 8-wave kernel's, but one
         // wave per SIMD leaves a tile's prologue and epilogue uncovered (~9 us + ~5 us of GELU against a 17 us K = 768 loop), so
         // they are rated for long K only (same-box tools/gemm_bench.py: conv1-4 +3-10 %, FFN2 +7 %, K = 768 shapes -5-20 %).
+        split = FMT == FMT_SPLIT;
         asm_ok = FMT != FMT_SPLIT && gemm_asm_applicable(EPI, a) && a.K >= 256;
         const bool long_k = a.K >= 1024;
         // 95: the same loop on eight waves (two per SIMD share the epilogue's VALU work): the GELU GEMMs, K = 768 included.
@@ -1007,7 +1013,10 @@ struct TileModel {
                                 {x3 ? 85 : 80, 256, 256, 1, long_k ? (r5 ? 1.28 : 1.20) : (!r5 && EPI == EPI_QK ? 1.00 : 1.10), pa},   // (q,k,v on 85: 0.795 vs 0.691 ms on 128x192 at 24 x 15 s)
                                 {91, 256, 192, 1, long_k ? 1.10 : 1.04, pa},
                                 {x3 ? 97 : 95, 256, 256, 1, long_k ? 1.32 : 1.27, pa}, {86, 256, 128, 1, 1.10, pa},
-                                {51, 192, 192, 1, (long_k ? 1.10 : 1.04) * GEMM_H192_EFF, pa}, {57, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa}};
+                                {51, 192, 192, 1, (long_k ? 1.10 : 1.04) * GEMM_H192_EFF, pa}, {57, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa},
+                                // 64-row tiles (round 6): a quarter / half of the 128x128 tile per workgroup at 0.34 / 0.50 of its per-output efficiency -- they only ever win where a
+                                // launch has fewer tiles than the chip has workgroup slots (one to four clips), which is what they exist for (fitted: profiles/r06_small_tiles.md §3)
+                                {1, 64, 64, 2, 0.34, p2}, {2, 64, 128, 2, 0.50, p2}};
         for (int i = 0; i < NCFG; ++i) cfgs[i] = init[i];
         // The 16-bit-output GEMMs (EPI_BF16, plain or GELU: conv1-5 and FFN1, 46 % of the 32 x 10 s forward) run on the v_mfma_f32_16x16x32 FAMILY
         // (gemm_asm16.hip; same-box +2.7 ... +7.2 % per launch, profiles/r06_mfma16_loop.md): 13 / 14 = the two-per-CU 128x128 / 128x192 kernels, 47 =
@@ -1031,7 +1040,7 @@ struct TileModel {
         int m;
         switch (cfg) {
             case 13: case 14: case 15: case 16: case 46: case 47: m = cfg; break;
-            case 3: case 5: m = 15; break;
+            case 1: case 2: case 3: case 5: m = 15; break;
             case 6: m = 16; break;
             case 51: case 57: m = 46; break;
             case 10: case 30: case 40: case 41: case 60: case 80: case 85: case 95: case 97: case 98: m = 47; break;
@@ -1045,6 +1054,7 @@ struct TileModel {
         const TileCfg& c = cfgs[i];
         if (c.id < 0) return 1e300;
         if (m16) { if (!gemm_asm16_has_tile(EPI, a, c.id)) return 1e300; }
+        else if (c.id == 1 || c.id == 2) { if (split || a.tune_model == 6) return 1e300; }    // (the split16 mode instantiates three tile shapes; model 6 = the round-6a choice, A/B)
         else if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, c.id))) return 1e300;   // only tiles that exist for this epilogue / format
         if ((c.id == 51 || c.id == 57 || c.id == 46) && (a.tune_h192 < 0 || r5)) return 1e300;
         const long tm = (rows + c.bm - 1) / c.bm, tn = (a.N + c.bn - 1) / c.bn;

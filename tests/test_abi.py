@@ -123,13 +123,17 @@ def test_gemm_tile_cost_model_picks():
     assert pick(ML, 2304, 768, QK, 0, 0, 0, 0) == 4
     # 24 x 10 s (48 row tiles): 64 row tiles of 192 = exactly one round
     assert pick(24 * 512, 768, 3072, RESLN, 0, 0, 0, 0) == 51 and pick(24 * 512, 3072, 768, BF16, GELU, 0, 0, 0) == 46 and pick(24 * 512, 3072, 768, BF16, GELU, 0, 100, 0) == 57
+    # small batches: 64-row tiles for the launches of one or two clips (fewer tiles than workgroup slots), not beyond (model + 6 = the round-6a choice)
+    assert pick(512, 768, 3072, RESLN, 0, 0, 0, 0) == 1 and pick(512, 768, 768, RESLN, 0, 0, 0, 0) == 1 and pick(512, 2304, 768, QK, 0, 0, 0, 0) == 1
+    assert pick(1024, 2304, 768, QK, 0, 0, 0, 0) == 2 and pick(2048, 768, 3072, RESLN, 0, 0, 0, 0) == 1 and pick(2048, 2304, 768, QK, 0, 0, 0, 0) == 3
+    assert pick(512, 768, 3072, RESLN, 0, 0, 6, 0) == 51 and pick(8192, 768, 3072, RESLN, 0, 0, 0, 0) == 3
     # small batches of the 16-bit-output role: the 128x128 tile on eight waves
-    assert pick(512, 3072, 768, BF16, GELU, 0, 0, 0) == 15 and pick(2048, 512, 1536, BF16, GELU, 0, 0, 1) == 15 and pick(512, 3072, 768, BF16, GELU, 0, 100, 0) in (3, 4)
+    assert pick(512, 3072, 768, BF16, GELU, 0, 0, 0) == 15 and pick(2048, 512, 1536, BF16, GELU, 0, 0, 1) == 15 and pick(512, 3072, 768, BF16, GELU, 0, 100, 0) in (1, 2, 3, 4)
     # fp16 has the same tiles for the epilogues its forward launches
     assert pick(M, 768, 3072, RESLN, 0, 1, 0, 0) == 91 and pick(ML, 768, 3072, RESLN, 0, 1, 0, 0) == 51
     # every answer is a tile id that exists
     for m in (256, 1000, 6144, 12288, 16384, 24064, 49152):
         for (n, k, e, a) in ((2304, 768, QK, 0), (768, 768, RESLN, 0), (3072, 768, BF16, GELU), (768, 3072, RESLN, 0), (512, 1024, BF16, GELU)):
             for model in (0, 5, 100, 105):
-                ids = (14, 15, 46, 47) if (e == BF16 and model < 100) else (3, 4, 10, 85, 91, 97, 86, 51, 57, 80, 90, 95)
+                ids = (14, 15, 46, 47) if (e == BF16 and model < 100) else (1, 2, 3, 4, 10, 85, 91, 97, 86, 51, 57, 80, 90, 95)
                 assert pick(m, n, k, e, a, 0, model, 0) in ids, (m, n, k, e, model)

@@ -148,7 +148,9 @@ def test_tile_selection_options_bitwise(sd):
     for (b, n, prec) in [(24, 160000, "bf16"), (5, 481000, "bf16"), (12, 240000, "fp16")]:
         x = noise_batch(b, n, seed=600 + b).cuda()
         ref = None
-        for opts in ((), ((12, 5),), ((11, -1),), ((8, 4),), ((8, 51),), ((12, 5), (8, 3))):
+        # (round 6, second half: model 6 = the tile choice without the lone-round rule and the 64-row tiles; forced ids 1 / 2 = the 64x64 / 64x128 tiles and 5 = 128x128 on
+        #  eight waves on every launch -- on the 16-bit-output launches a forced id runs on the 16x16x32 family member of its shape class)
+        for opts in ((), ((12, 5),), ((11, -1),), ((8, 4),), ((8, 51),), ((12, 5), (8, 3)), ((12, 6),), ((1, 1),), ((1, 2),), ((1, 5),)):
             e = HubertEncoderHIP(sd, precision=prec)
             for k, v in opts:
                 e.set_option(k, v)
