@@ -304,7 +304,7 @@ __device__ __forceinline__ void epilogue_direct_m16(const GemmArgs& a, const f32
 // same chain order on twice the waves: a workgroup that is ALONE on its CU (small batches: fewer tiles than CUs) is bound by what ONE wave per SIMD has to issue per
 // K step -- eight LDS-DMA pieces at 100+ issue cycles each beside 32 sixteen-cycle MFMAs and 16 fragment reads (~2 200 cycles per K step measured against 512 of
 // MFMA time); eight waves halve every per-wave count and put two waves on each SIMD
-template <int FM, int FN, int EPI, int ACT, int FMT, int NW = 4>
+template <int FM, int FN, int EPI, int ACT, int FMT, int NW = 4, int NSTAGE = 2>
 __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, const int tile_id, char* smem) {
     constexpr int BM = 64 * FM, BN = 64 * FN, RB = 128;
     constexpr int WNN = NW / 2;                              // waves along n
@@ -385,63 +385,71 @@ __device__ __forceinline__ void gemm16_tile(const GemmArgs& a, const int tile_id
 
     stage(0, 0);
     if (nt > 1) stage(1, 1);
-    if (nt > 1) wait_vmcnt_c<NPW>(); else wait_vmcnt_c<0>();
+    if constexpr (NSTAGE == 3) { if (nt > 2) stage(2, 2); }
+    if (NSTAGE == 3 && nt > 2) wait_vmcnt_c<2 * NPW>();
+    else if (nt > 1) wait_vmcnt_c<NPW>();
+    else wait_vmcnt_c<0>();
     __builtin_amdgcn_s_barrier();
     read_frags(smem, 0, 0);
     int slot = 0;
-    // pieces [0, D0) of tile t+2 are issued behind the barrier of tile t (under the second half of its slice 1), the rest under slice 0 of tile t+1
+    // pieces [0, D0) of the next tile to request are issued behind the barrier of tile t (under the second half of its slice 1), the rest under slice 0 of tile t+1
     constexpr int D0 = (NPW * 2 + 4) / 5;
-    // one K tile.  STEADY (1 <= t <= nt - 3): every "does tile t+1 / t+2 exist" test is true, so the loop that runs nearly all tiles carries no branch
-    // around its LDS-DMA instructions (as gemm_bf16_tile); the first and the last two tiles take the general form
+    // TWO-slot ring: the tile requested is t+2 (into the slot tile t just left), waited for -- all of it -- at the barrier of tile t+1: half a K step after its
+    // last piece.  THREE-slot ring (NSTAGE = 3, round 6: the 64x64 tile of small batches): the tile requested is t+3, tile t+2 stays in flight across the barrier
+    // (counted wait), so a piece is a step and a half old when it is needed -- what a LONE workgroup, with nobody to hide the latency behind, is bound by.
+    // One K tile.  STEADY: every "does tile t+k exist" test is true, so the loop that runs nearly all tiles carries no branch around its LDS-DMA instructions
     auto ktile = [&](auto steady, int t) {
         constexpr bool STEADY = decltype(steady)::value;
+        constexpr int A = NSTAGE - 1;                        // tiles ahead: the request issued around tile t is for tile t + A (+ 1 behind the barrier)
         const char* sb = smem + slot * STAGE;
-        const int nslot = slot ^ 1;
-        const bool has_next = STEADY || t + 1 < nt, cont = STEADY || (t >= 1 && t + 1 < nt), dma2 = STEADY || t + 2 < nt;
+        const int nslot = slot == NSTAGE - 1 ? 0 : slot + 1;
+        const int rslot = NSTAGE == 2 ? nslot : (nslot == NSTAGE - 1 ? 0 : nslot + 1);      // slot of tile t + A while tile t is consumed
+        const bool has_next = STEADY || t + 1 < nt, cont = STEADY || (t >= 1 && t + A < nt), dma2 = STEADY || t + A + 1 < nt;
         SCHED_FENCE_C();
         read_frags(sb, 1, 1);
         SCHED_FENCE_C();
-        mfmas_dma(0, 0, GX, t + 1, nslot, D0, NPW, cont);
+        mfmas_dma(0, 0, GX, t + A, rslot, D0, NPW, cont);
         mfmas_dma(1, 0, GX / 2, 0, 0, 0, 0, false);
         SCHED_FENCE_C();
         if (has_next) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wait_vmcnt_c<0>();
+            if (NSTAGE == 3 && (STEADY || t + 2 < nt)) wait_vmcnt_c<NPW>();      // tile t+2 (all of it requested by now) may stay in flight
+            else wait_vmcnt_c<0>();
             __builtin_amdgcn_s_barrier();
             SCHED_FENCE_C();
             read_frags(smem + nslot * STAGE, 0, 0);
             SCHED_FENCE_C();
         }
-        mfmas_dma(1, GX / 2, GX, t + 2, slot, 0, D0, dma2);
+        mfmas_dma(1, GX / 2, GX, t + A + 1, slot, 0, D0, dma2);
         slot = nslot;
     };
     {
         int t = 0;
         if (nt > 0) ktile(std::false_type{}, t++);
-        for (; t < nt - 2; ++t) ktile(std::true_type{}, t);
+        for (; t < nt - NSTAGE; ++t) ktile(std::true_type{}, t);
         for (; t < nt; ++t) ktile(std::false_type{}, t);
     }
     epilogue_direct_m16<GX, GW, EPI, ACT, FMT>(a, acc, m0 + wm * 32 * FM, n0 + wn * 16 * GW, lane);
 }
 
-template <int FM, int FN, int EPI, int ACT, int FMT, int NW = 4>
+template <int FM, int FN, int EPI, int ACT, int FMT, int NW = 4, int NSTAGE = 2>
 __global__ __launch_bounds__(64 * NW, 2) void gemm16_bf16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int BM = 64 * FM, BN = 64 * FN;
     const int ntiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        gemm16_tile<FM, FN, EPI, ACT, FMT, NW>(a, tile, smem);
+        gemm16_tile<FM, FN, EPI, ACT, FMT, NW, NSTAGE>(a, tile, smem);
         if (tile + (int)gridDim.x < ntiles) __builtin_amdgcn_s_barrier();
     }
 }
 
-template <int FM, int FN, int EPI, int ACT, int FMT, int NW = 4>
+template <int FM, int FN, int EPI, int ACT, int FMT, int NW = 4, int NSTAGE = 2>
 static int launch_s(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * FM, BN = 64 * FN;
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int LDS = NSTAGE * (BM + BN) * 128;
     const int tiles = ((a.M - a.m_begin + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static PerDeviceOnce attr_once;
-    auto kern = gemm16_bf16_kernel<FM, FN, EPI, ACT, FMT, NW>;
+    auto kern = gemm16_bf16_kernel<FM, FN, EPI, ACT, FMT, NW, NSTAGE>;
     if (attr_once.need()) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
@@ -455,13 +463,13 @@ static int launch_s(const GemmArgs& a, hipStream_t s) {
 
 // ---- the family's dispatch ------------------------------------------------------------------------------------------------------
 bool gemm_asm16_has_tile(int epi, const GemmArgs& a, int tile) {
-    if (tile != 13 && tile != 14 && tile != 15 && tile != 16 && tile != 46 && tile != 47) return false;
+    if (tile != 13 && tile != 14 && tile != 15 && tile != 16 && tile != 17 && tile != 46 && tile != 47) return false;
     if ((epi != EPI_BF16 && epi != EPI_F32) || (a.act != 0 && a.act != 1)) return false;
     if (a.fmt != FMT_BF16 && a.fmt != FMT_F16) return false;
     if (epi == EPI_F32 && (a.fmt != FMT_BF16 || a.kpat)) return false;
     if (a.K % 64 != 0 || a.K < 64) return false;
     if (a.kpat && a.K != 1536) return false;
-    if (tile == 13 || tile == 14 || tile == 15 || tile == 16) return true;
+    if (tile == 13 || tile == 14 || tile == 15 || tile == 16 || tile == 17) return true;
     if (a.K % 128 != 0 || a.K < 256) return false;         // the generated loops: pairs of K steps, at least four
     if (tile == 46 && a.kpat) return false;
     return true;
@@ -473,6 +481,7 @@ static int launch_family(int tile, const GemmArgs& a, hipStream_t s) {
     if (tile == 14) return launch_s<2, 3, EPI, ACT, FMT>(a, s);
     if (tile == 15) return launch_s<2, 2, EPI, ACT, FMT, 8>(a, s);
     if (tile == 16) return launch_s<2, 3, EPI, ACT, FMT, 8>(a, s);
+    if (tile == 17) return launch_s<1, 1, EPI, ACT, FMT, 4, 3>(a, s);      // 64x64, three-slot ring: the launches of one or two clips (gemm_bf16.hip tile 1)
     if (tile == 46) return launch_c<EPI, ACT, FMT, false, 3>(a, s);
     if constexpr (EPI == EPI_BF16) { if (a.kpat) return launch_c<EPI, ACT, FMT, true>(a, s); }
     return launch_c<EPI, ACT, FMT, false>(a, s);

@@ -931,7 +931,7 @@ static int launch_tile(int cfg, const GemmArgs& a, hipStream_t s) {
             }
             return launch_cfg8<4, 2, 2, 4, EPI, ACT, FMT>(a, s);                 // 256x256, 8 waves staggered
         case 11: return launch_cfg8<2, 3, 4, 2, EPI, ACT, FMT>(a, s);            // 256x192, 8 waves staggered
-        case 13: case 14: case 15: case 16: case 46: case 47:
+        case 13: case 14: case 15: case 16: case 17: case 46: case 47:
             // the v_mfma_f32_16x16x32 family (gemm_asm16.hip): the 16-bit-output launches by default (launch_f), any instantiated epilogue when forced
             if (gemm_asm16_has_tile(EPI, a, cfg)) { GemmArgs b = a; b.tune_cfg = cfg + 1; return launch_gemm_asm16(EPI, b, s); }
             break;
@@ -1028,9 +1028,10 @@ struct TileModel {
             // small tiles: 15 = the 128x128 tile on EIGHT waves (+3 ... +21 % over its four-wave form 13 on every shape of the role: a 16-cycle-MFMA loop is bound by
             // what one wave has to issue, profiles/r06_small_tiles.md); 14 = 128x192 on four waves, rated below it (it wins only where 512 of its tiles are exactly
             // one round: 8 clips).  13 and 16 (128x192 on eight waves: 136 VGPRs, one workgroup per CU) stay forced-only members.
-            const TileCfg fam[4] = {{15, 128, 128, 2, 1.00, p2}, {14, 128, 192, 2, 0.88, p2}, {47, 256, 256, 1, long_k ? 1.32 : 1.27, pa},
-                                    {46, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa}};
-            for (int i = 0; i < NCFG; ++i) cfgs[i] = i < 4 ? fam[i] : TileCfg{-1, 256, 256, 1, 1.0, 1.0};
+            // 17 = 64x64 on a three-slot ring: the launches of one or two clips (the family's form of tile 1 below)
+            const TileCfg fam[5] = {{15, 128, 128, 2, 1.00, p2}, {14, 128, 192, 2, 0.88, p2}, {47, 256, 256, 1, long_k ? 1.32 : 1.27, pa},
+                                    {46, 192, 256, 1, (long_k ? 1.32 : 1.27) * GEMM_H192_EFF, pa}, {17, 64, 64, 2, 0.36, p2}};
+            for (int i = 0; i < NCFG; ++i) cfgs[i] = i < 5 ? fam[i] : TileCfg{-1, 256, 256, 1, 1.0, 1.0};
         }
     }
     // the member of the 16x16x32 family that stands in for a FORCED tile id (SYLBER_OPT_GEMM_TILE is per handle: the parity tests force one id on
@@ -1039,8 +1040,9 @@ struct TileModel {
         const GemmArgs& a = *this->a;
         int m;
         switch (cfg) {
-            case 13: case 14: case 15: case 16: case 46: case 47: m = cfg; break;
-            case 1: case 2: case 3: case 5: m = 15; break;
+            case 13: case 14: case 15: case 16: case 17: case 46: case 47: m = cfg; break;
+            case 1: m = 17; break;
+            case 2: case 3: case 5: m = 15; break;
             case 6: m = 16; break;
             case 51: case 57: m = 46; break;
             case 10: case 30: case 40: case 41: case 60: case 80: case 85: case 95: case 97: case 98: m = 47; break;
@@ -1053,7 +1055,7 @@ struct TileModel {
         const GemmArgs& a = *this->a;
         const TileCfg& c = cfgs[i];
         if (c.id < 0) return 1e300;
-        if (m16) { if (!gemm_asm16_has_tile(EPI, a, c.id)) return 1e300; }
+        if (m16) { if (!gemm_asm16_has_tile(EPI, a, c.id) || (c.id == 17 && a.tune_model == 6)) return 1e300; }
         else if (c.id == 1 || c.id == 2) { if (split || a.tune_model == 6) return 1e300; }    // (the split16 mode instantiates three tile shapes; model 6 = the round-6a choice, A/B)
         else if (i >= 3 && (!asm_ok || !gemm_asm_has_tile(EPI, a, c.id))) return 1e300;   // only tiles that exist for this epilogue / format
         if ((c.id == 51 || c.id == 57 || c.id == 46) && (a.tune_h192 < 0 || r5)) return 1e300;

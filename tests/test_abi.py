@@ -107,7 +107,7 @@ def test_gemm_tile_cost_model_picks():
     QK, RESLN, BF16, GELU = 3, 6, 0, 1
     M = 32 * 512                                           # 32 x 10 s: 64 row tiles of 256
     # the headline batch: exactly 3 rounds (FFN1, q,k,v) / 1 round (out-proj, FFN2) of 256 tiles
-    # (16-bit-output launches: the v_mfma_f32_16x16x32 family, the model offers ids 14 / 15 / 46 / 47; model + 100 = SYLBER_OPT_GEMM_MFMA16 -1, the 32x32x16 kernels)
+    # (16-bit-output launches: the v_mfma_f32_16x16x32 family, the model offers ids 14 / 15 / 17 / 46 / 47; model + 100 = SYLBER_OPT_GEMM_MFMA16 -1, the 32x32x16 kernels)
     assert pick(M, 3072, 768, BF16, GELU, 0, 0, 0) == 47 and pick(M, 3072, 768, BF16, GELU, 0, 5, 0) == 47
     assert pick(M, 3072, 768, BF16, GELU, 0, 100, 0) == 97 and pick(M, 3072, 768, BF16, GELU, 0, 105, 0) == 97
     assert pick(M, 768, 3072, RESLN, 0, 0, 0, 0) == 91 and pick(M, 768, 3072, RESLN, 0, 0, 5, 0) == 91
@@ -128,12 +128,15 @@ def test_gemm_tile_cost_model_picks():
     assert pick(1024, 2304, 768, QK, 0, 0, 0, 0) == 2 and pick(2048, 768, 3072, RESLN, 0, 0, 0, 0) == 1 and pick(2048, 2304, 768, QK, 0, 0, 0, 0) == 3
     assert pick(512, 768, 3072, RESLN, 0, 0, 6, 0) == 51 and pick(8192, 768, 3072, RESLN, 0, 0, 0, 0) == 3
     # small batches of the 16-bit-output role: the 128x128 tile on eight waves
-    assert pick(512, 3072, 768, BF16, GELU, 0, 0, 0) == 15 and pick(2048, 512, 1536, BF16, GELU, 0, 0, 1) == 15 and pick(512, 3072, 768, BF16, GELU, 0, 100, 0) in (1, 2, 3, 4)
+    assert pick(1024, 3072, 768, BF16, GELU, 0, 0, 0) == 15 and pick(8192, 512, 1536, BF16, GELU, 0, 0, 1) == 15 and pick(512, 3072, 768, BF16, GELU, 0, 100, 0) in (1, 2, 3, 4)
+    # ... and its 64x64 three-slot form where a launch has at most ~one tile per workgroup slot (the conv layers of one or two clips)
+    assert pick(2048, 512, 1536, BF16, GELU, 0, 0, 1) == 17 and pick(1024, 512, 1024, BF16, GELU, 0, 0, 0) == 17 and pick(512, 3072, 768, BF16, GELU, 0, 0, 0) == 17
+    assert pick(2048, 512, 1536, BF16, GELU, 0, 6, 1) == 47
     # fp16 has the same tiles for the epilogues its forward launches
     assert pick(M, 768, 3072, RESLN, 0, 1, 0, 0) == 91 and pick(ML, 768, 3072, RESLN, 0, 1, 0, 0) == 51
     # every answer is a tile id that exists
     for m in (256, 1000, 6144, 12288, 16384, 24064, 49152):
         for (n, k, e, a) in ((2304, 768, QK, 0), (768, 768, RESLN, 0), (3072, 768, BF16, GELU), (768, 3072, RESLN, 0), (512, 1024, BF16, GELU)):
             for model in (0, 5, 100, 105):
-                ids = (14, 15, 46, 47) if (e == BF16 and model < 100) else (1, 2, 3, 4, 10, 85, 91, 97, 86, 51, 57, 80, 90, 95)
+                ids = (14, 15, 17, 46, 47) if (e == BF16 and model < 100) else (1, 2, 3, 4, 10, 85, 91, 97, 86, 51, 57, 80, 90, 95)
                 assert pick(m, n, k, e, a, 0, model, 0) in ids, (m, n, k, e, model)

@@ -241,13 +241,13 @@ def test_mfma16_family(lib):
     from sylber_amd import _lib
     g = torch.Generator().manual_seed(47)
     for (M, N, K, act) in [(700, 768, 768, 1), (1000, 512, 1536, 1), (333, 3072, 768, 0), (257, 768, 3072, 1), (16384, 3072, 768, 1), (4096, 4096, 4096, 0),
-                           (24064, 3072, 768, 1), (130, 512, 64, 1)]:
+                           (24064, 3072, 768, 1), (130, 512, 64, 1), (200, 512, 128, 1), (200, 512, 192, 0), (300, 768, 256, 1)]:
         a = torch.randn(M, K, generator=g)
         w = torch.randn(N, K, generator=g) / K ** 0.5
         b = torch.randn(N, generator=g)
         ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
         outs = {}
-        for cfg in (47, 97, 46, 13, 14, 15, 16, 47, 9047):
+        for cfg in (47, 97, 46, 13, 14, 15, 16, 17, 47, 9047):
             if K < 256 and cfg in (46, 47, 97, 9047):
                 continue                                     # the generated loops need four K steps; the small tiles take any K % 64 == 0
             c = torch.full((M, N), float("nan"), device="cuda")
@@ -277,11 +277,11 @@ def test_mfma16_role_16bit_outputs(lib):
         a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
         ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
         outs = {}
-        for tile in (-1, 47, 46, 13, 14, 15, 16, 97, 57, 3, 4, 10, 85, 91, 1000097, 1000004, 1000999):
+        for tile in (-1, 47, 46, 13, 14, 15, 16, 17, 1, 97, 57, 3, 4, 10, 85, 91, 1000097, 1000004, 1000999):
             c = torch.full((M, N), -1, dtype=torch.int16, device="cuda")
             _lib.check(lib.sylber_op_linear16(_p(ad), _p(wd), _p(bd), _p(c), M, N, K, 1, 0, tile, None), "op_linear16")
             outs[tile] = c
-        for tile in (47, 46, 13, 14, 15, 16, 97, 57, 3, 4, 10, 85, 91):
+        for tile in (47, 46, 13, 14, 15, 16, 17, 1, 97, 57, 3, 4, 10, 85, 91):
             assert torch.equal(outs[tile], outs[-1]), (tile, M, N, K)
         assert torch.equal(outs[1000097], outs[1000004]) and torch.equal(outs[1000097], outs[1000999]), (M, N, K)
         f, l = outs[-1].view(torch.bfloat16).float(), outs[1000097].view(torch.bfloat16).float()
@@ -297,7 +297,7 @@ def test_mfma16_role_16bit_outputs(lib):
         xd = x.cuda()
         wc = w.contiguous()
         ys = {}
-        for tile in (-1, 47, 13, 14, 15, 16, 1000097):
+        for tile in (-1, 47, 13, 14, 15, 16, 17, 1000097):
             y = torch.full((M, 512), -1, dtype=torch.int16, device="cuda")
             _lib.check(lib.sylber_op_conv3(_p(xd), ctypes.c_void_p(wc.data_ptr()), _p(y), R, M, tile, None), "op_conv3")
             ys[tile] = y
