@@ -126,6 +126,15 @@ int64_t sylber_ingest_workspace_bytes(int32_t sr_in);
 int sylber_ingest(const void* pcm_dev, int32_t sample_width, int32_t channels, int64_t frames_in, int32_t sr_in,
                   int32_t normalize, float* wav_out_dev, void* workspace_dev, void* stream);
 
+/* FLAC container -> interleaved integer PCM on the HOST (torchaudio.load at sylber.py:83 decodes .flac files too; the reference's data code falls back from .wav to
+ * .flac, sylber/dataset/collective_audio_segment.py:61-67).  A FLAC stream is a serial bit-granular entropy code: host work, like the RIFF header parse; the decoded
+ * samples then go through sylber_ingest as 16- or 32-bit PCM scaled to full range.  data = the whole file in memory (an ID3v2 tag in front is skipped).
+ * sylber_flac_info: sample rate, channels, bits per sample (4..32), frames (0 = the encoder did not know).  sylber_flac_decode: out_host [capacity_frames][channels] int32 at
+ * the samples' own scale, or NULL to verify and count only; every frame's CRC-8 / CRC-16 is checked and, when STREAMINFO carries the encoder's MD5 of the unencoded audio,
+ * the decoded PCM against it.  Stateless, no device is touched.  Parity unpinned (no codec / FLAC file in the build image): csrc/flac_host.hip restates RFC 9639. */
+int sylber_flac_info(const uint8_t* data_host, int64_t size, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample, int64_t* frames);
+int sylber_flac_decode(const uint8_t* data_host, int64_t size, int32_t* out_host, int64_t capacity_frames, int64_t* frames_out);
+
 /* ---- the two callers right behind the path, on device-resident outputs of sylber_segment --- */
 /* N4: k-means tokenisation, KMQuantizer.get_indices (sylber/model/quantizer.py:86-111; codebook look-up of
  * vector_quantize_pytorch's EuclideanCodebook: argmin_c ||x - c||, first index on ties).

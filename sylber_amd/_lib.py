@@ -67,6 +67,8 @@ EXPORTS = {
     "sylber_ingest_num_frames": (c_int64, [c_int64, c_int32]),
     "sylber_ingest_workspace_bytes": (c_int64, [c_int32]),
     "sylber_ingest": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "sylber_flac_info": (c_int, [c_void_p, c_int64, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
+    "sylber_flac_decode": (c_int, [c_void_p, c_int64, c_void_p, c_int64, POINTER(c_int64)]),
     "sylber_km_workspace_floats": (c_int64, [c_int32, c_int32, c_int32]),
     "sylber_km_assign": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "sylber_km_decode": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

@@ -25,7 +25,7 @@ GEN_DIR = os.path.join(HERE, "build", "gen")           # generated inline-asm lo
 GEN_EXP_DIR = os.path.join(HERE, "build", "gen_exp")   # the knock-out / timing variants of the experiments build: their own directory, so that
                                                        # they neither ship with the product snapshot nor age the product's objects
 GENERATORS = [os.path.join(os.path.dirname(HERE), "tools", g) for g in ("gen_gemm_asm.py", "gen_attn_asm.py")]
-SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip", "gemm_rowln.hip", "gemm_asm.hip", "gemm_asm_f8.hip", "gemm_asm16.hip"]
+SOURCES = ["api.hip", "gemm_bf16.hip", "frontend.hip", "attention.hip", "posconv.hip", "segment.hip", "fp32_path.hip", "ingest.hip", "gemm_mxfp8.hip", "downstream.hip", "gemm_rowln.hip", "gemm_asm.hip", "gemm_asm_f8.hip", "gemm_asm16.hip", "flac_host.hip"]
 EXTRA = {"segment.hip": ["-ffp-contract=off"]}
 # -fno-slp-vectorize: NO packed-fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the library.  Measured on
 # MI355X / ROCm 7.2 (profiles/r02_packed_f32_hazard.md): a wave running dependent packed-fp32 chains returns wrong values

@@ -25,12 +25,12 @@ class PcmFile(NamedTuple):
 def read_pcm(path: str) -> PcmFile:
     """RIFF/WAVE header parse + one read of the data chunk; no sample arithmetic on the host.  Integer PCM
     (WAVE_FORMAT_PCM, 8/16/24/32 bit), IEEE float (WAVE_FORMAT_IEEE_FLOAT, 32/64 bit) and WAVE_FORMAT_EXTENSIBLE
-    wrappers of either -- what ``torchaudio.load`` reads from a ``.wav`` (sylber.py:83).  Compressed containers
-    (flac / mp3 / ogg, which torchaudio decodes through ffmpeg / sox) are NOT supported: ValueError."""
+    wrappers of either -- what ``torchaudio.load`` reads from a ``.wav`` (sylber.py:83).  FLAC goes through ``read_flac``; other compressed
+    containers (mp3 / ogg, which torchaudio decodes through ffmpeg / sox) are NOT supported: ValueError."""
     with open(str(path), "rb") as f:
         head = f.read(12)
         if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
-            raise ValueError("%s is not a RIFF/WAVE file (compressed containers are not supported)" % path)
+            raise ValueError("%s is neither a RIFF/WAVE nor a FLAC file (other containers are not supported: decode them yourself and pass wav= tensors)" % path)
         fmt = None
         raw = None
         while True:
@@ -65,6 +65,41 @@ def read_pcm(path: str) -> PcmFile:
     return PcmFile(np.frombuffer(raw, dtype=np.uint8, count=n * bps).copy(), int(sr), int(nch), int(width), int(n))
 
 
+def read_flac(path: str) -> PcmFile:
+    """FLAC -> the PcmFile the device path takes: the bitstream is decoded on the host by the library (csrc/flac_host.hip: frame CRCs and the encoder's MD5 of the
+    audio are verified), the samples are handed over as 16-bit (up to 16 bits per sample) or 32-bit PCM scaled to full range -- the integer -> float conversion,
+    resampling and normalisation stay on the device, and the floats are the ones ``torchaudio.load`` returns for the file (sample / 2^(bits - 1))."""
+    lib = _lib.load()
+    raw = np.fromfile(str(path), dtype=np.uint8)
+    sr, nch, bps, frames = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+    _lib.check(lib.sylber_flac_info(raw.ctypes.data_as(ctypes.c_void_p), raw.size, ctypes.byref(sr), ctypes.byref(nch), ctypes.byref(bps), ctypes.byref(frames)),
+               "sylber_flac_info(%s)" % path)
+    n = int(frames.value)
+    got = ctypes.c_int64()
+    if n == 0:                                               # length unknown to the encoder: one verifying pass to count
+        _lib.check(lib.sylber_flac_decode(raw.ctypes.data_as(ctypes.c_void_p), raw.size, None, 0, ctypes.byref(got)), "sylber_flac_decode(%s)" % path)
+        n = int(got.value)
+    if n < 1:
+        raise ValueError("%s holds no audio frames" % path)
+    pcm = np.empty((n, nch.value), dtype=np.int32)
+    _lib.check(lib.sylber_flac_decode(raw.ctypes.data_as(ctypes.c_void_p), raw.size, pcm.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(got)),
+               "sylber_flac_decode(%s)" % path)
+    if bps.value <= 16:
+        data, width = (pcm << (16 - bps.value)).astype("<i2"), 2
+    else:
+        data, width = (pcm.astype(np.int64) << (32 - bps.value)).astype("<i4"), 4
+    return PcmFile(np.frombuffer(data.tobytes(), dtype=np.uint8).copy(), int(sr.value), int(nch.value), width, n)
+
+
+def read_audio(path: str) -> PcmFile:
+    """RIFF/WAVE or FLAC, by the file's first bytes (an ID3v2 tag may precede a FLAC stream); anything else: ValueError naming the format problem"""
+    with open(str(path), "rb") as f:
+        head = f.read(4)
+    if head == b"fLaC" or head[:3] == b"ID3":
+        return read_flac(path)
+    return read_pcm(path)
+
+
 def num_frames_16k(frames: int, sample_rate: int) -> int:
     return int(_lib.load().sylber_ingest_num_frames(int(frames), int(sample_rate)))
 
@@ -93,4 +128,4 @@ def ingest_pcm(pcm: PcmFile, device, normalize: bool = True) -> torch.Tensor:
 
 
 def ingest_file(path: str, device, normalize: bool = True) -> torch.Tensor:
-    return ingest_pcm(read_pcm(path), device, normalize)
+    return ingest_pcm(read_audio(path), device, normalize)
