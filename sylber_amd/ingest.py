@@ -81,6 +81,8 @@ def read_flac(path: str) -> PcmFile:
         n = int(got.value)
     if n < 1:
         raise ValueError("%s holds no audio frames" % path)
+    if n > raw.size * 8192:                                   # (a block of 65535 constant samples takes ~14 bytes: no stream holds more per byte)
+        raise ValueError("%s: STREAMINFO claims %d frames in %d bytes" % (path, n, raw.size))
     pcm = np.empty((n, nch.value), dtype=np.int32)
     _lib.check(lib.sylber_flac_decode(raw.ctypes.data_as(ctypes.c_void_p), raw.size, pcm.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(got)),
                "sylber_flac_decode(%s)" % path)
