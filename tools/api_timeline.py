@@ -1,4 +1,4 @@
-"""host timeline of one Segmenter.__call__ (32 x 10 s host tensors): where the call's milliseconds go"""
+"""host timeline of one Segmenter.__call__ (N x 10 s host tensors, N = argv[1] or 32): where the call's milliseconds go"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,7 +6,8 @@ from sylber_amd import Segmenter
 from sylber_amd.synth import noise_batch
 from sylber_amd.weights import synthetic_state_dict
 S = Segmenter(model_ckpt=synthetic_state_dict(0))
-wavs = [w[None, :].clone() for w in noise_batch(32, 160000, seed=1000)]
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+wavs = [w[None, :].clone() for w in noise_batch(NB, 160000, seed=1000)]
 for _ in range(3):
     S(wav=wavs)
 runs, gruns = [], []
