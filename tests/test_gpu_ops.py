@@ -234,7 +234,8 @@ def test_conv3_layer_every_tile(lib):
 
 
 def test_mfma16_family(lib):
-    """the v_mfma_f32_16x16x32 family (csrc/gemm_asm16.hip: tiles 13 / 14 hipcc-scheduled two per CU, 46 / 47 generated loops) -- the kernels the
+    """the v_mfma_f32_16x16x32 family (csrc/gemm_asm16.hip: tiles 13 / 14 hipcc-scheduled two per CU on four waves, 15 / 16 the same on eight, 17 = 64x64 on a
+    three-slot ring -- incl. K of one to four K steps, where its prologue paths differ --, 46 / 47 generated loops) -- the kernels the
     16-bit-output GEMMs (conv1-5 TP:154-213, FFN1 TP:347-368) run on by default.  An output element's fp32 chain adds 32-k blocks where the
     32x32x16 kernels add 16-k blocks, so: every member gives the SAME bits (whole and ragged tiles, several rounds of the persistent walk, with and
     without GELU), run to run; against torch at the tolerance of the other tiles; against tile 97 within fp32 accumulation noise"""
