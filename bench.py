@@ -97,6 +97,8 @@ def parse_args():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `other_configs` block (BASELINE configs[3] long-form, configs[4] fp8 and the split16 parity mode, "
                          "10 steps each in this same process after the headline run; N = 1, default workload only)")
+    ap.add_argument("--exchange-root-copies", action="store_true", help="A/B: root's own share goes through the collectives' device-to-device copies as in rounds 2-6a "
+                    "(default since round 6: root computes on a view of its chunk and writes its results straight into the gathered tensors; ShardedSegmenter.inplace_root)")
     ap.add_argument("--exchange-lookahead", type=int, default=0, help="A/B: batches ahead the input exchange is issued (0 = default = engines in flight; 1 = round 5)")
     ap.add_argument("--exchange-ingest-stream", choices=["default", "own", "engine"], default="default",
                     help="A/B: the input exchange under its own stream (default) or under the consuming engine's stream (round 5)")
@@ -602,6 +604,8 @@ def main():
         sharded.side_delay = args.exchange_side_delay
     if args.exchange_lookahead > 0:
         sharded.lookahead = args.exchange_lookahead
+    if args.exchange_root_copies:
+        sharded.inplace_root = False
     if args.exchange_ingest_stream != "default":
         sharded.ingest_stream = args.exchange_ingest_stream == "own"
     root_batch = None
@@ -747,7 +751,7 @@ def main():
                       "scatter_bytes_per_step_root": st_["scatter_bytes"] // max(st_["steps"], 1),
                       "gather_bytes_per_step_root": st_["gather_bytes"] // max(st_["steps"], 1),
                       "h2d_bytes_per_step_rank0": st_["h2d_bytes"] // max(st_["steps"], 1),
-                      "ingest": args.ingest,
+                      "ingest": args.ingest, "root_share": "through the collectives' copies" if args.exchange_root_copies else "in place (no copy of root's own rows)",
                       "host_issue_ms_per_step_by_phase_rank0": {k_: round(1e3 * v_ / max(st_["steps"], 1), 3) for k_, v_ in st_["host_s"].items()},
                       # a hipMalloc inside the timed steps synchronises the device (the caching allocator could not reuse a block that another
                       # stream still holds): must be 0 in steady state

@@ -84,6 +84,11 @@ class ShardedSegmenter:
         # that round 6 chased through allocators, streams and hardware queues (profiles/r06_exchange.md); frozen, a collection only walks what the
         # loop itself created
         self.freeze_gc = True
+        # Round 6, second half: ROOT'S OWN SHARE does not go through the collectives' copies.  Root computes on a view of its chunk of the batch (that view is also
+        # entry 0 of the scatter list) and its engine writes straight into slot 0 of the gathered tensors (that view is also the gather's input): the collective's
+        # own-rank step is `out.copy_(in)` with out IS in -- a no-op -- instead of a 20 MB + 68 MB device-to-device copy per step beside the GEMMs.  Same protocol for
+        # every other rank (still one scatter and four gathers per step).  False: rounds 2-6a (A/B switch; bench.py --exchange-root-copies).
+        self.inplace_root = True
         self.reset_stats()
 
     def consumer_stream(self):
@@ -183,8 +188,17 @@ class ShardedSegmenter:
         return self.gather(hidden, seg, nseg, feats, btot)
 
     # ---- overlapped stream of batches --------------------------------------------------------------
+    def full_results(self, bper: int, T: int, max_segments: int, ring_set=None, rbuf=None, ring_results: bool = False):
+        """root: the four gathered tensors of one step, allocated BEFORE its forward so that the engine can write root's own rows into slot 0
+        (hidden states [W * bper, T, 768], tables [W * bper, k, 2], counts [W * bper], pooled features [W * bper, k, 768])"""
+        W, k = self.world, max(1, min(int(max_segments), T))
+        shapes = (((W * bper, T, 768), torch.float32), ((W * bper, k, 2), torch.int64), ((W * bper,), torch.int32), ((W * bper, k, 768), torch.float32))
+        if ring_results and ring_set is not None and rbuf is not None:
+            return [rbuf(ring_set, "full%d" % j, shp, dt) for j, (shp, dt) in enumerate(shapes)]
+        return [torch.empty(shp, dtype=dt, device=self.device) for shp, dt in shapes]
+
     def gather_async(self, hidden, seg, nseg, feats, btot: int, max_segments: int, check: bool = True, ring_set=None, rbuf=None,
-                     ring_results: bool = False):
+                     ring_results: bool = False, fulls_pre=None):
         """Like ``gather`` but with asynchronous collectives and WITHOUT the host round trip that trims the pooled
         features to the global max segment count: the first ``max_segments`` slots are exchanged instead.  Returns a
         zero-argument ``wait`` function.  An utterance with more segments than that is an error: with ``check`` the
@@ -192,7 +206,18 @@ class ShardedSegmenter:
         count ONCE after its loop (``wait.nmax`` = device scalar), so that no step contains a host synchronisation."""
         W = self.world
         k = max(1, min(int(max_segments), seg.shape[1]))
-        if ring_set is not None and rbuf is not None:
+        bper_ = hidden.shape[0]
+        if fulls_pre is not None:
+            # root, in place: `hidden` IS slot 0 of the gathered hidden states (the engine wrote it there); the packed tables / counts / features are written
+            # into slot 0 of theirs; each gather's input is then the very tensor that is entry 0 of its output list
+            assert self.rank == 0 and hidden.data_ptr() == fulls_pre[0].data_ptr()
+            seg_k, nseg_v, feats_k = fulls_pre[1][:bper_], fulls_pre[2][:bper_], fulls_pre[3][:bper_]
+            seg_k.copy_(seg[:, :k])
+            if nseg.data_ptr() != nseg_v.data_ptr():
+                nseg_v.copy_(nseg)
+            feats_k.copy_(feats[:, :k])
+            parts = [hidden, seg_k, nseg_v, feats_k]
+        elif ring_set is not None and rbuf is not None:
             # the packed [:, :k] copies go into the set's own buffers (run_stream's ring: no allocation in steady state)
             seg_k = rbuf(ring_set, "seg_k", (seg.shape[0], k, 2), seg.dtype)
             seg_k.copy_(seg[:, :k])
@@ -227,11 +252,15 @@ class ShardedSegmenter:
             # root receives straight into the slices of ONE [W * Bper, ...] tensor: no concatenation copy afterwards
             if self.rank != 0:
                 full = None
+            elif fulls_pre is not None:
+                full = fulls_pre[j_]
             elif ring_results and ring_set is not None and rbuf is not None:
                 full = rbuf(ring_set, "full%d" % j_, (W * t.shape[0],) + tuple(t.shape[1:]), t.dtype)
             else:
                 full = torch.empty((W * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             o = list(full.view((W, t.shape[0]) + tuple(t.shape[1:])).unbind(0)) if self.rank == 0 else None
+            if fulls_pre is not None:
+                o[0] = t                                         # the same tensor object: the collective's own-rank copy is out.copy_(out)
             works.append(dist.gather(t, o, dst=0, group=self.group, async_op=True))
             fulls.append(full)
             nb = t.numel() * t.element_size()
@@ -342,6 +371,9 @@ class ShardedSegmenter:
 
         def ring_set(i):
             return ring.setdefault((i % E_, (i // E_) % RING_DEPTH), {"works": None})
+        # root's own share in place (self.inplace_root): the gathered tensors of a step exist before its forward
+        inplace = bool(self.inplace_root) and self.rank == 0 and self._coll and gather == "root"
+        pre_by_step = {}
 
         def rbuf(d, key, shape, dtype):
             numel = 1
@@ -374,6 +406,8 @@ class ShardedSegmenter:
                 full = batches[i] if pad == 0 else torch.cat(
                     [batches[i], torch.zeros(pad, lmax, dtype=torch.float32, device=self.device)], 0)
                 chunks = list(full.contiguous().view(W, bper, lmax).unbind(0))
+            if self.rank == 0 and self.inplace_root:
+                my_wav = chunks[0]                               # the scatter's own-rank copy becomes out.copy_(out); the engine reads the caller's rows
             self.phase = "scatter of batch %d (root -> ranks, %d bytes per rank)" % (i, my_wav.numel() * 4)
             dist.scatter(my_wav, chunks, src=0, group=self.group)
             return my_wav, mine, btot
@@ -472,7 +506,7 @@ class ShardedSegmenter:
                     if rs is not None and reuse_results and rs.get("consumed") is not None:
                         self._sides[k].wait_event(rs["consumed"])   # the caller's queued work on the results this gather overwrites
                     wait = self.gather_async(hidden, seg, nseg, feats, btot, max_segments, check=False, ring_set=rs, rbuf=rbuf if rs is not None else None,
-                                             ring_results=reuse_results)
+                                             ring_results=reuse_results, fulls_pre=pre_by_step.pop(i, None))
                     if rs is not None:
                         rs["works"] = getattr(wait, "works", None)
                         wait.ring_set = rs
@@ -510,9 +544,22 @@ class ShardedSegmenter:
                                     wk.wait()                                # (stream-side wait of the engine's stream; long done in steady state)
                                 rs["works"] = None
                             T_ = eng.num_frames(my_wav.shape[1])
-                            hidden = eng.forward(my_wav, [int(x) for x in my_lens], out=rbuf(rs, "hid", (my_wav.shape[0], T_, 768), torch.float32))
+                            fp_ = None
+                            if inplace:
+                                if reuse_results and rs.get("consumed") is not None:
+                                    self._streams[k].wait_event(rs["consumed"])     # the caller's queued work on the results this forward overwrites
+                                fp_ = self.full_results(my_wav.shape[0], T_, max_segments, rs, rbuf, reuse_results)
+                                hidden = eng.forward(my_wav, [int(x) for x in my_lens], out=fp_[0][:my_wav.shape[0]])
+                            else:
+                                hidden = eng.forward(my_wav, [int(x) for x in my_lens], out=rbuf(rs, "hid", (my_wav.shape[0], T_, 768), torch.float32))
+                            pre_by_step[i] = fp_
                         else:
                             hidden = eng.forward(my_wav, [int(x) for x in my_lens])
+                            if inplace:                                      # an engine without out= (the CPU engines of the gloo tests): one copy into slot 0
+                                fp_ = self.full_results(hidden.shape[0], hidden.shape[1], max_segments)
+                                fp_[0][:hidden.shape[0]].copy_(hidden)
+                                hidden = fp_[0][:hidden.shape[0]]
+                                pre_by_step[i] = fp_
                         ready = None
                         if self._cuda:
                             ready = torch.cuda.Event()

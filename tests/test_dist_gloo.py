@@ -74,6 +74,16 @@ def _worker(rank, world, port, q):
     S2 = ShardedSegmenter([S.engine, OracleEngine(sd)], norm_threshold=2.6, merge_threshold=0.8)
     streamed2 = list(S2.run_stream(batches, lens, max_segments=64))
     ok = True
+    # root's own share in place (round 6: root computes on a view of its chunk, its results are written straight into slot 0 of the gathered tensors, the
+    # collectives' own-rank copies become out.copy_(out)) against the copying form of rounds 2-6a: same results, and the caller's batches are left untouched
+    keep = [None if b is None else b.clone() for b in batches]
+    S.inplace_root = False
+    legacy = list(S.run_stream(batches, lens, max_segments=64))
+    S.inplace_root = True
+    if rank == 0:
+        for a, b in zip(streamed, legacy):
+            ok &= all(torch.equal(x, y) for x, y in zip(a, b))
+        ok &= all(torch.equal(x, y) for x, y in zip(batches, keep))
     # counters of the stream of batches (what the N > 1 bench line reports): three steps, both directions counted
     st = S.stats
     ok &= st["steps"] >= 3 and st["wait_s"] >= 0.0 and st["gather_bytes"] > 0 and st["scatter_bytes"] > 0
