@@ -104,8 +104,11 @@ def parse_args():
                     help="A/B: the input exchange under its own stream (default) or under the consuming engine's stream (round 5)")
     ap.add_argument("--gc-in-timing", action="store_true", help="A/B: leave Python's cyclic garbage collector enabled inside the timed regions")
     ap.add_argument("--exchange-side-delay", type=int, default=-1, help="A/B: iterations by which run_stream issues a batch's side-stream work late (default 1; 0 = rounds 2-5)")
-    ap.add_argument("--exchange-default-stream", action="store_true",
-                    help="A/B: consume the exchange steps on the process's default stream (rounds 2-5) instead of ShardedSegmenter.consumer_stream()")
+    ap.add_argument("--exchange-consumer-stream", action="store_true",
+                    help="A/B: the exchange loop's consumer (the waits for each batch's gather, the events that time the steps) under a stream of its own "
+                         "(ShardedSegmenter.consumer_stream; rounds 6a) instead of the process's current stream (default since the second half of round 6: with "
+                         "root's share in place the dedicated stream costs +5-7 % against +2.6-3.3 %, profiles/r06_exchange.md section 7)")
+    ap.add_argument("--exchange-default-stream", action="store_true", help="(the default now; kept so that older command lines still parse)")
     ap.add_argument("--exchange-fresh-results", action="store_true",
                     help="A/B: the gathered tensors of every step freshly allocated (run_stream's default) instead of from its buffer ring "
                          "(reuse_results=True: valid until 2 x engines - 1 further batches have been yielded)")
@@ -631,7 +634,7 @@ def main():
         # consumed under a stream of its own: the default stream shares a hardware queue with one of the pipeline's streams more often than not, and
         # every batch handed over puts a wait for its gather into the consumer's stream (ShardedSegmenter.consumer_stream)
         import contextlib as _cl
-        cons = sharded.consumer_stream() if not args.exchange_default_stream else None
+        cons = sharded.consumer_stream() if args.exchange_consumer_stream else None
         with (torch.cuda.stream(cons) if cons is not None else _cl.nullcontext()):
             _exchange_loop(src, n, evs)
         host_issue["s"], host_issue["n"] = time.perf_counter() - t_issue0, n
