@@ -107,7 +107,7 @@ def parse_args():
     ap.add_argument("--exchange-consumer-stream", action="store_true",
                     help="A/B: the exchange loop's consumer (the waits for each batch's gather, the events that time the steps) under a stream of its own "
                          "(ShardedSegmenter.consumer_stream; rounds 6a) instead of the process's current stream (default since the second half of round 6: with "
-                         "root's share in place the dedicated stream costs +5-7 % against +2.6-3.3 %, profiles/r06_exchange.md section 7)")
+                         "root's share in place the dedicated stream costs +5-7 %% against +2.6-3.3 %%, profiles/r06_exchange.md section 7)")
     ap.add_argument("--exchange-default-stream", action="store_true", help="(the default now; kept so that older command lines still parse)")
     ap.add_argument("--exchange-fresh-results", action="store_true",
                     help="A/B: the gathered tensors of every step freshly allocated (run_stream's default) instead of from its buffer ring "
